@@ -1,0 +1,133 @@
+// Selective-scan forward at the reference operator boundary (drop-in for
+// selective_scan_cuda_oflex.fwd: reference kernels/selective_scan/csrc/selective_scan/cusoflex/
+// selective_scan_oflex.cpp:143-231 and selective_scan_fwd_kernel_oflex.cuh:67-181).
+//
+// Layout (all float32, L contiguous): u, delta (B, D, L) [delta may be (B, Dd, L), D % Dd == 0];
+// A (D, N); Bm, Cm (B, G, N, L); Dv, delta_bias optional; out (B, D, L); last_state (B, D, N).
+//
+// CDNA4 mapping: one 64-lane wave owns one (batch, channel) row and walks it in 256-element
+// chunks (4 contiguous floats per lane = one 16-B load per operand per lane, 1 KiB per wave
+// instruction).  The linear recurrence h_l = a_l h_{l-1} + b_l is evaluated as a scan of
+// (a, b) pairs with op (a1*a0, a1*b0 + b1): 4 items serially per lane, 6 shuffle steps across
+// the wave, and a register carry between chunks.  No LDS, no barriers; HBM-bound.
+#include "xp_common.h"
+
+namespace {
+
+constexpr int kItems = 4;
+constexpr int kChunk = 64 * kItems;
+
+template <bool VEC>
+__device__ __forceinline__ void load4(const float* __restrict__ p, int64_t off, int rem, float (&v)[kItems], float fill) {
+    if (VEC && rem >= kItems) {
+        float4 t = *reinterpret_cast<const float4*>(p + off);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) v[i] = (i < rem) ? p[off + i] : fill;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void selective_scan_fwd_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv,
+    const float* __restrict__ delta_bias, float* __restrict__ out, float* __restrict__ last_state,
+    int batch, int dim, int delta_dim, int L, int N, int G, int softplus) {
+    __shared__ float carry[4][256];  // per-wave running state for N > 1 (MAX_DSTATE 256 as the reference)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)batch * dim) return;
+    const int b = (int)(row / dim), d = (int)(row % dim);
+    const int g = d / (dim / G);
+    const int dd = d / (dim / delta_dim);
+    const float* up = u + row * L;
+    const float* dp = delta + ((int64_t)b * delta_dim + dd) * L;
+    const float* Bp = Bm + ((int64_t)b * G + g) * N * L;
+    const float* Cp = Cm + ((int64_t)b * G + g) * N * L;
+    float* op = out + row * L;
+    const float Dval = Dv ? Dv[d] : 0.f;
+    const float bias = delta_bias ? delta_bias[dd] : 0.f;
+    float h1 = 0.f;  // carry for N == 1
+    for (int n = lane; n < N; n += 64) carry[wave][n] = 0.f;
+
+    for (int c0 = 0; c0 < L; c0 += kChunk) {
+        const int off = c0 + lane * kItems;
+        const int rem = L - off;  // may be <= 0
+        float uv[kItems], dv[kItems], ov[kItems];
+        load4<VEC>(up, off, rem, uv, 0.f);
+        load4<VEC>(dp, off, rem, dv, 0.f);
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            float t = dv[i] + bias;
+            dv[i] = softplus ? xp_softplus(t) : t;
+            ov[i] = Dval * uv[i];
+        }
+        for (int n = 0; n < N; ++n) {
+            const float An = A[(int64_t)d * N + n];
+            float bv[kItems], cv[kItems];
+            load4<VEC>(Bp + (int64_t)n * L, off, rem, bv, 0.f);
+            load4<VEC>(Cp + (int64_t)n * L, off, rem, cv, 0.f);
+            float la[kItems], lb[kItems];
+            float pa = 1.f, pb = 0.f;
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) {
+                float a = (i < rem) ? expf(dv[i] * An) : 1.f;   // identity past the end keeps last_state right
+                float bb = (i < rem) ? dv[i] * bv[i] * uv[i] : 0.f;
+                pb = a * pb + bb;
+                pa = a * pa;
+                la[i] = pa; lb[i] = pb;
+            }
+            // inclusive wave scan of the per-lane totals
+            float ta = pa, tb = pb;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float ua = __shfl_up(ta, o, 64), ub = __shfl_up(tb, o, 64);
+                if (lane >= o) { tb = ta * ub + tb; ta = ta * ua; }
+            }
+            float ea = __shfl_up(ta, 1, 64), eb = __shfl_up(tb, 1, 64);
+            if (lane == 0) { ea = 1.f; eb = 0.f; }
+            const float hprev = (N == 1) ? h1 : carry[wave][n];
+            const float hin = ea * hprev + eb;          // state entering this lane's first item
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) ov[i] += cv[i] * (la[i] * hin + lb[i]);
+            const float hend = __shfl(ta, 63, 64) * hprev + __shfl(tb, 63, 64);
+            if (N == 1) h1 = hend; else if (lane == 0) carry[wave][n] = hend;
+        }
+        if (VEC && rem >= kItems) {
+            *reinterpret_cast<float4*>(op + off) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) if (i < rem) op[off + i] = ov[i];
+        }
+    }
+    if (last_state) {
+        if (N == 1) { if (lane == 0) last_state[row] = h1; }
+        else for (int n = lane; n < N; n += 64) last_state[row * N + n] = carry[wave][n];
+    }
+}
+
+}  // namespace
+
+extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
+                                     const float* Cm, const float* Dv, const float* delta_bias, float* out,
+                                     float* last_state, int batch, int dim, int delta_dim, int seqlen, int dstate,
+                                     int ngroups, int delta_softplus, void* stream) {
+    XP_CHECK_ARG(u && delta && A && Bm && Cm && out, "xp_selective_scan_fwd: null tensor pointer");
+    XP_CHECK_ARG(batch > 0 && dim > 0 && seqlen > 0, "xp_selective_scan_fwd: batch/dim/seqlen must be positive");
+    XP_CHECK_ARG(dstate > 0 && dstate <= 256, "xp_selective_scan_fwd: dstate must be in [1,256] (got %d)", dstate);
+    XP_CHECK_ARG(ngroups > 0 && dim % ngroups == 0, "xp_selective_scan_fwd: dim %% ngroups != 0");
+    XP_CHECK_ARG(delta_dim > 0 && dim % delta_dim == 0, "xp_selective_scan_fwd: dim %% delta_dim != 0");
+    const int64_t rows = (int64_t)batch * dim;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (seqlen % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)Bm | (uintptr_t)Cm | (uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(selective_scan_fwd_kernel<true>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
+                           last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
+    else
+        hipLaunchKernelGGL(selective_scan_fwd_kernel<false>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
+                           last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}

@@ -1,0 +1,301 @@
+// Fused SS2D core in pixel (NHWC) layout — the MI355X-first form of reference
+// VMamba.py:601-646 (forward_corev2: cross_scan -> x_proj/dt_proj -> selective_scan -> cross_merge ->
+// out_norm) for d_state = 1.
+//
+// The four scan routes (csm_triton.py:22-53) are permutations of the same pixels and x_proj / dt_proj
+// are pointwise in L, so nothing is materialised per route: `xdbl` (M, 4*(R+2)) is ONE GEMM in pixel
+// layout, dt_proj + softplus + exp run inside the scan, and the four routes become four traversals
+// (row-major fwd/bwd, column-major fwd/bwd) of the same NHWC buffers.  With lanes over channels every
+// access is a contiguous C*4-byte segment in either traversal, so the column routes need no transpose.
+//
+// The recurrence is made parallel over L by chunks of T pixels:
+//   pass 1  per (image, route pair, chunk, channel): a-product P and local end state S of both routes
+//   pass 2  per (image, route, channel): sequential carry over chunks -> state entering each chunk
+//   pass 3  per (image, route pair, chunk, channel): re-run with the true start state, forward route
+//           into an LDS tile, backward route added to it; the column pair adds the row pair's result
+//           in the reference's order (y0 + y2) + (y1 + y3) (csm_triton.py:60-62) and applies out_norm
+//           (LayerNorm over C, VMamba.py:644) before the single store.
+// Directions are stored in the order (0, 2, 1, 3) so that a pair's operands are adjacent.
+#include "xp_common.h"
+
+namespace {
+
+struct SS2DParams {
+    const float* u;      // (B, H, W, C)   after dwconv + SiLU
+    const float* xdbl;   // (B*H*W, 4*(R+2))  [pair][dir][dtr(R), B, C]
+    const float* wdt;    // (4, C, R)  order (0,2,1,3)
+    const float* dtb;    // (4, C)
+    const float* A;      // (4, C)    = -exp(A_logs)
+    const float* Dp;     // (4, C)
+    const float* ln_w;   // (C) out_norm
+    const float* ln_b;
+    float* wsP;          // (B, 2, nc, 2, C)
+    float* wsS;          // same; pass 2 overwrites S with the chunk start state
+    float* ya;           // (B, H, W, C) row-pair partial
+    float* out;          // (B, H, W, C)
+    int Bn, H, W, C, T, nc, cpb;
+    float eps;
+};
+
+__device__ __forceinline__ int pixel_of(int l, int L, int H, int W, bool colmajor) {
+    if (l >= L) return -1;
+    if (!colmajor) return l;
+    int w = l / H, h = l - w * H;   // route 1: l = w*H + h   (x.transpose(2,3).flatten)
+    return h * W + w;
+}
+
+template <int R>
+__device__ __forceinline__ void step_vals(const float* __restrict__ xr, const float (&w)[R], float bias, float A,
+                                          float u, float& a, float& b) {
+    float dt = w[0] * xr[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) dt = fmaf(w[r], xr[r], dt);
+    const float delta = xp_softplus(dt + bias);
+    a = expf(delta * A);
+    b = delta * xr[R] * u;
+}
+
+// Shared staging of one block's chunk(s): pixel indices and the xdbl rows of this route pair.
+template <int R>
+__device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair, int chunk0, int* s_pix, float* s_x) {
+    const int L = p.H * p.W;
+    const int npx = p.cpb * p.T;
+    for (int i = threadIdx.x; i < npx; i += blockDim.x) {
+        int cl = i / p.T, ii = i - cl * p.T;
+        int chunk = chunk0 + cl;
+        s_pix[i] = (chunk < p.nc) ? pixel_of(chunk * p.T + ii, L, p.H, p.W, pair == 1) : -1;
+    }
+    __syncthreads();
+    constexpr int XW = 2 * (R + 2);
+    const int XD = 2 * XW;
+    for (int i = threadIdx.x; i < npx * XW; i += blockDim.x) {
+        int pi = i / XW, e = i - pi * XW;
+        int px = s_pix[pi];
+        s_x[i] = (px >= 0) ? p.xdbl[((int64_t)b * L + px) * XD + pair * XW + e] : 0.f;
+    }
+    __syncthreads();
+}
+
+template <int R>
+__global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
+    extern __shared__ __align__(16) char smem[];
+    const int npx = p.cpb * p.T;
+    int* s_pix = reinterpret_cast<int*>(smem);
+    float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * npx);
+    constexpr int XW = 2 * (R + 2);
+    const int b = blockIdx.y, pair = blockIdx.z, chunk0 = blockIdx.x * p.cpb;
+    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_x);
+    const int cl = threadIdx.x / p.C, c = threadIdx.x - cl * p.C;
+    const int chunk = chunk0 + cl;
+    if (chunk >= p.nc) return;
+    const int L = p.H * p.W;
+    float w0[R], w1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * p.C + c) * R + r];
+        w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * p.C + c) * R + r];
+    }
+    const float b0 = p.dtb[(pair * 2 + 0) * p.C + c], b1 = p.dtb[(pair * 2 + 1) * p.C + c];
+    const float A0 = p.A[(pair * 2 + 0) * p.C + c], A1 = p.A[(pair * 2 + 1) * p.C + c];
+    const float* ub = p.u + (int64_t)b * L * p.C + c;
+    float P0 = 1.f, S0 = 0.f, Q1 = 1.f, S1 = 0.f;
+    for (int i0 = 0; i0 < p.T; i0 += 4) {
+        float uv[4];
+        int px[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            px[k] = s_pix[cl * p.T + i0 + k];
+            uv[k] = (px[k] >= 0) ? ub[(int64_t)px[k] * p.C] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (px[k] < 0) continue;
+            const float* xr = s_x + (cl * p.T + i0 + k) * XW;
+            float a, bb;
+            step_vals<R>(xr, w0, b0, A0, uv[k], a, bb);
+            S0 = a * S0 + bb; P0 *= a;
+            step_vals<R>(xr + (R + 2), w1, b1, A1, uv[k], a, bb);
+            S1 = fmaf(Q1, bb, S1); Q1 *= a;     // backward route accumulated in forward order
+        }
+    }
+    const int64_t o = ((((int64_t)b * 2 + pair) * p.nc + chunk) * 2) * p.C + c;
+    p.wsP[o] = P0; p.wsS[o] = S0;
+    p.wsP[o + p.C] = Q1; p.wsS[o + p.C] = S1;
+}
+
+// pass 2: thread per (b, pair, dir, c); sequential over chunks.
+__global__ void ss2d_pass2(SS2DParams p) {
+    const int64_t n = (int64_t)p.Bn * 2 * 2 * p.C;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int c = (int)(t % p.C);
+    const int dir = (int)((t / p.C) % 2);
+    const int bp = (int)(t / (2 * p.C));   // b*2 + pair
+    float h = 0.f;
+    for (int jj = 0; jj < p.nc; ++jj) {
+        const int j = dir ? (p.nc - 1 - jj) : jj;
+        const int64_t o = (((int64_t)bp * p.nc + j) * 2 + dir) * p.C + c;
+        const float P = p.wsP[o], S = p.wsS[o];
+        p.wsS[o] = h;
+        h = fmaf(P, h, S);
+    }
+}
+
+template <int R, bool COLPAIR>
+__global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
+    extern __shared__ __align__(16) char smem[];
+    const int npx = p.cpb * p.T;
+    int* s_pix = reinterpret_cast<int*>(smem);
+    float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * npx);
+    constexpr int XW = 2 * (R + 2);
+    float* s_y = s_x + npx * XW;   // [npx][C]
+    const int pair = COLPAIR ? 1 : 0;
+    const int b = blockIdx.y, chunk0 = blockIdx.x * p.cpb;
+    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_x);
+    const int cl = threadIdx.x / p.C, c = threadIdx.x - cl * p.C;
+    const int chunk = chunk0 + cl;
+    const int L = p.H * p.W;
+    if (chunk < p.nc) {
+        float w0[R], w1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * p.C + c) * R + r];
+            w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * p.C + c) * R + r];
+        }
+        const float b0 = p.dtb[(pair * 2 + 0) * p.C + c], b1 = p.dtb[(pair * 2 + 1) * p.C + c];
+        const float A0 = p.A[(pair * 2 + 0) * p.C + c], A1 = p.A[(pair * 2 + 1) * p.C + c];
+        const float D0 = p.Dp[(pair * 2 + 0) * p.C + c], D1 = p.Dp[(pair * 2 + 1) * p.C + c];
+        const float* ub = p.u + (int64_t)b * L * p.C + c;
+        const int64_t o = ((((int64_t)b * 2 + pair) * p.nc + chunk) * 2) * p.C + c;
+        float h = p.wsS[o];
+        // forward route
+        for (int i0 = 0; i0 < p.T; i0 += 4) {
+            float uv[4];
+            int px[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                px[k] = s_pix[cl * p.T + i0 + k];
+                uv[k] = (px[k] >= 0) ? ub[(int64_t)px[k] * p.C] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (px[k] < 0) continue;
+                const int pi = cl * p.T + i0 + k;
+                const float* xr = s_x + pi * XW;
+                float a, bb;
+                step_vals<R>(xr, w0, b0, A0, uv[k], a, bb);
+                h = a * h + bb;
+                s_y[pi * p.C + c] = xr[R + 1] * h + D0 * uv[k];   // y = C*h + D*u (csms6s.py:61,67)
+            }
+        }
+        // backward route over the same pixels
+        h = p.wsS[o + p.C];
+        const float* prev = COLPAIR ? (p.ya + (int64_t)b * L * p.C + c) : nullptr;
+        float* dst = COLPAIR ? nullptr : (p.ya + (int64_t)b * L * p.C + c);
+        for (int i0 = p.T - 4; i0 >= 0; i0 -= 4) {
+            float uv[4], pv[4];
+            int px[4];
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                px[k] = s_pix[cl * p.T + i0 + k];
+                uv[k] = (px[k] >= 0) ? ub[(int64_t)px[k] * p.C] : 0.f;
+                if (COLPAIR) pv[k] = (px[k] >= 0) ? prev[(int64_t)px[k] * p.C] : 0.f;
+            }
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                if (px[k] < 0) continue;
+                const int pi = cl * p.T + i0 + k;
+                const float* xr = s_x + pi * XW + (R + 2);
+                float a, bb;
+                step_vals<R>(xr, w1, b1, A1, uv[k], a, bb);
+                h = a * h + bb;
+                const float y2 = xr[R + 1] * h + D1 * uv[k];
+                const float tot = s_y[pi * p.C + c] + y2;           // y_fwd + flip(y_bwd)
+                if (COLPAIR) s_y[pi * p.C + c] = pv[k] + tot;      // (y0+y2) + (y1+y3)
+                else dst[(int64_t)px[k] * p.C] = tot;
+            }
+        }
+    }
+    if (!COLPAIR) return;
+    __syncthreads();
+    // out_norm: LayerNorm over C per pixel, one wave per pixel (two-pass mean / variance).
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int pi = wave; pi < npx; pi += nw) {
+        const int px = s_pix[pi];
+        if (px < 0) continue;
+        const float* row = s_y + pi * p.C;
+        float s = 0.f;
+        for (int cc = lane; cc < p.C; cc += 64) s += row[cc];
+        const float mean = xp_wave_sum(s) / (float)p.C;
+        float v = 0.f;
+        for (int cc = lane; cc < p.C; cc += 64) { float d = row[cc] - mean; v = fmaf(d, d, v); }
+        const float rstd = 1.f / sqrtf(xp_wave_sum(v) / (float)p.C + p.eps);
+        float* orow = p.out + ((int64_t)b * L + px) * p.C;
+        for (int cc = lane; cc < p.C; cc += 64) orow[cc] = (row[cc] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+    }
+}
+
+template <int R>
+int launch_ss2d(const SS2DParams& p, hipStream_t s) {
+    constexpr int XW = 2 * (R + 2);
+    const int npx = p.cpb * p.T;
+    const int threads = p.cpb * p.C;
+    const size_t sm1 = sizeof(int) * npx + sizeof(float) * npx * XW;
+    const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * p.C;
+    dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
+    hipLaunchKernelGGL(ss2d_pass1<R>, grid1, dim3(threads), sm1, s, p);
+    const int64_t n2 = (int64_t)p.Bn * 4 * p.C;
+    hipLaunchKernelGGL(ss2d_pass2, dim3(xp_cdiv(n2, 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((ss2d_pass3<R, false>), grid3, dim3(threads), sm3, s, p);
+    hipLaunchKernelGGL((ss2d_pass3<R, true>), grid3, dim3(threads), sm3, s, p);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C) {
+    // P and S: (B, 2, nc, 2, C) each with the smallest chunk (T = 16) -> upper bound; + ya (B,H,W,C)
+    const int64_t L = (int64_t)H * W;
+    const int64_t nc = (L + 15) / 16;
+    return (size_t)(2 * (int64_t)batch * 2 * nc * 2 * C + (int64_t)batch * L * C) * sizeof(float);
+}
+
+extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const float* dt_bias,
+                                const float* A, const float* Ds, const float* ln_w, const float* ln_b, float* out,
+                                float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
+                                int dstate, float eps, void* stream) {
+    XP_CHECK_ARG(u && xdbl && wdt && dt_bias && A && Ds && ln_w && ln_b && out && workspace, "xp_ss2d_core_fwd: null pointer");
+    XP_CHECK_ARG(dstate == 1, "xp_ss2d_core_fwd: only d_state == 1 (the XPoint config) is implemented in the fused core; "
+                              "use xp_selective_scan_fwd for general d_state (got %d)", dstate);
+    XP_CHECK_ARG(batch > 0 && H > 0 && W > 0, "xp_ss2d_core_fwd: bad shape");
+    XP_CHECK_ARG(C % 32 == 0 && C >= 32 && C <= 768, "xp_ss2d_core_fwd: C must be a multiple of 32 in [32,768] (got %d)", C);
+    XP_CHECK_ARG(workspace_bytes >= xp_ss2d_core_workspace_bytes(batch, H, W, C), "xp_ss2d_core_fwd: workspace too small");
+    SS2DParams p;
+    p.u = u; p.xdbl = xdbl; p.wdt = wdt; p.dtb = dt_bias; p.A = A; p.Dp = Ds; p.ln_w = ln_w; p.ln_b = ln_b;
+    p.out = out; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
+    // threads = cpb * C must be a multiple of 64 and <= 768
+    int cpb = 1;
+    if (C < 192) { cpb = 192 / C; while ((cpb * C) % 64) ++cpb; }
+    XP_CHECK_ARG((cpb * C) % 64 == 0 && cpb * C <= 768, "xp_ss2d_core_fwd: unsupported C=%d", C);
+    p.cpb = cpb;
+    int T = 12288 / (cpb * C);
+    T = T >= 64 ? 64 : (T >= 32 ? 32 : 16);
+    p.T = T;
+    const int L = H * W;
+    p.nc = xp_cdiv(L, T);
+    const int64_t nps = (int64_t)batch * 2 * p.nc * 2 * C;
+    p.wsP = workspace; p.wsS = workspace + nps; p.ya = workspace + 2 * nps;
+    hipStream_t s = (hipStream_t)stream;
+    switch (R) {
+        case 2: return launch_ss2d<2>(p, s);
+        case 4: return launch_ss2d<4>(p, s);
+        case 6: return launch_ss2d<6>(p, s);
+        case 8: return launch_ss2d<8>(p, s);
+        case 12: return launch_ss2d<12>(p, s);
+        case 16: return launch_ss2d<16>(p, s);
+        case 24: return launch_ss2d<24>(p, s);
+        case 48: return launch_ss2d<48>(p, s);
+        default: xp_set_error("xp_ss2d_core_fwd: dt_rank %d not instantiated (2,4,6,8,12,16,24,48)", R); return XP_ERR_ARG;
+    }
+}
