@@ -2,12 +2,15 @@
  *
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / C++ types cross this boundary.
- *   - every function returns int: 0 = ok, <0 = error (text: xp_last_error(), thread-local).
+ *   - every function returns int: 0 = ok, <0 = error (text: xp_last_error(), thread-local),
+ *     except the *_bytes / *_numel size queries (size_t) and xp_version / xp_last_error.
  *   - the CALLER owns every buffer; pointers are device pointers (hipMalloc'd or torch
  *     `tensor.data_ptr()`), contiguous float32 unless stated, 16-byte aligned.
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and
  *     are stream-ordered; no function synchronises the device unless it says so.
- *   - no hidden allocation except inside xp_ctx_create / xp_ctx_destroy.
+ *   - the library never allocates device memory: weights and workspaces are caller buffers sized by
+ *     the *_workspace_bytes queries.  A context (xp_ctx_create) is host-only metadata.
+ *   - activations are NHWC (channels contiguous) inside the library.
  *
  * Each entry point cites the reference interface it replaces (paths relative to the reference
  * repo canyagmur/XPoint).
@@ -26,7 +29,8 @@ int xp_version(void);
 const char* xp_last_error(void);
 int xp_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
 
-/* Selective-scan forward.  Replaces the pybind op `selective_scan_cuda_oflex.fwd(u, delta, A, B, C,
+/* ---------------------------------------------------------------------------------------------
+ * Selective-scan forward.  Replaces the pybind op `selective_scan_cuda_oflex.fwd(u, delta, A, B, C,
  * D, delta_bias, delta_softplus, nrows, out_float)` —
  * xpoint/models/vmamba_src/kernels/selective_scan/csrc/selective_scan/cusoflex/selective_scan_oflex.cpp:143-231,
  * kernel selective_scan_fwd_kernel_oflex.cuh:67-181; Python caller vmamba_src/csms6s.py:71-87,112-126.
@@ -39,6 +43,109 @@ int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, co
                           const float* D, const float* delta_bias, float* out, float* last_state,
                           int batch, int dim, int delta_dim, int seqlen, int dstate, int ngroups,
                           int delta_softplus, void* stream);
+
+/* Fused SS2D core in pixel layout = cross_scan + dt_proj + selective_scan + cross_merge + out_norm of
+ * xpoint/models/vmamba_src/VMamba.py:601-646 (forward_corev2) with csm_triton.py:22-85 (cross scan/merge).
+ *   u (batch, H, W, C) = SiLU(dwconv(in_proj(x)));  xdbl (batch*H*W, 4*(R+2)) = u @ x_proj^T with the four
+ *   directions stored in the order (0, 2, 1, 3), each [dt_rank values, B, C];  wdt (4, C, R), dt_bias (4, C),
+ *   A (4, C) = -exp(A_logs), Ds (4, C) in the same direction order;  ln_w/ln_b = out_norm;  out (batch, H, W, C).
+ *   d_state must be 1 (the XPoint config; general d_state: xp_selective_scan_fwd). */
+size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C);
+int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const float* dt_bias, const float* A,
+                     const float* Ds, const float* ln_w, const float* ln_b, float* out, float* workspace,
+                     size_t workspace_bytes, int batch, int H, int W, int C, int R, int dstate, float eps,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers (nn.Linear / nn.Conv2d of VMamba.py:110-128,649,663,1405-1440 and XPoint.py:112-138).
+ *   C[m,n] = (act(sum_k A[m,k] Wt[n,k] + bias[n]) * scale[n] + shift[n]) + res[m,n]
+ *   act: 0 none, 1 GELU(erf), 2 ReLU;  bias/scale/shift/res may be NULL (scale and shift together);
+ *   K and lda multiples of 4.  xp_conv3x3_nhwc: NHWC input, weight (Co, 3, 3, Ci), pad 1 (zero or
+ *   reflection), stride 1 or 2, output NHWC (batch, Ho, Wo, Co). */
+int xp_gemm_nt(const float* A, const float* Wt, float* C, const float* bias, const float* scale, const float* shift,
+               const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
+int xp_conv3x3_nhwc(const float* x, const float* Wt, float* y, const float* bias, const float* scale,
+                    const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
+                    int act, void* stream);
+
+/* Glue kernels (HBM-bound). */
+int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps, int gelu,
+                 void* stream);
+int xp_dwconv3x3_silu(const float* x, const float* w9c, float* y, int batch, int H, int W, int C, void* stream);
+int xp_stem_conv_ln_gelu(const float* img, const float* w9co, const float* bias, const float* ln_w, const float* ln_b,
+                         float* y, int batch, int H, int W, int Co, float eps, void* stream);
+int xp_depth_to_space_nhwc(const float* x, float* y, int batch, int H, int W, int C, int bs, void* stream);
+int xp_softmax_shuffle(const float* logits, float* prob, int batch, int Hc, int Wc, int r, int ld, int mode, void* stream);
+int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, float eps, void* stream);
+int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int C, void* stream);
+int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_t n, void* stream);
+int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Model forward.  Replaces xpoint.models.XPoint.forward_impl (xpoint/models/XPoint.py:283-323) with the
+ * VMamba encoder (vmamba_src/VMamba.py:1507-1525) and the detector / descriptor heads (XPoint.py:348-371).
+ * Device-format parameters live in ONE caller-owned float blob; xp_param_info enumerates
+ * (name, offset, numel) so the host can fill it from a reference state_dict (xpoint_amd/models.py). */
+typedef struct xp_model_cfg {
+    int embed_dim;       /* MODEL.VSSM.EMBED_DIM (96) */
+    int n_stages;        /* len(DEPTHS) */
+    int depths[4];
+    int d_state;         /* SSM_D_STATE (1) */
+    int dt_rank;         /* 0 = "auto" = ceil(dim/16) */
+    float mlp_ratio;     /* 4.0 */
+    int head_channels;   /* 256 */
+    int desc_size;       /* descriptor_size (256) */
+    int det_channels;    /* 65 */
+} xp_model_cfg;
+
+int xp_ctx_create(const xp_model_cfg* cfg, void** ctx);
+int xp_ctx_destroy(void* ctx);
+int xp_param_count(void* ctx);
+size_t xp_weights_numel(void* ctx);
+int xp_param_info(void* ctx, int index, char* name, int name_len, size_t* offset, size_t* numel);
+int xp_forward_shapes(void* ctx, int batch, int H, int W, int* Hc, int* Wc, int* enc_channels);
+size_t xp_forward_workspace_bytes(void* ctx, int batch, int H, int W);
+/* images (batch,1,H,W) in [0,1]; outputs: prob (batch,H,W) or NULL; desc_nhwc (batch,Hc,Wc,desc_size) or NULL;
+ * enc_nhwc (batch,Hc,Wc,embed_dim/2) required; logits_nhwc (batch,Hc,Wc,65) or NULL. */
+int xp_xpoint_forward(void* ctx, const float* weights, const float* images, int batch, int H, int W, void* workspace,
+                      size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc, float* logits_nhwc,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Post-processing.
+ * xp_box_nms replaces xpoint.utils.box_nms (xpoint/utils/utils.py:148-192; torchvision.ops.nms /
+ * batched_nms): prob (batch,H,W) -> out (batch,H,W) with surviving scores, zeros elsewhere.
+ *   size: box side (multiple of 0.5, <= 16); keep_top_k > 0 keeps the k best survivors per image (needs cap >=
+ *   survivors).  max_sweeps_async == 0: iterate to the fixed point, synchronising the stream (like the
+ *   reference, which returns a finished tensor); > 0: enqueue that many sweeps and return without
+ *   synchronising — verify later with xp_box_nms_check (0 undecided tiles = exact result). */
+size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap);
+int xp_box_nms(const float* prob, float* out, void* workspace, size_t workspace_bytes, int batch, int H, int W,
+               float size, float min_prob, float iou, int keep_top_k, int cap, int max_sweeps_async,
+               int* converged_host, void* stream);
+int xp_box_nms_check(const void* workspace, int batch, int H, int W, int* undecided_tiles, void* stream);
+
+/* torch.nonzero((prob > thr) [* mask]) per image (predict_align_image_pair.py:242-243, predict_keypoints.py:213-215):
+ * kp (batch, cap, 2) int32 (y, x) in row-major order, counts (batch) int32 (may exceed cap: truncated list). */
+int xp_extract_keypoints(const float* prob, const uint8_t* mask, float thr, int* kp, int* counts, int batch, int H,
+                         int W, int cap, void* stream);
+
+/* xpoint.utils.interpolate_descriptors (utils.py:229-238): bilinear grid_sample (align_corners=True) of the
+ * NHWC descriptor volume (batch,Hc,Wc,D) at the keypoints + L2 normalisation -> out (batch, cap, D). */
+int xp_sample_descriptors(const int* kp, const int* counts, const float* desc_nhwc, float* out, int batch, int cap,
+                          int Hc, int Wc, int D, int H, int W, void* stream);
+
+/* xpoint.utils.get_matches(d1, d2, 'bfmatcher', False, crossCheck=True) (xpoint/utils/matching.py:4-36; OpenCV
+ * BFMatcher NORM_L2) for `pairs` independent pairs.  d1 (pairs,cap1,D), d2 (pairs,cap2,D); the number of valid
+ * rows of pair i is counts[i*cnt_stride + which1] / [.. + which2] (counts NULL: all cap rows).
+ * mode 0 = strict mutual nearest neighbour (primary), 1 = legacy cross-check.  Outputs: idx12/dist12 (pairs,cap1),
+ * idx21/dist21 (pairs,cap2), matches (pairs,cap1) as (queryIdx, trainIdx, distance) ascending in queryIdx,
+ * match_count (pairs). */
+size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2);
+int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs,
+                 int cap1, int cap2, int D, int mode, int* idx12, float* dist12, int* idx21, float* dist21,
+                 int* match_q, int* match_t, float* match_d, int* match_count, void* workspace, size_t workspace_bytes,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,92 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every symbol include/xpoint_hip.h declares, and the
+host-side logic that needs no GPU (context / parameter layout / weight packing / config and error behaviour)
+is correct.  No compute entry point is called here."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from xpoint_amd import _lib, synth
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _lib.exported_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    bound = set(_lib._SIGNATURES) | set(_lib._SIZE_QUERIES) | {"xp_version", "xp_last_error"}
+    assert set(declared) == bound
+    assert _lib.load().xp_version() == 100
+
+
+def test_argument_errors_surface_with_message():
+    lib = _lib.load()
+    rc = lib.xp_selective_scan_fwd(None, None, None, None, None, None, None, None, None, 1, 4, 4, 8, 1, 1, 1, None)
+    assert rc < 0 and b"null" in lib.xp_last_error()
+    with pytest.raises(_lib.XPointHipError):
+        _lib.call("xp_gemm_nt", None, None, None, None, None, None, None, 1, 1, 4, 4, 1, 1, 0, None)
+
+
+def test_context_layout_and_weight_packing():
+    from xpoint_amd import models
+    cfg = synth.xpoint_exp1_config(480, 640)
+    net = models.XPoint(cfg)
+    sd = synth.make_torch_state_dict(cfg)
+    r = net.load_state_dict(sd, strict=True)
+    assert r.missing_keys == [] and r.unexpected_keys == []
+    blob = net.pack_weights()
+    # device-format blob: every reference tensor except BN statistics (folded into scale/shift) and the 3->1
+    # channel fold of the stem; 81.6 MB of fp32 as SURVEY.md 5.8 estimates
+    assert blob.dtype == torch.float32 and 20.3e6 < blob.numel() < 20.5e6
+    lay = net._layout
+    assert list(lay)[0] == "stem.w" and "s3.b1.fc2_w" in lay and "desc2.shift" in lay
+    offs = sorted(lay.values())
+    for (o1, n1), (o2, _) in zip(offs, offs[1:]):
+        assert o1 + n1 <= o2 and o2 % 4 == 0                       # no overlap, 16-byte aligned
+    o, n = lay["s0.b0.A"]
+    A = -torch.exp(sd["encoder.layers.0.blocks.0.op.A_logs"].float()).view(4, 96)[[0, 2, 1, 3]].reshape(-1)
+    assert torch.equal(blob[o:o + n], A)
+    o, n = lay["s1.b0.xproj_w"]
+    assert torch.equal(blob[o:o + n], sd["encoder.layers.1.blocks.0.op.x_proj_weight"][[0, 2, 1, 3]].reshape(-1))
+    lib = _lib.load()
+    assert lib.xp_forward_workspace_bytes(net._ctx, 16, 480, 640) > 0
+    Hc, Wc, Ce = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.xp_forward_shapes(net._ctx, 1, 480, 640, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)) == 0
+    assert (Hc.value, Wc.value, Ce.value) == (60, 80, 48)
+
+
+def test_model_config_and_state_dict_errors():
+    from xpoint_amd import models
+    cfg = synth.xpoint_exp1_config(64, 96)
+    net = models.XPoint(cfg)
+    assert net.takes_pair() and net.get_encoder_downsample_ratio() == 8
+    with pytest.raises(ValueError):
+        net.set_force_return_logits("yes")
+    sd = synth.make_torch_state_dict(cfg)
+    bad = dict(sd); bad["encoder.patch_embed.0.weight"] = torch.zeros(48, 3, 5, 5)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad)
+    extra = dict(sd); extra["bogus.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(extra, strict=True)
+    assert models.XPoint(cfg).load_state_dict(extra, strict=False).unexpected_keys == ["bogus.weight"]
+    with pytest.raises(RuntimeError):                                 # forward before weights / on CPU
+        models.XPoint(cfg).eval()({"optical": {"image": torch.zeros(1, 1, 64, 96)}, "thermal": {"image": torch.zeros(1, 1, 64, 96)}})
+    with pytest.raises(NotImplementedError):
+        c2 = synth.xpoint_exp1_config(64, 96); c2["multispectral"] = True
+        models.XPoint(c2)
+    from xpoint_amd.utils import fix_model_weigth_keys, dict_update
+    assert list(fix_model_weigth_keys({"module__encoder.x": 1, "y": 2})) == ["encoder.x", "y"]
+    assert dict_update({"a": {"b": 1, "c": 2}}, {"a": {"b": 3}}) == {"a": {"b": 3, "c": 2}}
+
+
+def test_get_matches_host_errors():
+    from xpoint_amd.utils import get_matches
+    a = np.zeros((0, 256), np.float32)
+    assert get_matches(a, a) == []
+    with pytest.raises(ValueError):
+        get_matches(np.zeros((2, 4), np.float32), np.zeros((2, 4), np.float32), "nope")
+    with pytest.raises(NotImplementedError):
+        get_matches(np.zeros((2, 4), np.float32), np.zeros((2, 4), np.float32), "flann")

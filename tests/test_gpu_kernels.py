@@ -1,0 +1,303 @@
+"""GPU parity of every HIP kernel class against the oracle (same seeded inputs), through the C ABI.
+Tolerances are written per test; integer / index results are exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import xpoint_oracle as xo
+from xpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _u(name, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(synth.uniform("kern/" + name, shape, lo, hi))
+
+
+def _lib():
+    from xpoint_amd import _lib as L
+    return L
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / conv
+@pytest.mark.parametrize("M,N,K,act,res", [(300, 96, 96, 0, True), (1000, 32, 96, 0, False), (517, 56, 192, 0, False),
+                                           (260, 384, 96, 1, False), (260, 96, 384, 0, True), (130, 768, 768, 0, False),
+                                           (4800, 3072, 768, 1, False), (333, 65, 256, 0, False), (200, 200, 768, 0, False)])
+def test_gemm_nt(gpu_lib, M, N, K, act, res):
+    L = _lib()
+    A = _u(f"A{M}{N}{K}", (M, K)); Wt = _u(f"W{M}{N}{K}", (N, K), -0.1, 0.1); bias = _u(f"b{M}{N}{K}", (N,))
+    R = _u(f"r{M}{N}{K}", (M, N)) if res else None
+    ref = F.linear(A.double(), Wt.double(), bias.double())
+    if act == 1:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), Wt.cuda(), bias.cuda()
+    Rd = R.cuda() if res else None
+    C = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt", L.ptr(Ad), L.ptr(Wd), L.ptr(C), L.ptr(bd), None, None, L.ptr(Rd), M, N, K, K, N, N, act, L.current_stream())
+    err = float((C.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_gemm_scale_shift_lda(gpu_lib):
+    """act -> scale/shift epilogue (eval BatchNorm) and a strided A (lda > K), as the head 1x1 convs use."""
+    L = _lib()
+    M, N, K, lda = 257, 65, 256, 512
+    A = _u("Als", (M, lda)); Wt = _u("Wls", (N, K), -0.1, 0.1); b = _u("bls", (N,)); sc = _u("scls", (N,), 0.5, 1.5); sh = _u("shls", (N,))
+    ref = F.relu(F.linear(A[:, 256:].double(), Wt.double(), b.double())) * sc.double() + sh.double()
+    Ad, Wd, bd, scd, shd = A.cuda(), Wt.cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    C = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt", ctypes.c_void_p(Ad.data_ptr() + 256 * 4), L.ptr(Wd), L.ptr(C), L.ptr(bd), L.ptr(scd),
+           L.ptr(shd), None, M, N, K, lda, N, 0, 2, L.current_stream())
+    assert float((C.cpu().double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,reflect", [(2, 12, 20, 48, 96, 2, 0), (1, 15, 20, 96, 192, 2, 0), (2, 8, 12, 48, 512, 1, 1),
+                                                        (1, 9, 7, 16, 32, 2, 0)])
+def test_conv3x3(gpu_lib, B, H, W, Ci, Co, stride, reflect):
+    L = _lib()
+    x = _u(f"cx{Ci}{Co}", (B, Ci, H, W)); w = _u(f"cw{Ci}{Co}", (Co, Ci, 3, 3), -0.1, 0.1); b = _u(f"cb{Ci}{Co}", (Co,))
+    xin = F.pad(x.double(), (1, 1, 1, 1), mode="reflect") if reflect else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), stride=stride, padding=0 if reflect else 1)
+    Ho, Wo = ref.shape[2:]
+    y = torch.empty((B, Ho, Wo, Co), device="cuda")
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), b.cuda()
+    L.call("xp_conv3x3_nhwc", L.ptr(xd), L.ptr(wd), L.ptr(y), L.ptr(bd), None, None, B, H, W, Ci, Co, stride, reflect, 0, L.current_stream())
+    err = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+# ------------------------------------------------------------------------------------------------ glue kernels
+@pytest.mark.parametrize("M,C", [(1000, 96), (77, 48), (50, 768), (33, 16)])
+def test_layernorm(gpu_lib, M, C):
+    L = _lib()
+    x = _u(f"ln{M}{C}", (M, C), -3, 3); w = _u(f"lnw{C}", (C,), 0.5, 1.5); b = _u(f"lnb{C}", (C,))
+    y = torch.empty((M, C), device="cuda")
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    L.call("xp_layernorm", L.ptr(xd), L.ptr(y), L.ptr(wd), L.ptr(bd), M, C, 1e-5, 0, L.current_stream())
+    np.testing.assert_allclose(y.cpu().numpy(), F.layer_norm(x, (C,), w, b, 1e-5).numpy(), atol=3e-6)
+
+
+def test_dwconv_silu(gpu_lib):
+    L = _lib()
+    B, H, W, C = 2, 9, 13, 96
+    x = _u("dwx", (B, C, H, W)); w = _u("dww", (C, 1, 3, 3))
+    ref = F.silu(F.conv2d(x, w, None, padding=1, groups=C)).permute(0, 2, 3, 1)
+    y = torch.empty((B, H, W, C), device="cuda")
+    xd, wd = x.permute(0, 2, 3, 1).contiguous().cuda(), w.reshape(C, 9).t().contiguous().cuda()
+    L.call("xp_dwconv3x3_silu", L.ptr(xd), L.ptr(wd), L.ptr(y), B, H, W, C, L.current_stream())
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+def test_stem(gpu_lib):
+    L = _lib()
+    B, H, W, Co = 2, 32, 64, 48
+    img = _u("stem", (B, 1, H, W), 0, 1); w = _u("stemw", (Co, 3, 3, 3), -0.2, 0.2); b = _u("stemb", (Co,), -0.2, 0.2)
+    lw = _u("stemlw", (Co,), 0.8, 1.2); lb = _u("stemlb", (Co,), -0.1, 0.1)
+    r = F.conv2d(torch.cat((img, img, img), 1), w, b, stride=2, padding=1).permute(0, 2, 3, 1)
+    ref = F.gelu(F.layer_norm(r, (Co,), lw, lb, 1e-5))
+    w9 = w.double().sum(1).permute(1, 2, 0).reshape(9, Co).float().contiguous()
+    y = torch.empty((B, H // 2, W // 2, Co), device="cuda")
+    imd, w9d, bd, lwd, lbd = img.cuda(), w9.cuda(), b.cuda(), lw.cuda(), lb.cuda()
+    L.call("xp_stem_conv_ln_gelu", L.ptr(imd), L.ptr(w9d), L.ptr(bd), L.ptr(lwd), L.ptr(lbd), L.ptr(y),
+           B, H, W, Co, 1e-5, L.current_stream())
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=5e-6)
+
+
+def test_depth_to_space_and_layout(gpu_lib):
+    L = _lib()
+    B, H, W, C = 2, 3, 5, 768
+    x = _u("d2s", (B, C, H, W))
+    ref = xo.depth_to_space(x, 4)                                    # NCHW (B,48,12,20)
+    y = torch.empty((B, H * 4, W * 4, C // 16), device="cuda")
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    L.call("xp_depth_to_space_nhwc", L.ptr(xd), L.ptr(y), B, H, W, C, 4, L.current_stream())
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
+    z = torch.empty((B, C // 16, H * 4, W * 4), device="cuda")
+    L.call("xp_nhwc_to_nchw", L.ptr(y), L.ptr(z), B, H * 4 * W * 4, C // 16, L.current_stream())
+    assert torch.equal(z.cpu(), ref)
+
+
+def test_softmax_shuffle_and_l2norm(gpu_lib):
+    L = _lib()
+    B, Hc, Wc = 2, 5, 7
+    lg = _u("sms", (B, 65, Hc, Wc), -6, 6)
+    ref = F.pixel_shuffle(F.softmax(lg, 1)[:, :-1], 8)[:, 0]
+    p = torch.empty((B, Hc * 8, Wc * 8), device="cuda")
+    lgd = lg.permute(0, 2, 3, 1).contiguous().cuda()
+    L.call("xp_softmax_shuffle", L.ptr(lgd), L.ptr(p), B, Hc, Wc, 8, 65, 0, L.current_stream())
+    np.testing.assert_allclose(p.cpu().numpy(), ref.numpy(), atol=1e-6)
+    d = _u("l2", (40, 256), -2, 2)
+    y = torch.empty((40, 256), device="cuda")
+    dd = d.cuda()
+    L.call("xp_l2norm_rows", L.ptr(dd), L.ptr(y), 40, 256, 1e-12, L.current_stream())
+    np.testing.assert_allclose(y.cpu().numpy(), F.normalize(d, p=2, dim=1).numpy(), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ fused SS2D core
+@pytest.mark.parametrize("B,C,H,W", [(2, 96, 16, 24), (1, 192, 8, 12), (1, 384, 7, 10), (1, 768, 15, 20), (2, 32, 16, 24), (1, 96, 33, 58)])
+def test_ss2d_core_vs_oracle(gpu_lib, B, C, H, W):
+    """Fused pixel-layout core == reference forward_corev2 (VMamba.py:601-646): cross_scan, x_proj, dt_proj,
+    selective scan, cross_merge (incl. the (y0+y2)+(y1+y3) order), out_norm.  Includes H,W not multiples of
+    the chunk/tile sizes (33x58 is the reference's own odd-size check, csm_triton.py:670)."""
+    L = _lib()
+    R, N = (C + 15) // 16, 1
+    pre = "op."
+    sd = {pre + "x_proj_weight": _u(f"xp{C}", (4, R + 2, C), -C ** -0.5, C ** -0.5),
+          pre + "dt_projs_weight": _u(f"dtw{C}", (4, C, R), -R ** -0.5, R ** -0.5),
+          pre + "dt_projs_bias": _u(f"dtb{C}", (4, C), -6.9, -2.25),
+          pre + "A_logs": _u(f"al{C}", (4 * C, N), -0.5, 0.5), pre + "Ds": _u(f"ds{C}", (4 * C,), 0.5, 1.5),
+          pre + "out_norm.weight": _u(f"onw{C}", (C,), 0.8, 1.2), pre + "out_norm.bias": _u(f"onb{C}", (C,), -0.1, 0.1)}
+    x = _u(f"ss2dx{C}{H}", (B, C, H, W), -0.3, 1.0)
+    ref = xo.ss2d_core(x, sd, pre)                                  # (B,H,W,C)
+    order = [0, 2, 1, 3]
+    u = x.permute(0, 2, 3, 1).contiguous().cuda()
+    xw = sd[pre + "x_proj_weight"][order].reshape(4 * (R + 2), C).contiguous().cuda()
+    xdbl = torch.empty((B * H * W, 4 * (R + 2)), device="cuda")
+    L.call("xp_gemm_nt", L.ptr(u), L.ptr(xw), L.ptr(xdbl), None, None, None, None, B * H * W, 4 * (R + 2), C, C, 4 * (R + 2), 0, 0, L.current_stream())
+    A = (-torch.exp(sd[pre + "A_logs"].float())).view(4, C)[order].contiguous().cuda()
+    out = torch.empty((B, H, W, C), device="cuda")
+    nbytes = L.load().xp_ss2d_core_workspace_bytes(B, H, W, C)
+    ws = torch.empty(nbytes // 4 + 4, device="cuda")
+    dtw = sd[pre + "dt_projs_weight"][order].contiguous().cuda(); dtb = sd[pre + "dt_projs_bias"][order].contiguous().cuda()
+    Dd = sd[pre + "Ds"].view(4, C)[order].contiguous().cuda()
+    lnw, lnb = sd[pre + "out_norm.weight"].cuda(), sd[pre + "out_norm.bias"].cuda()
+    L.call("xp_ss2d_core_fwd", L.ptr(u), L.ptr(xdbl), L.ptr(dtw), L.ptr(dtb), L.ptr(A), L.ptr(Dd), L.ptr(lnw), L.ptr(lnb), L.ptr(out),
+           L.ptr(ws), nbytes, B, H, W, C, R, 1, 1e-5, L.current_stream())
+    err = float((out.cpu() - ref).abs().max())
+    assert err < 2e-5, err
+
+
+# ------------------------------------------------------------------------------------------------ NMS / keypoints / sampling
+def _nms_case(name, shape, levels):
+    p = synth.uniform("nms/" + name, shape, 0.0, 1.0)
+    if levels:
+        p = (np.floor(p * levels) / levels).astype(np.float32)
+    return torch.from_numpy(p)
+
+
+@pytest.mark.parametrize("name,shape,size,levels", [("ties", (1, 1, 40, 56), 8, 16), ("size4", (1, 1, 33, 47), 4, 0),
+                                                    ("batch", (3, 1, 32, 48), 8, 64), ("size3", (1, 1, 24, 24), 3, 0)])
+def test_box_nms_golden(gpu_lib, golden, name, shape, size, levels):
+    from xpoint_amd.utils import box_nms
+    g = golden("g6_box_nms.npz")
+    p = _nms_case(name, shape, levels)
+    assert np.array_equal(box_nms(p.cuda(), size, 0.3).cpu().numpy(), g[name + "/out"])
+    assert np.array_equal(box_nms(p.cuda(), size, 0.3, keep_top_k=5).cpu().numpy(), g[name + "/out_top5"])
+
+
+def test_box_nms_large_vs_oracle_and_errors(gpu_lib):
+    from xpoint_amd.utils import box_nms
+    # 480x640 heat-map with many exact ties and long decreasing ridges (worst case for the parallel fixed point)
+    p = synth.uniform("nms/large", (2, 1, 480, 640), 0.0, 1.0)
+    p = (np.floor(p * 256) / 256).astype(np.float32)
+    ramp = (np.arange(640, dtype=np.float32) / 640.0)[None, None, None, :]
+    p[:, :, 100:104, :] = 0.5 + 0.4 * ramp          # monotone ridge: a chain as long as the image is wide
+    pt = torch.from_numpy(p)
+    ref = xo.box_nms(pt, 8, 0.015)
+    out = box_nms(pt.cuda(), 8, 0.015)
+    assert torch.equal(out.cpu(), ref)
+    ref_k = xo.box_nms(pt, 8, 0.015, keep_top_k=300)
+    assert torch.equal(box_nms(pt.cuda(), 8, 0.015, keep_top_k=300).cpu(), ref_k)
+    with pytest.raises(ValueError):
+        box_nms(torch.zeros(3, 4, 5, device="cuda"), 8, 0.5)
+    assert float(box_nms(torch.zeros(1, 1, 16, 16, device="cuda"), 8, 0.5).abs().sum()) == 0.0
+    p2 = torch.from_numpy(synth.uniform("nms/2d", (30, 44), 0.0, 1.0))
+    assert torch.equal(box_nms(p2.cuda(), 8, 0.5).cpu(), xo.box_nms(p2, 8, 0.5))
+
+
+def test_extract_keypoints_order_and_mask(gpu_lib):
+    from xpoint_amd.utils import extract_keypoints
+    p = torch.from_numpy(synth.uniform("kp/p", (3, 1, 70, 130), 0, 1))
+    m = torch.from_numpy(synth.uniform("kp/m", (3, 1, 70, 130), 0, 1) > 0.3)
+    kp, cnt = extract_keypoints(p.cuda(), 0.9, m.cuda())
+    for i in range(3):
+        ref = xo.extract_keypoints(p[i, 0], 0.9, m[i, 0])
+        assert int(cnt[i]) == len(ref)
+        assert torch.equal(kp[i, :len(ref)].cpu().long(), ref)
+    kp, cnt = extract_keypoints(torch.zeros(1, 8, 8, device="cuda"), 0.5)
+    assert int(cnt[0]) == 0
+
+
+def test_interpolate_descriptors(gpu_lib, golden):
+    from xpoint_amd.utils import interpolate_descriptors
+    g = golden("g7_interpolate.npz")
+    desc = torch.from_numpy(synth.uniform("interp/desc", (16, 6, 9), -1, 1))
+    out = interpolate_descriptors(torch.from_numpy(g["kp"]).cuda(), desc.cuda(), 48, 72)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=1e-6)
+    # model-sized: 256-d volume at 60x80, keypoints over the whole 480x640 image incl. the last row / column
+    desc = _u("interp/big", (256, 60, 80))
+    ys = torch.arange(0, 480, 7); xs = torch.arange(0, 640, 11)
+    kp = torch.stack(torch.meshgrid(ys, xs, indexing="ij"), -1).reshape(-1, 2)
+    kp = torch.cat([kp, torch.tensor([[479, 639], [0, 639], [479, 0]])])
+    out = interpolate_descriptors(kp.cuda(), desc.cuda(), 480, 640)
+    np.testing.assert_allclose(out.cpu().numpy(), xo.interpolate_descriptors(kp, desc, 480, 640).numpy(), atol=1e-6)
+    assert interpolate_descriptors(kp[:0].cuda(), desc.cuda(), 480, 640).shape == (0, 256)
+
+
+# ------------------------------------------------------------------------------------------------ matching
+def _unit(name, n, d):
+    x = synth.uniform(name, (n, d), -1, 1)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_match_golden_and_modes(gpu_lib, golden):
+    from xpoint_amd.utils import get_matches
+    g = golden("g8_match.npz")
+    ref = [tuple(x) for x in g["matches"].tolist()]
+    ms = get_matches(g["d1"], g["d2"], "bfmatcher", False, crossCheck=True)
+    assert [(m.queryIdx, m.trainIdx) for m in ms] == ref                   # identical indices, ascending queryIdx
+    oms = xo.get_matches(g["d1"], g["d2"], "strict_mnn")
+    np.testing.assert_allclose([m.distance for m in ms], [m.distance for m in oms], atol=1e-6)
+    leg = get_matches(g["d1"], g["d2"], "bfmatcher", False, mode="legacy_crosscheck", crossCheck=True)
+    oleg = xo.get_matches(g["d1"], g["d2"], "legacy_crosscheck")
+    assert [(m.queryIdx, m.trainIdx) for m in leg] == [(m.queryIdx, m.trainIdx) for m in oleg]
+    assert get_matches(g["d1"][:0], g["d2"]) == [] and get_matches(g["d1"], g["d2"][:0]) == []
+    nn = get_matches(g["d1"], g["d2"], "nnmatcher", False, threshold=10.0)
+    assert [(m.queryIdx, m.trainIdx) for m in nn] == ref
+    with pytest.raises(ValueError):
+        get_matches(g["d1"], g["d2"], "nope")
+
+
+@pytest.mark.parametrize("n1,n2", [(4096, 4096), (4160, 3999), (1, 1), (130, 5)])
+def test_match_exact_indices_vs_oracle(gpu_lib, n1, n2):
+    """BASELINE config-4 size (4k x 4k x 256): nearest-neighbour indices in both directions and the mutual
+    matches are IDENTICAL to the fp64 direct-form oracle — including planted exact duplicates (first index wins)
+    and planted near-ties (gap ~1e-7, far below fp32 Gram-form noise)."""
+    from xpoint_amd.utils import match_descriptors
+    d1, d2 = _unit(f"m/a{n1}", n1, 256), _unit(f"m/b{n2}", n2, 256)
+    if n2 > 100:
+        d2[57] = d2[3]                                   # exact duplicate targets: tie -> lowest index
+        d2[77] = d1[10]; d2[91] = d1[10]                 # two exact copies of a query
+        near = d1[20].copy(); near[0] += 3e-7            # near-tie pair
+        d2[40] = d1[20]; d2[41] = near / np.linalg.norm(near)
+    idx12, dist12, gap12, idx21, dist21 = xo.nn_both(d1, d2)
+    res = match_descriptors(torch.from_numpy(d1).cuda().unsqueeze(0), torch.from_numpy(d2).cuda().unsqueeze(0))
+    assert np.array_equal(res["idx12"][0].cpu().numpy(), idx12)
+    assert np.array_equal(res["idx21"][0].cpu().numpy(), idx21)
+    np.testing.assert_allclose(res["dist12"][0].cpu().numpy(), dist12, atol=1e-6)
+    q = np.nonzero(idx21[idx12] == np.arange(n1))[0]
+    nm = int(res["match_count"][0])
+    assert nm == len(q) and np.array_equal(res["match_q"][0, :nm].cpu().numpy(), q)
+    assert np.array_equal(res["match_t"][0, :nm].cpu().numpy(), idx12[q])
+
+
+def test_match_batched_ragged_counts(gpu_lib):
+    from xpoint_amd.utils import match_descriptors
+    P, cap = 3, 300
+    d1 = np.stack([_unit(f"mb/a{i}", cap, 64) for i in range(P)]); d2 = np.stack([_unit(f"mb/b{i}", cap, 64) for i in range(P)])
+    n1, n2 = [300, 17, 0], [250, 300, 40]
+    counts = torch.tensor(n1 + n2, dtype=torch.int32).cuda()
+    res = match_descriptors(torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda(), counts)
+    for i in range(P):
+        nm = int(res["match_count"][i])
+        if n1[i] == 0:
+            assert nm == 0
+            continue
+        oms = xo.get_matches(d1[i, :n1[i]], d2[i, :n2[i]])
+        assert [(int(a), int(b)) for a, b in zip(res["match_q"][i, :nm].cpu(), res["match_t"][i, :nm].cpu())] == \
+               [(m.queryIdx, m.trainIdx) for m in oms]

@@ -22,9 +22,41 @@ class XPointHipError(RuntimeError):
 
 
 # name -> argtypes; every function returns int (0 ok) except xp_last_error / xp_version.
+c_sz = ctypes.c_size_t
 _SIGNATURES = {
     "xp_device_info": [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
     "xp_selective_scan_fwd": [c_p] * 9 + [c_i] * 7 + [c_p],
+    "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
+    "xp_gemm_nt": [c_p] * 7 + [c_i] * 7 + [c_p],
+    "xp_conv3x3_nhwc": [c_p] * 6 + [c_i] * 8 + [c_p],
+    "xp_layernorm": [c_p] * 4 + [c_l, c_i, c_f, c_i, c_p],
+    "xp_dwconv3x3_silu": [c_p] * 3 + [c_i] * 4 + [c_p],
+    "xp_stem_conv_ln_gelu": [c_p] * 6 + [c_i] * 4 + [c_f, c_p],
+    "xp_depth_to_space_nhwc": [c_p] * 2 + [c_i] * 5 + [c_p],
+    "xp_softmax_shuffle": [c_p] * 2 + [c_i] * 6 + [c_p],
+    "xp_l2norm_rows": [c_p] * 2 + [c_l, c_i, c_f, c_p],
+    "xp_nhwc_to_nchw": [c_p] * 2 + [c_i] * 3 + [c_p],
+    "xp_mul_mask": [c_p] * 3 + [c_l, c_p],
+    "xp_maxpool2_nhwc": [c_p] * 2 + [c_i] * 4 + [c_p],
+    "xp_ctx_create": [c_p, ctypes.POINTER(c_p)],
+    "xp_ctx_destroy": [c_p],
+    "xp_param_info": [c_p, c_i, ctypes.c_char_p, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)],
+    "xp_forward_shapes": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
+    "xp_xpoint_forward": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p],
+    "xp_box_nms": [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
+    "xp_box_nms_check": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
+    "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "xp_sample_descriptors": [c_p] * 4 + [c_i] * 7 + [c_p],
+    "xp_match_mnn": [c_p, c_p, c_p] + [c_i] * 8 + [c_p] * 9 + [c_sz, c_p],
+}
+# size queries: (restype size_t / int, argtypes)
+_SIZE_QUERIES = {
+    "xp_weights_numel": (c_sz, [c_p]),
+    "xp_param_count": (c_i, [c_p]),
+    "xp_forward_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
+    "xp_ss2d_core_workspace_bytes": (c_sz, [c_i] * 4),
+    "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
+    "xp_match_workspace_bytes": (c_sz, [c_i] * 3),
 }
 
 
@@ -52,6 +84,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_i
+    for name, (res, argtypes) in _SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = res
     _lib = lib
     return lib
 

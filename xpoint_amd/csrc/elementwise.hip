@@ -1,0 +1,335 @@
+// HBM-bound glue kernels of the encoder and heads, NHWC layout (channels contiguous):
+// LayerNorm, depthwise 3x3 + SiLU, the 1-channel stem convolution (+LN+GELU), depth-to-space,
+// detector softmax + pixel shuffle, descriptor L2 normalisation, NHWC->NCHW export.
+#include "xp_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (C <= 1024), one wave per row, two-pass mean/variance in registers.
+// Reference: nn.LayerNorm eps 1e-5, biased variance (VMamba.py:1222-1234, :1405-1440).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        int64_t M, int C, float eps, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * C;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < C) ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = xp_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = 1.f / sqrtf(xp_wave_sum(q) / (float)C + eps);
+    float* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            float o = (v[i] - mean) * rstd * w[c] + b[c];
+            if (gelu) o = xp_gelu(o);
+            yr[c] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise 3x3 (zero pad 1, no bias) + SiLU, NHWC.  Reference VMamba.py:655-658.
+// weight layout [9][C] (tap-major) so that a lane's 4 channels are one 16-B load.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv3x3_silu_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * H * W * C4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    const int64_t pix = idx / C4;
+    const int ww = (int)(pix % W);
+    const int hh = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = hh + kh - 1;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ww + kw - 1;
+            if (iw < 0 || iw >= W) continue;
+            const float4 xv = *reinterpret_cast<const float4*>(x + (((b * H + ih) * W + iw) * C4 + c4) * 4);
+            const float4 wv = *reinterpret_cast<const float4*>(w + ((kh * 3 + kw) * C4 + c4) * 4);
+            acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
+            acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+        }
+    }
+    acc.x = xp_silu(acc.x); acc.y = xp_silu(acc.y); acc.z = xp_silu(acc.z); acc.w = xp_silu(acc.w);
+    *reinterpret_cast<float4*>(y + idx * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem: gray image (B,1,H,W) -> conv3x3 stride 2 pad 1 (1 -> CO channels; the reference replicates gray
+// to 3 channels, VMamba.py:1509-1510, so the 3 input-channel weights are pre-summed on the host)
+// + bias + LayerNorm(CO) + GELU -> NHWC (B,H/2,W/2,CO).  Reference VMamba.py:1411-1416.
+// One thread per output pixel, CO accumulators in registers; output staged through LDS for coalescing.
+// ---------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __restrict__ img, const float* __restrict__ w9,
+                                                               const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                               const float* __restrict__ lnb, float* __restrict__ y,
+                                                               int B, int H, int W, float eps) {
+    __shared__ float s_w[9 * CO + 3 * CO];
+    __shared__ float s_o[64 * (CO + 1)];
+    for (int i = threadIdx.x; i < 9 * CO; i += 64) s_w[i] = w9[i];          // [tap][CO]
+    for (int i = threadIdx.x; i < CO; i += 64) { s_w[9 * CO + i] = bias[i]; s_w[10 * CO + i] = lnw[i]; s_w[11 * CO + i] = lnb[i]; }
+    __syncthreads();
+    const int Ho = H / 2 + (H & 1), Wo = W / 2 + (W & 1);   // floor((H+2-3)/2)+1
+    const int64_t total = (int64_t)B * Ho * Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int64_t pix = p0 + threadIdx.x;
+    if (pix < total) {
+        const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho);
+        const int64_t b = pix / ((int64_t)Wo * Ho);
+        float xin[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
+                xin[kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? img[(b * H + ih) * W + iw] : 0.f;
+            }
+        float acc[CO];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(xin[t], s_w[t * CO + c], a);
+            a += s_w[9 * CO + c];
+            acc[c] = a; s += a;
+        }
+        const float mean = s / (float)CO;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) { const float d = acc[c] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.f / sqrtf(q / (float)CO + eps);
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+            s_o[threadIdx.x * (CO + 1) + c] = xp_gelu((acc[c] - mean) * rstd * s_w[10 * CO + c] + s_w[11 * CO + c]);
+    }
+    __syncthreads();
+    const int64_t nvalid = (total - p0 < 64) ? (total - p0) : 64;
+    for (int i = threadIdx.x; i < nvalid * CO; i += 64) {
+        const int pl = i / CO, c = i - pl * CO;
+        y[(p0 + pl) * CO + c] = s_o[pl * (CO + 1) + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depth_to_space(4) in NHWC: out[n, bs*h+i, bs*w+j, c] = x[n, h, w, (bs*i+j)*Cq + c]  (VMamba.py:1500-1505;
+// block-major channel order, NOT PixelShuffle order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int B, int H, int W, int C, int bs) {
+    const int Cq = C / (bs * bs);
+    const int64_t total = (int64_t)B * H * W * C;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % C);
+    const int64_t pix = idx / C;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const int64_t n = pix / ((int64_t)W * H);
+    const int blk = ch / Cq, c = ch - blk * Cq;
+    const int i = blk / bs, j = blk - i * bs;
+    y[((n * (H * bs) + (h * bs + i)) * (int64_t)(W * bs) + (w * bs + j)) * Cq + c] = x[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Detector tail: softmax over the 65 logits of a cell, drop the dustbin, PixelShuffle(r):
+// prob[b, r*h+i, r*w+j] = p[b, h, w, r*i+j]   (XPoint.py:356-358).  One wave per cell.
+// mode 1 = SuperPointMagicLeap heat-map: exp(x)/(sum+1e-5), no max subtraction (SuperPointMagicLeap.py:73-74).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __restrict__ logits, float* __restrict__ prob,
+                                                              int B, int Hc, int Wc, int r, int ld, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= (int64_t)B * Hc * Wc) return;
+    const int nch = r * r + 1;
+    const float* lp = logits + cell * ld;
+    float v0 = (lane < nch) ? lp[lane] : -INFINITY;
+    float v1 = (lane + 64 < nch) ? lp[lane + 64] : -INFINITY;
+    float e0, e1, inv;
+    if (mode == 0) {
+        const float mx = xp_wave_max(fmaxf(v0, v1));
+        e0 = (lane < nch) ? expf(v0 - mx) : 0.f;
+        e1 = (lane + 64 < nch) ? expf(v1 - mx) : 0.f;
+        inv = 1.f / xp_wave_sum(e0 + e1);
+        e0 *= inv; e1 *= inv;
+    } else {
+        e0 = (lane < nch) ? expf(v0) : 0.f;
+        e1 = (lane + 64 < nch) ? expf(v1) : 0.f;
+        const float den = xp_wave_sum(e0 + e1) + 0.00001f;
+        e0 = e0 / den; e1 = e1 / den;
+    }
+    const int w = (int)(cell % Wc), h = (int)((cell / Wc) % Hc);
+    const int64_t b = cell / ((int64_t)Wc * Hc);
+    const int64_t Wf = (int64_t)Wc * r;
+    for (int k = 0; k < 2; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < r * r) {
+            const int i = ch / r, j = ch - i * r;
+            prob[(b * Hc * r + (h * r + i)) * Wf + (w * r + j)] = k ? e1 : e0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2 normalise rows (F.normalize p=2 dim=channel, eps 1e-12: x / max(||x||, eps); XPoint.py:365-366).
+// eps < 0 selects the SuperPoint form x / ||x|| without clamp (SuperPointMagicLeap.py:59-60).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t M, int C,
+                                                          float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = xr[c]; s = fmaf(v, v, s); }
+    float nrm = sqrtf(xp_wave_sum(s));
+    if (eps >= 0.f) nrm = fmaxf(nrm, eps);
+    float* yr = y + row * C;
+    for (int c = lane; c < C; c += 64) yr[c] = xr[c] / nrm;
+}
+
+// NHWC (B, HW, C) -> NCHW (B, C, HW) through a padded 32x32 LDS tile.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        t[i][tx] = (p < HW && c < C) ? x[((int64_t)b * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (p < HW && c < C) y[((int64_t)b * C + c) * HW + p] = t[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                                       float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * (m[i] ? 1.f : 0.f);
+}
+
+// 2x2 max pool stride 2, NHWC (conv backbones: XPoint.py:451-466, SuperPointMagicLeap.py:42-48).
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t pix = idx / C;
+    const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho);
+    const int64_t b = pix / ((int64_t)Wo * Ho);
+    const float* p = x + ((b * H + oh * 2) * W + ow * 2) * (int64_t)C + c;
+    y[idx] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(int64_t)W * C], p[(int64_t)W * C + C]));
+}
+
+}  // namespace
+
+extern "C" int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps,
+                            int gelu, void* stream) {
+    XP_CHECK_ARG(x && y && w && b, "xp_layernorm: null pointer");
+    XP_CHECK_ARG(C > 0 && C <= 1024, "xp_layernorm: C must be in [1,1024] (got %d)", C);
+    if (rows == 0) return XP_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b, rows, C, eps, gelu);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_dwconv3x3_silu(const float* x, const float* w9c, float* y, int batch, int H, int W, int C, void* stream) {
+    XP_CHECK_ARG(x && w9c && y, "xp_dwconv3x3_silu: null pointer");
+    XP_CHECK_ARG(C % 4 == 0, "xp_dwconv3x3_silu: C %% 4 != 0");
+    const int64_t total = (int64_t)batch * H * W * (C / 4);
+    hipLaunchKernelGGL(dwconv3x3_silu_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w9c, y, batch, H, W, C);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_stem_conv_ln_gelu(const float* img, const float* w9co, const float* bias, const float* ln_w,
+                                    const float* ln_b, float* y, int batch, int H, int W, int Co, float eps, void* stream) {
+    XP_CHECK_ARG(img && w9co && bias && ln_w && ln_b && y, "xp_stem_conv_ln_gelu: null pointer");
+    const int Ho = H / 2 + (H & 1), Wo = W / 2 + (W & 1);
+    const int64_t total = (int64_t)batch * Ho * Wo;
+    dim3 grid(xp_cdiv(total, 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    if (Co == 48) hipLaunchKernelGGL(stem_conv_ln_gelu_kernel<48>, grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
+    else if (Co == 16) hipLaunchKernelGGL(stem_conv_ln_gelu_kernel<16>, grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
+    else { xp_set_error("xp_stem_conv_ln_gelu: Co must be 48 or 16 (EMBED_DIM 96 / 32), got %d", Co); return XP_ERR_ARG; }
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_depth_to_space_nhwc(const float* x, float* y, int batch, int H, int W, int C, int bs, void* stream) {
+    XP_CHECK_ARG(x && y && C % (bs * bs) == 0, "xp_depth_to_space_nhwc: bad args");
+    const int64_t total = (int64_t)batch * H * W * C;
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C, bs);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_softmax_shuffle(const float* logits, float* prob, int batch, int Hc, int Wc, int r, int ld, int mode, void* stream) {
+    XP_CHECK_ARG(logits && prob, "xp_softmax_shuffle: null pointer");
+    XP_CHECK_ARG(r * r + 1 <= 128 && ld >= r * r + 1, "xp_softmax_shuffle: r*r+1 must be <= 128 and <= ld");
+    const int64_t cells = (int64_t)batch * Hc * Wc;
+    hipLaunchKernelGGL(softmax_shuffle_kernel, dim3(xp_cdiv(cells, 4)), dim3(256), 0, (hipStream_t)stream, logits, prob, batch, Hc, Wc, r, ld, mode);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
+    XP_CHECK_ARG(x && y, "xp_l2norm_rows: null pointer");
+    if (rows == 0) return XP_OK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, C, eps);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int C, void* stream) {
+    XP_CHECK_ARG(x && y, "xp_nhwc_to_nchw: null pointer");
+    dim3 grid(xp_cdiv(HW, 32), xp_cdiv(C, 32), batch);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_t n, void* stream) {
+    XP_CHECK_ARG(x && mask && y, "xp_mul_mask: null pointer");
+    if (n == 0) return XP_OK;
+    hipLaunchKernelGGL(mul_mask_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, y, n);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream) {
+    XP_CHECK_ARG(x && y, "xp_maxpool2_nhwc: null pointer");
+    const int64_t total = (int64_t)batch * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}

@@ -1,0 +1,161 @@
+// fp32 MFMA GEMM / implicit-GEMM 3x3 convolution with fused epilogue, for the encoder's dense
+// layers (reference VMamba.py:649,663 in/out_proj; :110-128 Mlp; :605 x_proj; :1405-1440 strided
+// 3x3 convs; XPoint.py:112-138 head convs).
+//
+//   C[m, n] = epilogue( sum_k A'[m, k] * Wt[n, k] )        A' = A (row-major M x K)  or  im2col(NHWC image)
+//   epilogue(v) = (act(v + bias[n]) * scale[n] + shift[n]) + res[m, n]
+//
+// Tile engine: gemm_core.h.  MFMA-bound for the deep stages, HBM-bound at stage 0 (K = N = 96).
+#include "gemm_core.h"
+
+namespace {
+
+struct GemmParams {
+    const float* A;
+    const float* Wt;      // (N, K) row-major
+    float* C;
+    const float* bias;    // (N) or null
+    const float* scale;   // (N) or null   (applied after the activation; eval-mode BatchNorm)
+    const float* shift;
+    const float* res;     // (M, ldres) or null
+    int M, N, K;
+    int lda, ldc, ldres;
+    int act;              // 0 none, 1 GELU(erf), 2 ReLU
+    int mode;             // 0: plain A; 1: implicit 3x3 conv over NHWC (K order = kh, kw, ci)
+    int Hi, Wi, Ci, Ho, Wo, stride, reflect;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+    using T = GemmTile<WM, WN, TM, TN>;
+    extern __shared__ __align__(16) float lds[];
+    const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
+
+    int64_t a_base[T::A_LD];
+    int a_oh[T::A_LD], a_ow[T::A_LD];
+    bool a_ok[T::A_LD];
+#pragma unroll
+    for (int s = 0; s < T::A_LD; ++s) {
+        const int m = m0 + T::slot_row(s);
+        a_ok[s] = m < p.M;
+        if (p.mode == 0) {
+            a_base[s] = (int64_t)m * p.lda; a_oh[s] = a_ow[s] = 0;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, r = m - b * hw;
+            a_oh[s] = (r / p.Wo) * p.stride - 1; a_ow[s] = (r % p.Wo) * p.stride - 1;
+            a_base[s] = (int64_t)b * p.Hi * p.Wi * p.Ci;
+        }
+    }
+    const float* wrow[T::B_LD];
+#pragma unroll
+    for (int s = 0; s < T::B_LD; ++s) {
+        const int n = n0 + T::slot_row(s);
+        wrow[s] = (n < p.N) ? p.Wt + (int64_t)n * p.K : nullptr;
+    }
+    auto ldA = [&](int s, int k) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_ok[s] && k < p.K) {
+            if (p.mode == 0) {
+                v = *reinterpret_cast<const float4*>(p.A + a_base[s] + k);
+            } else {
+                const int tap = k / p.Ci, ci = k - tap * p.Ci;
+                int ih = a_oh[s] + tap / 3, iw = a_ow[s] + tap % 3;
+                bool ok = true;
+                if (p.reflect) {
+                    ih = ih < 0 ? -ih : (ih >= p.Hi ? 2 * p.Hi - 2 - ih : ih);
+                    iw = iw < 0 ? -iw : (iw >= p.Wi ? 2 * p.Wi - 2 - iw : iw);
+                } else {
+                    ok = ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+                }
+                if (ok) v = *reinterpret_cast<const float4*>(p.A + a_base[s] + ((int64_t)ih * p.Wi + iw) * p.Ci + ci);
+            }
+        }
+        return v;
+    };
+    auto ldB = [&](int s, int k) -> float4 {
+        return (wrow[s] && k < p.K) ? *reinterpret_cast<const float4*>(wrow[s] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    f32x16 acc[TM][TN];
+    T::run(lds, p.K, ldA, ldB, acc);
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + T::col_of(j);
+            if (col >= p.N) continue;
+            const float bi = p.bias ? p.bias[col] : 0.f;
+            const float sc = p.scale ? p.scale[col] : 1.f;
+            const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + T::row_of(i, r);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bi;
+                if (p.act == 1) v = xp_gelu(v);
+                else if (p.act == 2) v = fmaxf(v, 0.f);
+                if (p.scale) v = v * sc + sh;
+                if (p.res) v = p.res[(int64_t)row * p.ldres + col] + v;
+                p.C[(int64_t)row * p.ldc + col] = v;
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN>
+void launch(const GemmParams& p, hipStream_t s) {
+    using T = GemmTile<WM, WN, TM, TN>;
+    static bool attr_set = false;
+    if (!attr_set && T::kLdsBytes > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        attr_set = true;
+    }
+    dim3 grid(xp_cdiv(p.N, T::BN), xp_cdiv(p.M, T::BM));
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+}
+
+int dispatch(const GemmParams& p, hipStream_t s) {
+    // tile choice by N (the encoder's N are 32..3072; M is large except at the last stage)
+    const int N = p.N;
+    if (N <= 32) launch<4, 1, 1, 1>(p, s);                                   // 128 x 32
+    else if (N <= 64) launch<4, 1, 1, 2>(p, s);                              // 128 x 64
+    else if (N % 96 == 0 && (N / 96) % 4 != 0) launch<4, 1, 1, 3>(p, s);     // 128 x 96  (N = 96, 192)
+    else if (p.M <= 8192 && N >= 512) launch<2, 2, 1, 2>(p, s);              // 64 x 128: more blocks when M is small
+    else launch<2, 2, 2, 2>(p, s);                                           // 128 x 128
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+}  // namespace
+
+extern "C" int xp_gemm_nt(const float* A, const float* Wt, float* C, const float* bias, const float* scale,
+                          const float* shift, const float* res, int M, int N, int K, int lda, int ldc, int ldres,
+                          int act, void* stream) {
+    XP_CHECK_ARG(A && Wt && C, "xp_gemm_nt: null pointer");
+    XP_CHECK_ARG(M > 0 && N > 0 && K > 0, "xp_gemm_nt: bad shape %d %d %d", M, N, K);
+    XP_CHECK_ARG(K % 4 == 0 && lda % 4 == 0, "xp_gemm_nt: K and lda must be multiples of 4 (got %d, %d)", K, lda);
+    XP_CHECK_ARG((scale == nullptr) == (shift == nullptr), "xp_gemm_nt: scale and shift go together");
+    XP_CHECK_ARG(act >= 0 && act <= 2, "xp_gemm_nt: bad act %d", act);
+    GemmParams p{};
+    p.A = A; p.Wt = Wt; p.C = C; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.act = act; p.mode = 0;
+    return dispatch(p, (hipStream_t)stream);
+}
+
+extern "C" int xp_conv3x3_nhwc(const float* x, const float* Wt, float* y, const float* bias, const float* scale,
+                               const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride,
+                               int reflect_pad, int act, void* stream) {
+    XP_CHECK_ARG(x && Wt && y, "xp_conv3x3_nhwc: null pointer");
+    XP_CHECK_ARG(Ci % 4 == 0, "xp_conv3x3_nhwc: Ci must be a multiple of 4 (got %d)", Ci);
+    XP_CHECK_ARG(stride == 1 || stride == 2, "xp_conv3x3_nhwc: stride 1 or 2");
+    XP_CHECK_ARG((scale == nullptr) == (shift == nullptr), "xp_conv3x3_nhwc: scale and shift go together");
+    XP_CHECK_ARG(!reflect_pad || (Hi >= 2 && Wi >= 2), "xp_conv3x3_nhwc: reflection pad needs H,W >= 2");
+    GemmParams p{};
+    p.A = x; p.Wt = Wt; p.C = y; p.bias = bias; p.scale = scale; p.shift = shift; p.res = nullptr;
+    p.Hi = Hi; p.Wi = Wi; p.Ci = Ci; p.stride = stride; p.reflect = reflect_pad;
+    p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = (Wi + 2 - 3) / stride + 1;
+    p.M = batch * p.Ho * p.Wo; p.N = Co; p.K = 9 * Ci; p.lda = 0; p.ldc = Co; p.ldres = 0; p.act = act; p.mode = 1;
+    return dispatch(p, (hipStream_t)stream);
+}

@@ -1,0 +1,293 @@
+// Dense descriptor matching: all-pairs L2 distance + nearest neighbour in both directions + mutual
+// (cross-check) test.  Replaces cv2.BFMatcher(NORM_L2, crossCheck=True).match as called from
+// reference xpoint/utils/matching.py:4-36 (and the in-repo NNMatcher, matching.py:38-75).
+//
+// CDNA4 mapping.  d2[q,t] = |a_q|^2 + |b_t|^2 - 2 a_q.b_t : the N1 x 256 . 256 x N2 contraction runs on
+// the fp32 MFMA tile engine (gemm_core.h, 128x128 tiles), the row/column minima are reduced with wave
+// shuffles inside the tile and merged across tiles with one 64-bit atomicMin per row/column and tile
+// (key = float bits of d2 << 32 | index, so equal distances resolve to the smallest index = first
+// minimum, independent of scheduling).
+//
+// Index exactness.  fp32 Gram-form distances carry ~1e-7 cancellation noise, which is larger than the
+// smallest best/second-best gaps seen on real data (3e-6).  So the MFMA pass only
+// NOMINATES: every (q,t) whose approximate d2 is within EPS of the running row (column) minimum is
+// appended to that row's (column's) candidate list — a superset of the candidates near the final
+// minimum, because the running minimum only decreases.  A second kernel re-evaluates the nominated
+// pairs in direct form with fp64 accumulation and picks the exact first minimum.  The result is the
+// exact-arithmetic mutual nearest neighbour; it does not depend on fp32 rounding or tile order.
+#include "gemm_core.h"
+
+namespace {
+
+constexpr int CAND_CAP = 16;
+constexpr float MATCH_EPS = 2e-5f;   // relative to (|a|^2 + |b|^2): >= 2x the fp32 Gram-form error bound
+
+struct MatchParams {
+    const float* d1; const float* d2;            // (cap, D) per pair
+    const int* n1p; const int* n2p;               // device counts per pair (may be null -> n1max/n2max)
+    int which1, which2;                           // index into counts for this pair layout (see host)
+    int cap1, cap2, D;
+    float* na; float* nb;                         // norms^2 (pairs, cap)
+    unsigned long long* rowkey; unsigned long long* colkey;   // (pairs, cap)
+    int* rcnt; int* ccnt; int* rcand; int* ccand; // candidate lists (pairs, cap[, CAND_CAP])
+};
+
+__device__ __forceinline__ int count_of(const int* p, int idx, int cap) { int n = p ? p[idx] : cap; return n < cap ? n : cap; }
+
+__global__ __launch_bounds__(256) void match_prepare_kernel(const float* __restrict__ d, const int* __restrict__ cnt, int cnt_stride,
+                                                            int cnt_off, int cap, int D, float* __restrict__ nrm,
+                                                            unsigned long long* __restrict__ key, int* __restrict__ ccount) {
+    const int pair = blockIdx.y;
+    const int n = count_of(cnt, pair * cnt_stride + cnt_off, cap);
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= cap) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)pair * cap + i;
+    if (i < n) {
+        const float* r = d + o * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s = fmaf(r[c], r[c], s);
+        s = xp_wave_sum(s);
+        if (lane == 0) nrm[o] = s;
+    }
+    if (lane == 0) { key[o] = ~0ull; ccount[o] = 0; }
+}
+
+__device__ __forceinline__ unsigned long long pack_key(float d2, int idx) {
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)idx;
+}
+
+// One 128x128 tile of the distance matrix of one pair.
+__global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_stride) {
+    using T = GemmTile<2, 2, 2, 2>;
+    extern __shared__ __align__(16) float lds[];
+    __shared__ unsigned long long s_row[T::BM], s_col[T::BN];
+    const int pair = blockIdx.z;
+    const int n1 = count_of(p.n1p, pair * cnt_stride + p.which1, p.cap1);
+    const int n2 = count_of(p.n2p, pair * cnt_stride + p.which2, p.cap2);
+    const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
+    if (m0 >= n1 || n0 >= n2) return;
+    const float* A = p.d1 + (int64_t)pair * p.cap1 * p.D;
+    const float* B = p.d2 + (int64_t)pair * p.cap2 * p.D;
+    const float* arow[T::A_LD]; const float* brow[T::B_LD];
+#pragma unroll
+    for (int s = 0; s < T::A_LD; ++s) { const int m = m0 + T::slot_row(s); arow[s] = m < n1 ? A + (int64_t)m * p.D : nullptr; }
+#pragma unroll
+    for (int s = 0; s < T::B_LD; ++s) { const int n = n0 + T::slot_row(s); brow[s] = n < n2 ? B + (int64_t)n * p.D : nullptr; }
+    auto ldA = [&](int s, int k) -> float4 { return (arow[s] && k < p.D) ? *reinterpret_cast<const float4*>(arow[s] + k) : make_float4(0.f, 0.f, 0.f, 0.f); };
+    auto ldB = [&](int s, int k) -> float4 { return (brow[s] && k < p.D) ? *reinterpret_cast<const float4*>(brow[s] + k) : make_float4(0.f, 0.f, 0.f, 0.f); };
+    for (int i = threadIdx.x; i < T::BM; i += 256) s_row[i] = ~0ull;
+    for (int i = threadIdx.x; i < T::BN; i += 256) s_col[i] = ~0ull;
+    f32x16 acc[2][2];
+    T::run(lds, p.D, ldA, ldB, acc);   // ends with a barrier, so s_row/s_col init is visible
+
+    const float* na = p.na + (int64_t)pair * p.cap1;
+    const float* nb = p.nb + (int64_t)pair * p.cap2;
+    const int lane = threadIdx.x & 63;
+    float nbv[2]; int colg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { colg[j] = n0 + T::col_of(j); nbv[j] = colg[j] < n2 ? nb[colg[j]] : 0.f; }
+    // distances in place; invalid entries -> +inf
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + T::row_of(i, r);
+            const float nav = row < n1 ? na[row] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float d = fmaxf(nav + nbv[j] - 2.f * acc[i][j][r], 0.f);
+                if (row >= n1 || colg[j] >= n2) d = INFINITY;
+                acc[i][j][r] = d;
+            }
+        }
+    // row minima: over j in-lane, then over the 32 lanes of a half (same row), then LDS across waves
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned long long k = pack_key(acc[i][0][r], colg[0]);
+            const unsigned long long k1 = pack_key(acc[i][1][r], colg[1]);
+            k = k1 < k ? k1 : k;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(k, o, 64); k = t < k ? t : k; }
+            if ((lane & 31) == 0) atomicMin(&s_row[T::row_of(i, r)], k);
+        }
+    // column minima: over i, r in-lane, then across the two halves, then LDS across waves
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        unsigned long long k = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long t = pack_key(acc[i][j][r], m0 + T::row_of(i, r));
+                k = t < k ? t : k;
+            }
+        const unsigned long long t = __shfl_xor(k, 32, 64);
+        k = t < k ? t : k;
+        if (lane < 32) atomicMin(&s_col[T::col_of(j)], k);
+    }
+    __syncthreads();
+    // merge with the other tiles; keep the running minimum (old min mine) for the nomination threshold
+    unsigned long long* rk = p.rowkey + (int64_t)pair * p.cap1;
+    unsigned long long* ck = p.colkey + (int64_t)pair * p.cap2;
+    for (int i = threadIdx.x; i < T::BM; i += 256)
+        if (m0 + i < n1) { const unsigned long long mine = s_row[i]; const unsigned long long old = atomicMin(&rk[m0 + i], mine); s_row[i] = old < mine ? old : mine; }
+    for (int i = threadIdx.x; i < T::BN; i += 256)
+        if (n0 + i < n2) { const unsigned long long mine = s_col[i]; const unsigned long long old = atomicMin(&ck[n0 + i], mine); s_col[i] = old < mine ? old : mine; }
+    __syncthreads();
+    // nominate candidates within EPS of the running minima
+    int* rcnt = p.rcnt + (int64_t)pair * p.cap1; int* rcand = p.rcand + (int64_t)pair * p.cap1 * CAND_CAP;
+    int* ccnt = p.ccnt + (int64_t)pair * p.cap2; int* ccand = p.ccand + (int64_t)pair * p.cap2 * CAND_CAP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = T::row_of(i, r), row = m0 + rl;
+            if (row >= n1) continue;
+            const float rmin = __uint_as_float((unsigned int)(s_row[rl] >> 32));
+            const float nav = na[row];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (colg[j] >= n2) continue;
+                const float d = acc[i][j][r];
+                const float eps = MATCH_EPS * (nav + nbv[j] + 1e-30f);
+                if (d <= rmin + eps) { const int pos = atomicAdd(&rcnt[row], 1); if (pos < CAND_CAP) rcand[(int64_t)row * CAND_CAP + pos] = colg[j]; }
+                const float cmin = __uint_as_float((unsigned int)(s_col[T::col_of(j)] >> 32));
+                if (d <= cmin + eps) { const int pos = atomicAdd(&ccnt[colg[j]], 1); if (pos < CAND_CAP) ccand[(int64_t)colg[j] * CAND_CAP + pos] = row; }
+            }
+        }
+}
+
+// Exact nearest neighbour among the nominated candidates (fp64 direct form); one wave per query.
+// Falls back to scanning every target when the candidate list overflowed.
+__global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ dq, const float* __restrict__ dt, const int* __restrict__ nqp,
+                                                           const int* __restrict__ ntp, int cnt_stride, int whichq, int whicht, int capq,
+                                                           int capt, int D, const int* __restrict__ cnt, const int* __restrict__ cand,
+                                                           int* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int pair = blockIdx.y;
+    const int nq = count_of(nqp, pair * cnt_stride + whichq, capq), nt = count_of(ntp, pair * cnt_stride + whicht, capt);
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63;
+    const float* a = dq + ((int64_t)pair * capq + q) * D;
+    const float* tb = dt + (int64_t)pair * capt * D;
+    const int nc = cnt[(int64_t)pair * capq + q];
+    const bool overflow = nc > CAND_CAP;
+    const int total = overflow ? nt : nc;
+    double best = INFINITY; int bi = -1;
+    for (int c = 0; c < total; ++c) {
+        const int t = overflow ? c : cand[((int64_t)pair * capq + q) * CAND_CAP + c];
+        const float* b = tb + (int64_t)t * D;
+        double s = 0.0;
+        for (int k = lane; k < D; k += 64) { const double df = (double)a[k] - (double)b[k]; s = fma(df, df, s); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (s < best || (s == best && t < bi)) { best = s; bi = t; }
+    }
+    if (lane == 0) { idx_out[(int64_t)pair * capq + q] = bi; dist_out[(int64_t)pair * capq + q] = (float)sqrt(best); }
+}
+
+// Mutual test + ordered compaction (ascending queryIdx, like BFMatcher.match output order).
+// mode 0 strict mutual NN: keep q iff idx21[idx12[q]] == q.
+// mode 1 legacy cross-check (OpenCV <= 3.4.1 semantics): for every q the nearest t among
+//        {t : idx21[t] == q} (strict <, ascending t).
+__global__ __launch_bounds__(1024) void match_mutual_kernel(const int* __restrict__ idx12, const float* __restrict__ dist12,
+                                                            const int* __restrict__ idx21, const float* __restrict__ dist21,
+                                                            const int* __restrict__ n1p, const int* __restrict__ n2p, int cnt_stride,
+                                                            int which1, int which2, int cap1, int cap2, int mode,
+                                                            int* __restrict__ mq, int* __restrict__ mt, float* __restrict__ md,
+                                                            int* __restrict__ mcount, unsigned long long* __restrict__ scratch) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int pair = blockIdx.x;
+    const int n1 = count_of(n1p, pair * cnt_stride + which1, cap1), n2 = count_of(n2p, pair * cnt_stride + which2, cap2);
+    const int* i12 = idx12 + (int64_t)pair * cap1; const int* i21 = idx21 + (int64_t)pair * cap2;
+    const float* d12 = dist12 + (int64_t)pair * cap1; const float* d21 = dist21 + (int64_t)pair * cap2;
+    unsigned long long* sk = scratch + (int64_t)pair * cap1;
+    if (mode == 1) {
+        for (int q = threadIdx.x; q < n1; q += 1024) sk[q] = ~0ull;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n2; t += 1024) { const int q = i21[t]; if (q >= 0) atomicMin(&sk[q], pack_key(d21[t], t)); }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    int* oq = mq + (int64_t)pair * cap1; int* ot = mt + (int64_t)pair * cap1; float* od = md + (int64_t)pair * cap1;
+    for (int q0 = 0; q0 < n1; q0 += 1024) {
+        const int q = q0 + threadIdx.x;
+        bool hit = false; int t = -1; float d = 0.f;
+        if (q < n1) {
+            if (mode == 0) { t = i12[q]; hit = t >= 0 && i21[t] == q; d = d12[q]; }
+            else { const unsigned long long k = sk[q]; hit = k != ~0ull; t = (int)(k & 0xffffffffu); d = __uint_as_float((unsigned int)(k >> 32)); }
+        }
+        const unsigned long long bal = __ballot(hit);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (hit) { oq[off + before] = q; ot[off + before] = t; od[off + before] = d; }
+        __syncthreads();
+        if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += s_wave[w]; s_base += s; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mcount[pair] = s_base;
+}
+
+}  // namespace
+
+extern "C" size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2) {
+    const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
+    // na, nb (f32) | rowkey, colkey, scratch (u64) | rcnt, ccnt | rcand, ccand
+    return 4 * (a + b) + 8 * (a + b + a) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 256;
+}
+
+// d1 (pairs, cap1, D), d2 (pairs, cap2, D); counts: device int array, n1 of pair i at counts[i*cnt_stride + which1]
+// (null -> every pair has cap rows).  Outputs (pairs, cap1|cap2): idx12/dist12, idx21/dist21; matches
+// (pairs, cap1) q/t/dist + count per pair.
+extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2,
+                            int pairs, int cap1, int cap2, int D, int mode, int* idx12, float* dist12, int* idx21,
+                            float* dist21, int* match_q, int* match_t, float* match_d, int* match_count, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    XP_CHECK_ARG(d1 && d2 && idx12 && dist12 && idx21 && dist21 && match_q && match_t && match_d && match_count && workspace,
+                 "xp_match_mnn: null pointer");
+    XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D % 4 == 0, "xp_match_mnn: bad shape (D must be a multiple of 4)");
+    XP_CHECK_ARG(mode == 0 || mode == 1, "xp_match_mnn: mode 0 (strict_mnn) or 1 (legacy_crosscheck)");
+    XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2), "xp_match_mnn: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
+    char* w = (char*)workspace;
+    MatchParams p{};
+    p.d1 = d1; p.d2 = d2; p.n1p = counts; p.n2p = counts; p.which1 = which1; p.which2 = which2;
+    p.cap1 = cap1; p.cap2 = cap2; p.D = D;
+    p.rowkey = (unsigned long long*)w; w += 8 * a;
+    p.colkey = (unsigned long long*)w; w += 8 * b;
+    unsigned long long* scratch = (unsigned long long*)w; w += 8 * a;
+    p.na = (float*)w; w += 4 * a;
+    p.nb = (float*)w; w += 4 * b;
+    p.rcnt = (int*)w; w += 4 * a;
+    p.ccnt = (int*)w; w += 4 * b;
+    p.rcand = (int*)w; w += 4 * CAND_CAP * a;
+    p.ccand = (int*)w;
+    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, counts, cnt_stride, which1, cap1, D, p.na, p.rowkey, p.rcnt);
+    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, counts, cnt_stride, which2, cap2, D, p.nb, p.colkey, p.ccnt);
+    using T = GemmTile<2, 2, 2, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        attr_set = true;
+    }
+    dim3 grid(xp_cdiv(cap2, T::BN), xp_cdiv(cap1, T::BM), pairs);
+    hipLaunchKernelGGL(match_tile_kernel, grid, dim3(256), T::kLdsBytes, s, p, cnt_stride);
+    hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
+                       cap1, cap2, D, p.rcnt, p.rcand, idx12, dist12);
+    hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, d1, counts, counts, cnt_stride, which2, which1,
+                       cap2, cap1, D, p.ccnt, p.ccand, idx21, dist21);
+    hipLaunchKernelGGL(match_mutual_kernel, dim3(pairs), dim3(1024), 0, s, idx12, dist12, idx21, dist21, counts, counts, cnt_stride, which1,
+                       which2, cap1, cap2, mode, match_q, match_t, match_d, match_count, scratch);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}

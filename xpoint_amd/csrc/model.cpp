@@ -1,0 +1,228 @@
+// Host-side orchestration of the XPoint forward (reference XPoint.py:283-323 forward_impl with the
+// VMamba encoder, VMamba.py:1507-1525): a fixed sequence of kernel launches on one HIP stream.
+// The context is host-only metadata (model dims + the device-format parameter table); weights and
+// workspace are caller-owned device buffers, so the library never allocates device memory.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "xp_common.h"
+#include "../../include/xpoint_hip.h"
+
+namespace {
+
+struct Param { std::string name; size_t offset; size_t numel; };
+
+struct Ctx {
+    xp_model_cfg cfg;
+    int nstages;
+    int dims[4], ranks[4];
+    std::vector<Param> params;
+    size_t total;
+    size_t add(const std::string& n, size_t numel) {
+        size_t off = total;
+        params.push_back({n, off, numel});
+        total += (numel + 3) / 4 * 4;   // keep every tensor 16-byte aligned inside the blob
+        return off;
+    }
+    size_t off(const std::string& n) const {
+        for (auto& p : params) if (p.name == n) return p.offset;
+        return (size_t)-1;
+    }
+};
+
+int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1
+
+void build_layout(Ctx& c) {
+    const int E = c.cfg.embed_dim, N = c.cfg.d_state;
+    c.total = 0;
+    c.add("stem.w", 9 * (E / 2)); c.add("stem.b", E / 2); c.add("stem.ln_w", E / 2); c.add("stem.ln_b", E / 2);
+    c.add("pe2.w", (size_t)E * 9 * (E / 2)); c.add("pe2.b", E); c.add("pe2.ln_w", E); c.add("pe2.ln_b", E);
+    for (int s = 0; s < c.nstages; ++s) {
+        const size_t C = c.dims[s], R = c.ranks[s], H4 = (size_t)(C * c.cfg.mlp_ratio);
+        for (int j = 0; j < c.cfg.depths[s]; ++j) {
+            std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
+            c.add(b + "ln1_w", C); c.add(b + "ln1_b", C);
+            c.add(b + "in_w", C * C);
+            c.add(b + "dw_w", 9 * C);
+            c.add(b + "xproj_w", 4 * (R + 2 * N) * C);
+            c.add(b + "dt_w", 4 * C * R); c.add(b + "dt_b", 4 * C);
+            c.add(b + "A", 4 * C * N); c.add(b + "D", 4 * C);
+            c.add(b + "onorm_w", C); c.add(b + "onorm_b", C);
+            c.add(b + "out_w", C * C);
+            c.add(b + "ln2_w", C); c.add(b + "ln2_b", C);
+            c.add(b + "fc1_w", H4 * C); c.add(b + "fc1_b", H4);
+            c.add(b + "fc2_w", C * H4); c.add(b + "fc2_b", C);
+        }
+        if (s < c.nstages - 1) {
+            std::string d = "s" + std::to_string(s) + ".ds.";
+            c.add(d + "w", 2 * C * 9 * C); c.add(d + "b", 2 * C); c.add(d + "ln_w", 2 * C); c.add(d + "ln_b", 2 * C);
+        }
+    }
+    const size_t HC = c.cfg.head_channels, EC = E / 2, DS = c.cfg.desc_size, DET = c.cfg.det_channels;
+    c.add("head.w", 2 * HC * 9 * EC); c.add("head.b", 2 * HC); c.add("head.scale", 2 * HC); c.add("head.shift", 2 * HC);
+    c.add("det2.w", DET * HC); c.add("det2.b", DET); c.add("det2.scale", DET); c.add("det2.shift", DET);
+    c.add("desc2.w", DS * HC); c.add("desc2.b", DS); c.add("desc2.scale", DS); c.add("desc2.shift", DS);
+}
+
+struct Shapes {
+    int Hs, Ws;            // stem output
+    int H[4], W[4];        // per stage
+    int Hc, Wc;            // encoder output (x4 of the last stage)
+    int64_t M[4];
+};
+
+bool shapes_of(const Ctx& c, int batch, int H, int W, Shapes& s) {
+    s.Hs = conv_out(H); s.Ws = conv_out(W);
+    s.H[0] = conv_out(s.Hs); s.W[0] = conv_out(s.Ws);
+    for (int i = 1; i < c.nstages; ++i) { s.H[i] = conv_out(s.H[i - 1]); s.W[i] = conv_out(s.W[i - 1]); }
+    for (int i = 0; i < c.nstages; ++i) s.M[i] = (int64_t)batch * s.H[i] * s.W[i];
+    s.Hc = s.H[c.nstages - 1] * 4; s.Wc = s.W[c.nstages - 1] * 4;
+    return s.H[c.nstages - 1] > 0 && s.W[c.nstages - 1] > 0;
+}
+
+struct WsPlan { size_t X, T1, T2, T3, HB, XD, SS, total_floats; size_t ss_bytes; };
+
+WsPlan plan_ws(const Ctx& c, int batch, const Shapes& s) {
+    WsPlan w{};
+    size_t mc = 0, mh = 0, mx = 0, ss = 0;
+    for (int i = 0; i < c.nstages; ++i) {
+        const size_t MC = (size_t)s.M[i] * c.dims[i];
+        mc = std::max(mc, MC);
+        mh = std::max(mh, (size_t)(MC * c.cfg.mlp_ratio));
+        mx = std::max(mx, (size_t)s.M[i] * 4 * (c.ranks[i] + 2 * c.cfg.d_state));
+        ss = std::max(ss, xp_ss2d_core_workspace_bytes(batch, s.H[i], s.W[i], c.dims[i]));
+    }
+    mh = std::max(mh, (size_t)batch * s.Hs * s.Ws * (c.cfg.embed_dim / 2));           // stem output aliases HB
+    mh = std::max(mh, (size_t)batch * s.Hc * s.Wc * 2 * c.cfg.head_channels);         // head trunk aliases HB
+    mc = std::max(mc, (size_t)batch * s.Hc * s.Wc * (size_t)std::max(c.cfg.desc_size, c.cfg.det_channels + 3));
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    size_t o = 0;
+    w.X = o; o += al(mc); w.T1 = o; o += al(mc); w.T2 = o; o += al(mc); w.T3 = o; o += al(mc);
+    w.HB = o; o += al(mh); w.XD = o; o += al(mx); w.SS = o; o += al(ss / 4 + 1);
+    w.total_floats = o; w.ss_bytes = ss;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int xp_ctx_create(const xp_model_cfg* cfg, void** ctx_out) {
+    XP_CHECK_ARG(cfg && ctx_out, "xp_ctx_create: null pointer");
+    XP_CHECK_ARG(cfg->n_stages >= 1 && cfg->n_stages <= 4, "xp_ctx_create: n_stages must be 1..4");
+    XP_CHECK_ARG(cfg->embed_dim % 32 == 0 && (cfg->embed_dim == 96 || cfg->embed_dim == 32),
+                 "xp_ctx_create: embed_dim must be 96 (XPoint config) or 32 (reduced test model), got %d", cfg->embed_dim);
+    XP_CHECK_ARG(cfg->d_state == 1, "xp_ctx_create: the fused encoder implements d_state == 1 (XPoint config); got %d", cfg->d_state);
+    XP_CHECK_ARG(cfg->head_channels % 4 == 0 && cfg->desc_size > 0 && cfg->det_channels == 65, "xp_ctx_create: bad head dims");
+    Ctx* c = new Ctx();
+    c->cfg = *cfg;
+    c->nstages = cfg->n_stages;
+    for (int s = 0; s < c->nstages; ++s) {
+        c->dims[s] = cfg->embed_dim << s;
+        c->ranks[s] = cfg->dt_rank > 0 ? cfg->dt_rank : (c->dims[s] + 15) / 16;   // "auto" = ceil(d_model / 16), VMamba.py:414
+        XP_CHECK_ARG(cfg->depths[s] >= 0, "xp_ctx_create: negative depth");
+    }
+    build_layout(*c);
+    *ctx_out = c;
+    return XP_OK;
+}
+
+extern "C" int xp_ctx_destroy(void* ctx) { delete (Ctx*)ctx; return XP_OK; }
+
+extern "C" int xp_param_count(void* ctx) { return ctx ? (int)((Ctx*)ctx)->params.size() : -1; }
+extern "C" size_t xp_weights_numel(void* ctx) { return ctx ? ((Ctx*)ctx)->total : 0; }
+
+extern "C" int xp_param_info(void* ctx, int index, char* name, int name_len, size_t* offset, size_t* numel) {
+    XP_CHECK_ARG(ctx && name && offset && numel, "xp_param_info: null pointer");
+    Ctx* c = (Ctx*)ctx;
+    XP_CHECK_ARG(index >= 0 && index < (int)c->params.size(), "xp_param_info: index out of range");
+    const Param& p = c->params[index];
+    strncpy(name, p.name.c_str(), name_len - 1); name[name_len - 1] = 0;
+    *offset = p.offset; *numel = p.numel;
+    return XP_OK;
+}
+
+extern "C" int xp_forward_shapes(void* ctx, int batch, int H, int W, int* Hc, int* Wc, int* enc_channels) {
+    XP_CHECK_ARG(ctx, "xp_forward_shapes: null ctx");
+    Ctx* c = (Ctx*)ctx; Shapes s;
+    XP_CHECK_ARG(shapes_of(*c, batch, H, W, s), "xp_forward_shapes: image too small");
+    if (Hc) *Hc = s.Hc; if (Wc) *Wc = s.Wc; if (enc_channels) *enc_channels = c->cfg.embed_dim / 2;
+    return XP_OK;
+}
+
+extern "C" size_t xp_forward_workspace_bytes(void* ctx, int batch, int H, int W) {
+    if (!ctx) return 0;
+    Ctx* c = (Ctx*)ctx; Shapes s;
+    if (!shapes_of(*c, batch, H, W, s)) return 0;
+    return plan_ws(*c, batch, s).total_floats * sizeof(float);
+}
+
+#define RUN(call) do { int rc__ = (call); if (rc__ != XP_OK) return rc__; } while (0)
+
+extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const float* images, int batch, int H, int W,
+                                 void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
+                                 float* logits_nhwc, void* stream) {
+    XP_CHECK_ARG(ctx && weights && images && workspace && enc_nhwc, "xp_xpoint_forward: null pointer");
+    XP_CHECK_ARG(batch > 0, "xp_xpoint_forward: empty batch");
+    Ctx* c = (Ctx*)ctx; Shapes sh;
+    XP_CHECK_ARG(shapes_of(*c, batch, H, W, sh), "xp_xpoint_forward: image too small");
+    // The reference mis-sizes its outputs when H or W is not a multiple of 32; the drop-in refuses instead.
+    XP_CHECK_ARG(H % 32 == 0 && W % 32 == 0, "xp_xpoint_forward: H and W must be multiples of 32 for the VMamba encoder (got %dx%d)", H, W);
+    const WsPlan wp = plan_ws(*c, batch, sh);
+    XP_CHECK_ARG(workspace_bytes >= wp.total_floats * sizeof(float), "xp_xpoint_forward: workspace too small");
+    float* ws = (float*)workspace;
+    float *X = ws + wp.X, *T1 = ws + wp.T1, *T2 = ws + wp.T2, *T3 = ws + wp.T3, *HB = ws + wp.HB, *XD = ws + wp.XD, *SS = ws + wp.SS;
+    auto P = [&](const std::string& n) -> const float* { return weights + c->off(n); };
+    const float eps = 1e-5f;
+    const int E = c->cfg.embed_dim;
+
+    // patch embed (VMamba.py:1405-1420)
+    RUN(xp_stem_conv_ln_gelu(images, P("stem.w"), P("stem.b"), P("stem.ln_w"), P("stem.ln_b"), HB, batch, H, W, E / 2, eps, stream));
+    RUN(xp_conv3x3_nhwc(HB, P("pe2.w"), T1, P("pe2.b"), nullptr, nullptr, batch, sh.Hs, sh.Ws, E / 2, E, 2, 0, 0, stream));
+    RUN(xp_layernorm(T1, X, P("pe2.ln_w"), P("pe2.ln_b"), sh.M[0], E, eps, 0, stream));
+
+    for (int s = 0; s < c->nstages; ++s) {
+        const int C = c->dims[s], R = c->ranks[s], H4 = (int)(C * c->cfg.mlp_ratio);
+        const int M = (int)sh.M[s];
+        const int XW = 4 * (R + 2);
+        for (int j = 0; j < c->cfg.depths[s]; ++j) {
+            const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
+            // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
+            RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
+            RUN(xp_gemm_nt(T1, P(b + "in_w"), T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0, stream));
+            RUN(xp_dwconv3x3_silu(T2, P(b + "dw_w"), T3, batch, sh.H[s], sh.W[s], C, stream));
+            RUN(xp_gemm_nt(T3, P(b + "xproj_w"), XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0, stream));
+            RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
+                                 T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
+            RUN(xp_gemm_nt(T1, P(b + "out_w"), X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0, stream));
+            // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
+            RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
+            RUN(xp_gemm_nt(T1, P(b + "fc1_w"), HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1, stream));
+            RUN(xp_gemm_nt(HB, P(b + "fc2_w"), X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0, stream));
+        }
+        if (s < c->nstages - 1) {   // downsample v3 (VMamba.py:1432-1440)
+            const std::string d = "s" + std::to_string(s) + ".ds.";
+            RUN(xp_conv3x3_nhwc(X, P(d + "w"), T1, P(d + "b"), nullptr, nullptr, batch, sh.H[s], sh.W[s], C, 2 * C, 2, 0, 0, stream));
+            RUN(xp_layernorm(T1, X, P(d + "ln_w"), P(d + "ln_b"), sh.M[s + 1], 2 * C, eps, 0, stream));
+        }
+    }
+    const int L = c->nstages - 1;
+    RUN(xp_depth_to_space_nhwc(X, enc_nhwc, batch, sh.H[L], sh.W[L], c->dims[L], 4, stream));   // VMamba.py:1500-1505
+
+    // heads (XPoint.py:112-138, :348-371): shared 3x3 trunk GEMM for both heads, then the two 1x1 convs
+    const int EC = c->dims[L] / 16, HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
+    const int Mc = batch * sh.Hc * sh.Wc;
+    if (prob || logits_nhwc || desc_nhwc) {
+        RUN(xp_conv3x3_nhwc(enc_nhwc, P("head.w"), HB, P("head.b"), P("head.scale"), P("head.shift"), batch, sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2, stream));
+    }
+    if (prob || logits_nhwc) {
+        float* lg = logits_nhwc ? logits_nhwc : T2;
+        RUN(xp_gemm_nt(HB, P("det2.w"), lg, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0, stream));
+        if (prob) RUN(xp_softmax_shuffle(lg, prob, batch, sh.Hc, sh.Wc, 8, DET, 0, stream));
+    }
+    if (desc_nhwc) {
+        RUN(xp_gemm_nt(HB + HC, P("desc2.w"), T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0, stream));
+        RUN(xp_l2norm_rows(T1, desc_nhwc, Mc, DS, 1e-12f, stream));
+    }
+    return XP_OK;
+}

@@ -1,0 +1,315 @@
+"""Host-side mirror of the reference model interface for the hot path:
+`xpoint.models.XPoint` (reference xpoint/models/XPoint.py:28-214) — same constructor config,
+`forward(data)`, `takes_pair()`, `get_encoder_downsample_ratio()`, `set_force_return_logits()`,
+`load_state_dict()` with the reference's key names — over the HIP C ABI (include/xpoint_hip.h).
+
+PyTorch here is plumbing only: device buffers, the weight re-layout at load time, streams.
+There is no CPU path: forward() on CPU tensors raises.
+"""
+from __future__ import annotations
+
+import collections
+import copy
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_i, ptr
+from .utils import dict_update
+
+
+class _ModelCfg(ctypes.Structure):
+    _fields_ = [("embed_dim", c_i), ("n_stages", c_i), ("depths", c_i * 4), ("d_state", c_i), ("dt_rank", c_i),
+                ("mlp_ratio", ctypes.c_float), ("head_channels", c_i), ("desc_size", c_i), ("det_channels", c_i)]
+
+
+_LoadResult = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+_DIR_ORDER = [0, 2, 1, 3]   # device order of the four scan routes (row pair, then column pair)
+
+
+class XPoint(torch.nn.Module):
+    # reference XPoint.py:29-59
+    default_config = {
+        'multispectral': True, 'descriptor_head': True, 'intepolation_mode': 'bilinear', 'descriptor_size': 256,
+        'normalize_descriptors': True, 'final_batchnorm': True, 'reflection_pad': True, 'bn_first': False,
+        'double_convolution': True, 'channel_version': 0, 'verbose': False, 'mixed_precision': False,
+        'force_return_logits': False, 'takes_pair': False,
+        'homography_regression_head': {'check': False, 'type': 'HomographyNet'},
+        'use_attention': {'check': False, 'type': 'SimpleViT', 'height': 256, 'width': 256,
+                          'pretrained': {'check': True, 'type_dir': "model_weights/swinv2-imagenet/base256"}},
+    }
+
+    def __init__(self, config=None):
+        super().__init__()
+        if config:
+            self.config = dict_update(copy.deepcopy(self.default_config), config)
+        else:
+            self.config = copy.deepcopy(self.default_config)
+        ua = self.config['use_attention']
+        if not (ua['check'] and ua['type'] == 'VMamba'):
+            raise NotImplementedError("xpoint_amd.models.XPoint implements the VMamba encoder (use_attention.type 'VMamba', "
+                                      "model_weights/XPoint-EXP1/params.yaml); conv / SwinV2 encoders are out of scope")
+        if self.config['multispectral']:
+            raise NotImplementedError("multispectral two-encoder routing (XPoint.py:284-305) is out of scope; XPoint-EXP1 uses one shared encoder")
+        for k, v in (('reflection_pad', True), ('bn_first', False), ('final_batchnorm', True), ('descriptor_head', True),
+                     ('normalize_descriptors', True)):
+            if self.config[k] != v:
+                raise NotImplementedError(f"config['{k}'] = {self.config[k]!r} is not implemented (XPoint-EXP1 uses {v!r})")
+        if self.config['homography_regression_head']['check']:
+            assert self.config['takes_pair'], "RegNet can only be used with takes_pair=True"       # XPoint.py:103
+        vssm = ua['model_parameters']['MODEL']['VSSM']
+        if vssm.get('SSM_FORWARDTYPE', 'v05_noz') != 'v05_noz' or float(vssm.get('SSM_RATIO', 1.0)) != 1.0:
+            raise NotImplementedError("only SSM_FORWARDTYPE v05_noz / SSM_RATIO 1.0 (the XPoint config) is implemented")
+        self.encoder_downsample_ratio = 8
+        self.detector_head_last_dim = 65
+        self.head_channels = 256
+        depths = list(vssm['DEPTHS'])
+        cfg = _ModelCfg()
+        cfg.embed_dim = int(vssm['EMBED_DIM']); cfg.n_stages = len(depths)
+        for i, d in enumerate(depths):
+            cfg.depths[i] = int(d)
+        cfg.d_state = int(vssm['SSM_D_STATE'])
+        cfg.dt_rank = 0 if vssm.get('SSM_DT_RANK', 'auto') == 'auto' else int(vssm['SSM_DT_RANK'])
+        cfg.mlp_ratio = float(vssm.get('MLP_RATIO', 4.0))
+        cfg.head_channels = 256; cfg.desc_size = int(self.config['descriptor_size']); cfg.det_channels = 65
+        self._cfg = cfg
+        self._ctx = ctypes.c_void_p()
+        _lib.check(_lib.load().xp_ctx_create(ctypes.byref(cfg), ctypes.byref(self._ctx)), "xp_ctx_create")
+        self._layout = self._read_layout()
+        self._ref_state: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
+        self._blob: Optional[torch.Tensor] = None        # device-format weights (one float32 tensor)
+        self._device = torch.device("cpu")
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.n_channels = [1, 64, 64, 128, cfg.embed_dim // 2]
+
+    # ------------------------------------------------------------------ reference surface
+    def takes_pair(self):
+        return self.config['takes_pair']
+
+    def get_encoder_downsample_ratio(self):
+        return self.encoder_downsample_ratio
+
+    def set_force_return_logits(self, value):
+        if not isinstance(value, bool):
+            raise ValueError('set_force_return_logits: The input value needs to be a bool')      # XPoint.py:175-179
+        self.config['force_return_logits'] = value
+
+    def __del__(self):
+        try:
+            if self._ctx:
+                _lib.load().xp_ctx_destroy(self._ctx)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def _read_layout(self):
+        lib = _lib.load()
+        out = collections.OrderedDict()
+        name = ctypes.create_string_buffer(128)
+        off = ctypes.c_size_t(); num = ctypes.c_size_t()
+        for i in range(lib.xp_param_count(self._ctx)):
+            _lib.check(lib.xp_param_info(self._ctx, i, name, 128, ctypes.byref(off), ctypes.byref(num)), "xp_param_info")
+            out[name.value.decode()] = (off.value, num.value)
+        return out
+
+    def expected_keys(self):
+        from .synth import xpoint_state_spec
+        return xpoint_state_spec(self.config)
+
+    def state_dict(self, *a, **k):
+        return collections.OrderedDict(self._ref_state)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's key names.  Like nn.Module.load_state_dict:
+        returns (missing_keys, unexpected_keys); raises on strict mismatch or shape mismatch."""
+        spec = self.expected_keys()
+        sd = {}
+        for k, v in state_dict.items():
+            # legacy VMamba renames (reference VMamba.py:1577-1583)
+            k = k.replace(".ln_1.", ".norm.").replace(".self_attention.", ".op.")
+            sd[k] = v
+        missing = [k for k in spec if k not in sd]
+        unexpected = [k for k in sd if k not in spec]
+        for k, (shape, _) in spec.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(shape)}")
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        for k in spec:
+            if k in sd:
+                t = sd[k]
+                t = torch.from_numpy(np.array(t, copy=True)) if isinstance(t, np.ndarray) else t
+                self._ref_state[k] = t.detach().to("cpu").clone()
+        self._blob = None
+        return _LoadResult(missing, unexpected)
+
+    def _bn_affine(self, pre, eps=1e-5):
+        s = self._ref_state
+        scale = s[pre + "weight"].double() / torch.sqrt(s[pre + "running_var"].double() + eps)
+        shift = s[pre + "bias"].double() - s[pre + "running_mean"].double() * scale
+        return scale.float(), shift.float()
+
+    def _device_params(self):
+        """reference state dict -> device-format tensors (names of csrc/model.cpp build_layout)."""
+        s = self._ref_state
+        missing = [k for k, (_, kind) in self.expected_keys().items() if k not in s and kind != "bn_count"
+                   and not k.startswith("hm_regressor.")]
+        if missing:
+            raise RuntimeError(f"XPoint: weights not loaded ({len(missing)} tensors missing, e.g. {missing[:3]}); "
+                               "call load_state_dict first")
+        out = {}
+        e = "encoder."
+        w0 = s[e + "patch_embed.0.weight"].double().sum(dim=1)                 # gray replicated to 3 channels (VMamba.py:1509)
+        out["stem.w"] = w0.permute(1, 2, 0).reshape(9, -1).float()
+        out["stem.b"] = s[e + "patch_embed.0.bias"]
+        out["stem.ln_w"] = s[e + "patch_embed.2.weight"]; out["stem.ln_b"] = s[e + "patch_embed.2.bias"]
+        out["pe2.w"] = s[e + "patch_embed.5.weight"].permute(0, 2, 3, 1)
+        out["pe2.b"] = s[e + "patch_embed.5.bias"]
+        out["pe2.ln_w"] = s[e + "patch_embed.7.weight"]; out["pe2.ln_b"] = s[e + "patch_embed.7.bias"]
+        for st in range(self._cfg.n_stages):
+            for j in range(self._cfg.depths[st]):
+                r = f"{e}layers.{st}.blocks.{j}."
+                d = f"s{st}.b{j}."
+                C = s[r + "norm.weight"].shape[0]
+                out[d + "ln1_w"] = s[r + "norm.weight"]; out[d + "ln1_b"] = s[r + "norm.bias"]
+                out[d + "in_w"] = s[r + "op.in_proj.weight"]
+                out[d + "dw_w"] = s[r + "op.conv2d.weight"].reshape(C, 9).t()
+                out[d + "xproj_w"] = s[r + "op.x_proj_weight"][_DIR_ORDER]
+                out[d + "dt_w"] = s[r + "op.dt_projs_weight"][_DIR_ORDER]
+                out[d + "dt_b"] = s[r + "op.dt_projs_bias"][_DIR_ORDER]
+                out[d + "A"] = (-torch.exp(s[r + "op.A_logs"].float())).view(4, C, -1)[_DIR_ORDER]      # VMamba.py:619
+                out[d + "D"] = s[r + "op.Ds"].view(4, C)[_DIR_ORDER]
+                out[d + "onorm_w"] = s[r + "op.out_norm.weight"]; out[d + "onorm_b"] = s[r + "op.out_norm.bias"]
+                out[d + "out_w"] = s[r + "op.out_proj.weight"]
+                out[d + "ln2_w"] = s[r + "norm2.weight"]; out[d + "ln2_b"] = s[r + "norm2.bias"]
+                out[d + "fc1_w"] = s[r + "mlp.fc1.weight"]; out[d + "fc1_b"] = s[r + "mlp.fc1.bias"]
+                out[d + "fc2_w"] = s[r + "mlp.fc2.weight"]; out[d + "fc2_b"] = s[r + "mlp.fc2.bias"]
+            if st < self._cfg.n_stages - 1:
+                r = f"{e}layers.{st}.downsample."
+                d = f"s{st}.ds."
+                out[d + "w"] = s[r + "1.weight"].permute(0, 2, 3, 1); out[d + "b"] = s[r + "1.bias"]
+                out[d + "ln_w"] = s[r + "3.weight"]; out[d + "ln_b"] = s[r + "3.bias"]
+        det, dsc = "detector_head_convolutions.", "descriptor_head_convolutions."
+        out["head.w"] = torch.cat([s[det + "1.weight"], s[dsc + "1.weight"]], 0).permute(0, 2, 3, 1)
+        out["head.b"] = torch.cat([s[det + "1.bias"], s[dsc + "1.bias"]], 0)
+        a, b = self._bn_affine(det + "3."), self._bn_affine(dsc + "3.")
+        out["head.scale"] = torch.cat([a[0], b[0]]); out["head.shift"] = torch.cat([a[1], b[1]])
+        out["det2.w"] = s[det + "4.weight"].reshape(s[det + "4.weight"].shape[0], -1); out["det2.b"] = s[det + "4.bias"]
+        out["det2.scale"], out["det2.shift"] = self._bn_affine(det + "5.")
+        out["desc2.w"] = s[dsc + "4.weight"].reshape(s[dsc + "4.weight"].shape[0], -1); out["desc2.b"] = s[dsc + "4.bias"]
+        out["desc2.scale"], out["desc2.shift"] = self._bn_affine(dsc + "5.")
+        return out
+
+    def pack_weights(self) -> torch.Tensor:
+        """The device-format blob on the CPU (one float32 vector); what rank 0 broadcasts over RCCL."""
+        total = _lib.load().xp_weights_numel(self._ctx)
+        blob = torch.zeros(total, dtype=torch.float32)
+        dp = self._device_params()
+        for name, (off, num) in self._layout.items():
+            t = dp[name].contiguous().float().reshape(-1)
+            if t.numel() != num:
+                raise RuntimeError(f"internal: {name} has {t.numel()} elements, layout expects {num}")
+            blob[off:off + num] = t
+        return blob
+
+    def weights_numel(self) -> int:
+        return int(_lib.load().xp_weights_numel(self._ctx))
+
+    def set_weight_blob(self, blob: torch.Tensor):
+        """Adopt an already packed device blob (e.g. received by RCCL broadcast)."""
+        assert blob.is_cuda and blob.dtype == torch.float32 and blob.numel() == self.weights_numel()
+        self._blob = blob.contiguous()
+        self._device = blob.device
+
+    def to(self, device=None, *a, **k):
+        if device is not None:
+            self._device = torch.device(device)
+            if self._blob is not None and self._blob.device != self._device:
+                self._blob = self._blob.to(self._device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, n_img, H, W, device):
+        key = (n_img, H, W, str(device))
+        if key not in self._ws:
+            nbytes = _lib.load().xp_forward_workspace_bytes(self._ctx, n_img, H, W)
+            if nbytes == 0:
+                raise RuntimeError(f"XPoint: invalid image size {H}x{W}")
+            self._ws.clear()
+            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws[key]
+
+    def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False):
+        """images (N,1,H,W) float32 on the GPU -> dict of NHWC device tensors (no layout exports):
+        prob (N,H,W), desc_nhwc (N,Hc,Wc,D), enc_nhwc (N,Hc,Wc,E/2), logits_nhwc (N,Hc,Wc,65)."""
+        if not images.is_cuda:
+            raise RuntimeError("xpoint_amd.XPoint runs on the GPU only (no CPU fallback): move the data to 'cuda'")
+        if self.training:
+            raise RuntimeError("xpoint_amd.XPoint is inference-only: call .eval()")
+        if images.dim() != 4 or images.shape[1] != 1:
+            raise RuntimeError("image must be (B,1,H,W)")
+        images = images.contiguous().float()
+        dev = images.device
+        if self._blob is None or self._blob.device != dev:
+            self._blob = self.pack_weights().to(dev)
+        n, _, H, W = images.shape
+        lib = _lib.load()
+        Hc = c_i(); Wc = c_i(); Ce = c_i()
+        _lib.check(lib.xp_forward_shapes(self._ctx, n, H, W, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)), "xp_forward_shapes")
+        Hc, Wc, Ce = Hc.value, Wc.value, Ce.value
+        ws = self._workspace(n, H, W, dev)
+        out = {"enc_nhwc": torch.empty((n, Hc, Wc, Ce), device=dev)}
+        out["prob"] = torch.empty((n, H, W), device=dev) if want_prob else None
+        out["desc_nhwc"] = torch.empty((n, Hc, Wc, self._cfg.desc_size), device=dev) if want_desc else None
+        out["logits_nhwc"] = torch.empty((n, Hc, Wc, 65), device=dev) if want_logits else None
+        _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(self._blob), ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
+                                         ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
+                                         _lib.current_stream()), "xp_xpoint_forward")
+        return out
+
+    @staticmethod
+    def _nchw(t):
+        n, h, w, c = t.shape
+        y = torch.empty((n, c, h, w), device=t.device)
+        _lib.call("xp_nhwc_to_nchw", ptr(t), ptr(y), c_i(n), c_i(h * w), c_i(c), _lib.current_stream())
+        return y
+
+    def _export(self, raw, sl):
+        """reference forward_impl output dict (XPoint.py:311-323) for images raw[sl]."""
+        logits_mode = self.config['force_return_logits']
+        out = {'prob': None if logits_mode else raw["prob"][sl].unsqueeze(1),
+               'logits': self._nchw(raw["logits_nhwc"][sl]) if logits_mode else None,
+               'desc': self._nchw(raw["desc_nhwc"][sl]),
+               'encoder_output': self._nchw(raw["enc_nhwc"][sl]),
+               # extra (not in the reference): the NHWC descriptor volume the sampling kernel reads directly
+               'desc_nhwc': raw["desc_nhwc"][sl]}
+        return out
+
+    def forward_impl(self, data):
+        lm = self.config['force_return_logits']
+        raw = self.forward_raw(data['image'], want_prob=not lm, want_logits=lm)
+        return self._export(raw, slice(0, data['image'].shape[0]))
+
+    def forward(self, data):
+        """reference XPoint.py:181-214.  Both spectra share one encoder (multispectral False), so the optical
+        and thermal batches run as ONE 2B-image batch."""
+        if not self.takes_pair():
+            return self.forward_impl(data)
+        io, it = data["optical"]["image"], data["thermal"]["image"]
+        lm = self.config['force_return_logits']
+        raw = self.forward_raw(torch.cat([io, it], 0), want_prob=not lm, want_logits=lm)
+        B = io.shape[0]
+        pred_optical = self._export(raw, slice(0, B))
+        pred_thermal = self._export(raw, slice(B, B + it.shape[0]))
+        pred_hm = None
+        if self.config["homography_regression_head"]["check"]:
+            from .regnet import regnet_forward
+            pred_hm = regnet_forward(self, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
+        return pred_optical, pred_thermal, pred_hm

@@ -1,0 +1,170 @@
+"""The reference's two prediction flows as functions (they are scripts upstream):
+  predict_align_image_pair  — reference predict_align_image_pair.py:176-264 (= benchmark_evaluation.py:16-142,
+                              demo.py:30-69,427-462): forward -> prob*mask -> box_nms -> nonzero ->
+                              interpolate_descriptors -> get_matches.
+  predict_keypoints         — reference predict_keypoints.py:144-216: NMS on the UNMASKED prob, mask applied at
+                              extraction.
+plus `PairPipeline`, the batched device-resident form of the first flow used by bench.py (no host
+synchronisation between stages, preallocated buffers)."""
+from __future__ import annotations
+
+import copy
+import ctypes
+
+import torch
+
+from . import _lib
+from . import utils
+from ._lib import c_i, ptr
+
+# reference configs/cipdp.yaml:47-61
+DEFAULT_PREDICTION = dict(detection_threshold=0.015, nms=8, cpu_nms=True, topk=0,
+                          matching=dict(method="bfmatcher", knn_matches=False, method_kwargs=dict(crossCheck=True)))
+
+
+def _cfg(pred):
+    c = copy.deepcopy(DEFAULT_PREDICTION)
+    if pred:
+        utils.dict_update(c, pred)
+    return c
+
+
+def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_mnn"):
+    """data: the reference pair dict ({'optical': {'image','valid_mask',...}, 'thermal': {...}}) on the GPU.
+    Returns (out_optical, out_thermal, results) where results[i] = dict(kp_optical, kp_thermal (N,2) int64 (y,x),
+    desc_optical, desc_thermal (N,D), matches [DMatch])."""
+    pred = _cfg(cfg_prediction)
+    if net.takes_pair():
+        out_o, out_t, _ = net(data)
+    else:
+        out_o, out_t = net(data['optical']), net(data['thermal'])
+    thr = pred['detection_threshold']
+    H, W = data['optical']['image'].shape[2:]
+    for out, spec in ((out_o, 'optical'), (out_t, 'thermal')):
+        p = out['prob'] * data[spec]['valid_mask']
+        if pred['nms'] > 0:
+            p = utils.box_nms(p, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'])
+        out['prob'] = p
+    results = []
+    for i in range(out_o['prob'].shape[0]):
+        ko = torch.nonzero((out_o['prob'][i].squeeze() > thr).float())
+        kt = torch.nonzero((out_t['prob'][i].squeeze() > thr).float())
+        do = utils.interpolate_descriptors_nhwc(ko, out_o['desc_nhwc'][i], H, W)
+        dt = utils.interpolate_descriptors_nhwc(kt, out_t['desc_nhwc'][i], H, W)
+        ms = utils.get_matches(do, dt, pred['matching']['method'], pred['matching']['knn_matches'], mode=match_mode,
+                               **pred['matching']['method_kwargs'])
+        results.append(dict(kp_optical=ko, kp_thermal=kt, desc_optical=do, desc_thermal=dt, matches=ms))
+    return out_o, out_t, results
+
+
+def predict_keypoints(net, data, cfg_prediction=None):
+    """Returns ([kp per optical image], [kp per thermal image]); kp (N,2) int64 (y,x)."""
+    pred = _cfg(cfg_prediction)
+    if net.takes_pair():
+        out_o, out_t, _ = net(data)
+    else:
+        out_o, out_t = net(data['optical']), net(data['thermal'])
+    thr = pred['detection_threshold']
+    res = []
+    for out, spec in ((out_o, 'optical'), (out_t, 'thermal')):
+        p = out['prob']
+        if pred['nms'] > 0:
+            p = utils.box_nms(p, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'])
+        m = data[spec]['valid_mask']
+        res.append([torch.nonzero((p[i].squeeze() > thr).float() * m[i].squeeze()) for i in range(p.shape[0])])
+    return res[0], res[1]
+
+
+class PairPipeline:
+    """encode + detect + describe + match for a batch of B pairs, entirely stream-ordered on the device.
+
+    run() enqueues: one 2B-image forward, prob*mask, box NMS (fixed number of sweeps, verified afterwards),
+    keypoint extraction, descriptor sampling, mutual-NN matching.  Results stay on the GPU; `fetch()`
+    synchronises, checks NMS convergence / capacity and returns host lists."""
+
+    def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=6):
+        self.net, self.B, self.H, self.W, self.cap = net, int(batch), int(H), int(W), int(cap)
+        self.pred = _cfg(cfg_prediction)
+        self.mode = match_mode
+        self.sweeps = int(nms_sweeps)
+        dev = torch.device("cuda")
+        n = 2 * self.B
+        lib = _lib.load()
+        self.images = torch.empty((n, 1, H, W), device=dev)
+        self.prob_nms = torch.empty((n, H, W), device=dev)
+        self.prob_masked = torch.empty((n, H, W), device=dev)
+        self.nms_ws = torch.empty(lib.xp_box_nms_workspace_bytes(n, H, W, self.cap), dtype=torch.uint8, device=dev)
+        self.kp = torch.zeros((n, self.cap, 2), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        D = int(net.config['descriptor_size'])
+        self.D = D
+        self.desc = torch.zeros((n, self.cap, D), device=dev)
+        P = self.B
+        self.m = dict(idx12=torch.empty((P, self.cap), dtype=torch.int32, device=dev), dist12=torch.empty((P, self.cap), device=dev),
+                      idx21=torch.empty((P, self.cap), dtype=torch.int32, device=dev), dist21=torch.empty((P, self.cap), device=dev),
+                      match_q=torch.empty((P, self.cap), dtype=torch.int32, device=dev),
+                      match_t=torch.empty((P, self.cap), dtype=torch.int32, device=dev),
+                      match_d=torch.empty((P, self.cap), device=dev), match_count=torch.zeros((P,), dtype=torch.int32, device=dev))
+        self.match_ws = torch.empty(lib.xp_match_workspace_bytes(P, self.cap, self.cap), dtype=torch.uint8, device=dev)
+        self.raw = None
+
+    def run(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        B, H, W, n = self.B, self.H, self.W, 2 * self.B
+        lib = _lib.load()
+        st = _lib.current_stream()
+        self.images[:B].copy_(optical, non_blocking=True)
+        self.images[B:].copy_(thermal, non_blocking=True)
+        raw = self.net.forward_raw(self.images, want_prob=True, want_desc=True)
+        self.raw = raw
+        prob = raw["prob"]
+        if mask_optical is not None:
+            mask = torch.cat([mask_optical.reshape(B, H, W), mask_thermal.reshape(B, H, W)], 0).to(torch.uint8).contiguous()
+            _lib.check(lib.xp_mul_mask(ptr(prob), ptr(mask), ptr(self.prob_masked), n * H * W, st), "xp_mul_mask")
+            prob = self.prob_masked
+        thr = float(self.pred['detection_threshold'])
+        if self.pred['nms'] > 0:
+            _lib.check(lib.xp_box_nms(ptr(prob), ptr(self.prob_nms), ptr(self.nms_ws), self.nms_ws.numel(), n, H, W,
+                                      float(self.pred['nms']), thr, 0.1, int(self.pred['topk']), self.cap, self.sweeps, None, st),
+                       "xp_box_nms")
+            prob = self.prob_nms
+        _lib.check(lib.xp_extract_keypoints(ptr(prob), None, thr, ptr(self.kp), ptr(self.counts), n, H, W, self.cap, st),
+                   "xp_extract_keypoints")
+        d = raw["desc_nhwc"]
+        _lib.check(lib.xp_sample_descriptors(ptr(self.kp), ptr(self.counts), ptr(d), ptr(self.desc), n, self.cap, d.shape[1],
+                                             d.shape[2], self.D, H, W, st), "xp_sample_descriptors")
+        m = self.m
+        _lib.check(lib.xp_match_mnn(ptr(self.desc[:B]), ptr(self.desc[B:]), ptr(self.counts), 1, 0, B, B, self.cap, self.cap, self.D,
+                                    utils.MATCH_MODES[self.mode], ptr(m["idx12"]), ptr(m["dist12"]), ptr(m["idx21"]), ptr(m["dist21"]),
+                                    ptr(m["match_q"]), ptr(m["match_t"]), ptr(m["match_d"]), ptr(m["match_count"]),
+                                    ptr(self.match_ws), self.match_ws.numel(), st), "xp_match_mnn")
+        return self
+
+    def verify(self):
+        """After a synchronisation point: the async NMS must have reached its fixed point and no list may have
+        overflowed its capacity.  Raises otherwise (the caller can re-run with more sweeps / capacity)."""
+        lib = _lib.load()
+        if self.pred['nms'] > 0:
+            left = c_i(-1)
+            _lib.check(lib.xp_box_nms_check(ptr(self.nms_ws), 2 * self.B, self.H, self.W, ctypes.byref(left), _lib.current_stream()),
+                       "xp_box_nms_check")
+            if left.value != 0:
+                raise RuntimeError(f"PairPipeline: NMS not converged after {self.sweeps} sweeps ({left.value} tiles undecided)")
+        mx = int(self.counts.max().item())
+        if mx > self.cap:
+            raise RuntimeError(f"PairPipeline: {mx} keypoints exceed capacity {self.cap}")
+
+    def fetch(self):
+        torch.cuda.synchronize()
+        self.verify()
+        B = self.B
+        counts = self.counts.cpu().numpy()
+        mc = self.m["match_count"].cpu().numpy()
+        out = []
+        for i in range(B):
+            no, nt, nm = int(counts[i]), int(counts[B + i]), int(mc[i])
+            out.append(dict(kp_optical=self.kp[i, :no].cpu().long(), kp_thermal=self.kp[B + i, :nt].cpu().long(),
+                            desc_optical=self.desc[i, :no].cpu(), desc_thermal=self.desc[B + i, :nt].cpu(),
+                            match_q=self.m["match_q"][i, :nm].cpu().numpy(), match_t=self.m["match_t"][i, :nm].cpu().numpy(),
+                            match_d=self.m["match_d"][i, :nm].cpu().numpy(),
+                            idx12=self.m["idx12"][i, :no].cpu().numpy(), idx21=self.m["idx21"][i, :nt].cpu().numpy()))
+        return out

@@ -227,7 +227,7 @@ def make_state_dict(cfg: dict, tag: str = "xpoint-synth-v1", detector_gain: floa
 
 def make_torch_state_dict(cfg: dict, **kw):
     import torch
-    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in make_state_dict(cfg, **kw).items())
+    return OrderedDict((k, torch.from_numpy(np.array(v, copy=True))) for k, v in make_state_dict(cfg, **kw).items())
 
 
 # ------------------------------------------------------------------------------------------

@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's `xpoint.utils` functions on the hot path, over the HIP C ABI:
+`box_nms`, `interpolate_descriptors` (reference xpoint/utils/utils.py:148-192, 229-238),
+`get_matches` (xpoint/utils/matching.py:4-36) plus the small dict helpers the callers use
+(utils.py:73-113, 240-246).  Same names, argument meaning and error behaviour."""
+from __future__ import annotations
+
+import collections
+import collections.abc
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_f, c_i, ptr
+
+
+# ---------------------------------------------------------------- dict / data helpers (utils.py:73-113,240-246)
+def dict_update(d, u):
+    for k, v in u.items():
+        if isinstance(v, collections.abc.Mapping):
+            d[k] = dict_update(d.get(k, {}), v)
+        else:
+            d[k] = v
+    return d
+
+
+def data_to_device(data, device):
+    for key in data.keys():
+        if type(data[key]) is torch.Tensor:
+            data[key] = data[key].to(device)
+        elif type(data[key]) is dict:
+            data[key] = data_to_device(data[key], device)
+    return data
+
+
+def data_unsqueeze(data, dim):
+    for key in data.keys():
+        if type(data[key]) is torch.Tensor:
+            data[key] = data[key].unsqueeze(dim)
+        elif type(data[key]) is dict:
+            data[key] = data_unsqueeze(data[key], dim)
+    return data
+
+
+def fix_model_weigth_keys(weights):
+    new_weights = collections.OrderedDict()
+    for key, value in weights.items():
+        new_weights[key.split('__')[-1]] = value
+    return new_weights
+
+
+# ---------------------------------------------------------------- box_nms (utils.py:148-192)
+def box_nms(prob, size, min_prob, iou=0.1, keep_top_k=0, on_cpu=False):
+    """prob (H,W) or (B,1,H,W) on the GPU -> same shape: surviving scores, zeros elsewhere.
+    `on_cpu` (the reference moves the tensors to the CPU for torchvision's CPU NMS) is accepted and ignored:
+    the result is defined by the algorithm, not by where it runs."""
+    if not (len(prob.shape) == 2 or len(prob.shape) == 4):
+        raise ValueError('The probability must be either 2D (H,W), or 4D (B, 1, H, W)')
+    if not prob.is_cuda:
+        raise RuntimeError("xpoint_amd.utils.box_nms runs on the GPU only (no CPU fallback)")
+    if len(prob.shape) == 4 and prob.shape[1] != 1:
+        raise ValueError('The probability must be either 2D (H,W), or 4D (B, 1, H, W)')
+    p = prob.contiguous().float()
+    H, W = p.shape[-2:]
+    B = p.numel() // (H * W) if H * W else 0
+    out = torch.zeros_like(p)
+    if p.numel() == 0:
+        return out
+    cap = H * W if keep_top_k > 0 else 1
+    lib = _lib.load()
+    ws = torch.empty(lib.xp_box_nms_workspace_bytes(B, H, W, cap), dtype=torch.uint8, device=p.device)
+    conv = c_i(0)
+    _lib.check(lib.xp_box_nms(ptr(p), ptr(out), ptr(ws), ws.numel(), B, H, W, float(size), float(min_prob), float(iou),
+                              int(keep_top_k), cap, 0, ctypes.byref(conv), _lib.current_stream()), "xp_box_nms")
+    return out
+
+
+def extract_keypoints(prob, thr, mask=None, cap=None):
+    """torch.nonzero((prob > thr)[* mask]) for every image of prob (B,H,W) / (B,1,H,W) / (H,W):
+    returns (kp (B,cap,2) int32 (y,x) row-major, counts (B) int32) on the GPU."""
+    p = prob.contiguous().float()
+    H, W = p.shape[-2:]
+    B = p.numel() // (H * W)
+    cap = int(cap or H * W)
+    kp = torch.zeros((B, cap, 2), dtype=torch.int32, device=p.device)
+    counts = torch.zeros((B,), dtype=torch.int32, device=p.device)
+    m = None
+    if mask is not None:
+        m = mask.contiguous().to(torch.uint8)
+    _lib.call("xp_extract_keypoints", ptr(p), ptr(m), float(thr), ptr(kp), ptr(counts), B, H, W, cap, _lib.current_stream())
+    return kp, counts
+
+
+# ---------------------------------------------------------------- interpolate_descriptors (utils.py:229-238)
+def interpolate_descriptors(keypoints, descriptors_lowres, H, W):
+    """keypoints (N,2) (y,x) integer tensor; descriptors_lowres (C,Hc,Wc) as the reference passes it
+    (or (Hc,Wc,C) NHWC with `descriptors_lowres.nhwc = True` via interpolate_descriptors_nhwc) -> (N,C)."""
+    d = descriptors_lowres
+    if d.dim() != 3:
+        raise RuntimeError("descriptors_lowres must be (C,Hc,Wc)")
+    return interpolate_descriptors_nhwc(keypoints, d.permute(1, 2, 0).contiguous(), H, W)
+
+
+def interpolate_descriptors_nhwc(keypoints, desc_nhwc, H, W):
+    if not desc_nhwc.is_cuda:
+        raise RuntimeError("xpoint_amd.utils.interpolate_descriptors runs on the GPU only (no CPU fallback)")
+    Hc, Wc, D = desc_nhwc.shape
+    n = int(keypoints.shape[0])
+    out = torch.empty((max(n, 1), D), device=desc_nhwc.device)
+    if n == 0:
+        return out[:0]
+    kp = keypoints.to(device=desc_nhwc.device, dtype=torch.int32).contiguous().view(1, n, 2)
+    counts = torch.tensor([n], dtype=torch.int32, device=desc_nhwc.device)
+    dvol = desc_nhwc.contiguous().float()      # hold a reference: ptr() of a temporary could be reused before the launch
+    _lib.call("xp_sample_descriptors", ptr(kp), ptr(counts), ptr(dvol), ptr(out), 1, n, Hc, Wc, D,
+              int(H), int(W), _lib.current_stream())
+    return out
+
+
+# ---------------------------------------------------------------- get_matches (matching.py:4-36)
+class DMatch:
+    """cv2.DMatch stand-in: the fields the reference's callers read
+    (predict_align_image_pair.py:283-284, benchmark_evaluation.py:666-675)."""
+    __slots__ = ("queryIdx", "trainIdx", "distance", "imgIdx")
+
+    def __init__(self, queryIdx=-1, trainIdx=-1, distance=0.0):
+        self.queryIdx, self.trainIdx, self.distance, self.imgIdx = int(queryIdx), int(trainIdx), float(distance), 0
+
+    def __repr__(self):
+        return f"DMatch({self.queryIdx}, {self.trainIdx}, {self.distance:.6f})"
+
+
+MATCH_MODES = {"strict_mnn": 0, "legacy_crosscheck": 1}
+
+
+def match_descriptors(d1, d2, counts=None, mode="strict_mnn"):
+    """Batched device-side matching.  d1 (P,cap1,D), d2 (P,cap2,D) GPU float32; counts: optional int32 (2P,)
+    = [n1 of every pair..., n2 of every pair...].  Returns a dict of device tensors."""
+    P, cap1, D = d1.shape
+    cap2 = d2.shape[1]
+    dev = d1.device
+    lib = _lib.load()
+    res = dict(idx12=torch.empty((P, cap1), dtype=torch.int32, device=dev), dist12=torch.empty((P, cap1), device=dev),
+               idx21=torch.empty((P, cap2), dtype=torch.int32, device=dev), dist21=torch.empty((P, cap2), device=dev),
+               match_q=torch.empty((P, cap1), dtype=torch.int32, device=dev), match_t=torch.empty((P, cap1), dtype=torch.int32, device=dev),
+               match_d=torch.empty((P, cap1), device=dev), match_count=torch.zeros((P,), dtype=torch.int32, device=dev))
+    ws = torch.empty(lib.xp_match_workspace_bytes(P, cap1, cap2), dtype=torch.uint8, device=dev)
+    d1, d2 = d1.contiguous(), d2.contiguous()
+    _lib.check(lib.xp_match_mnn(ptr(d1), ptr(d2), ptr(counts), 1, 0, P, P, cap1, cap2, D, MATCH_MODES[mode],
+                                ptr(res["idx12"]), ptr(res["dist12"]), ptr(res["idx21"]), ptr(res["dist21"]), ptr(res["match_q"]),
+                                ptr(res["match_t"]), ptr(res["match_d"]), ptr(res["match_count"]), ptr(ws), ws.numel(),
+                                _lib.current_stream()), "xp_match_mnn")
+    res["_ws"] = ws
+    return res
+
+
+def get_matches(desc_1, desc_2, method='bfmatcher', knn_matches=False, mode="strict_mnn", **kwargs):
+    """desc_1 (N1,D), desc_2 (N2,D): numpy arrays (as the reference passes them) or torch tensors.
+    method 'bfmatcher' with crossCheck=True (configs/cipdp.yaml:57-61) -> list of DMatch in ascending queryIdx;
+    `mode` picks the cross-check semantics: 'strict_mnn' (default) or 'legacy_crosscheck'.
+    'nnmatcher' = strict mutual NN with the reference's distance threshold (matching.py:38-75)."""
+    if method not in ('bfmatcher', 'nnmatcher'):
+        if method in ('flann', 'thresholdmatcher'):
+            raise NotImplementedError(f"matching method '{method}' is out of scope (not selected by configs/cipdp.yaml)")
+        raise ValueError('unknown matching method')
+    if knn_matches:
+        raise NotImplementedError("knn_matches (Lowe ratio) is out of scope (configs/cipdp.yaml: knn_matches False)")
+    if desc_1.shape[0] == 0 or desc_2.shape[0] == 0:
+        return []
+    dev = torch.device("cuda")
+    t1 = torch.as_tensor(np.ascontiguousarray(desc_1) if isinstance(desc_1, np.ndarray) else desc_1).to(dev).float()
+    t2 = torch.as_tensor(np.ascontiguousarray(desc_2) if isinstance(desc_2, np.ndarray) else desc_2).to(dev).float()
+    res = match_descriptors(t1.unsqueeze(0), t2.unsqueeze(0), None, mode)
+    if method == 'bfmatcher' and not kwargs.get('crossCheck', False):
+        # BFMatcher default (crossCheck False): the nearest train descriptor of every query
+        t = res["idx12"][0].cpu().numpy(); d = res["dist12"][0].cpu().numpy(); q = np.arange(len(t))
+    else:
+        n = int(res["match_count"][0].item())
+        q = res["match_q"][0, :n].cpu().numpy(); t = res["match_t"][0, :n].cpu().numpy(); d = res["match_d"][0, :n].cpu().numpy()
+    if method == 'nnmatcher':
+        keep = d < float(kwargs.get('threshold', 0.7))
+        q, t, d = q[keep], t[keep], d[keep]
+    return [DMatch(a, b, c) for a, b, c in zip(q, t, d)]
