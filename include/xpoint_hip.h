@@ -147,6 +147,17 @@ int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_st
                  int* match_q, int* match_t, float* match_d, int* match_count, void* workspace, size_t workspace_bytes,
                  void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; replaces the
+ * reference's wall-clock brackets, benchmark_evaluation.py:12-37).  Off by default.  xp_prof_filter(tag)
+ * restricts recording to one kernel tag (NULL/"" = all).  xp_prof_count / xp_prof_get synchronise on the
+ * recorded events and return, per tag: total ms, launches, algorithmic FLOPs and bytes of those launches. */
+int xp_prof_enable(int on);
+int xp_prof_filter(const char* tag);
+int xp_prof_reset(void);
+int xp_prof_count(void);
+int xp_prof_get(int index, char* tag, int tag_len, double* total_ms, int* launches, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ from xpoint_amd import _lib, synth
 
 
 def test_library_exports_every_declared_symbol():
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib = _lib.load()
     declared = _lib.exported_symbols()
     assert len(declared) >= 30
     missing = [s for s in declared if not hasattr(lib, s)]

@@ -48,6 +48,12 @@ _SIGNATURES = {
     "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "xp_sample_descriptors": [c_p] * 4 + [c_i] * 7 + [c_p],
     "xp_match_mnn": [c_p, c_p, c_p] + [c_i] * 8 + [c_p] * 9 + [c_sz, c_p],
+    "xp_prof_enable": [c_i],
+    "xp_prof_filter": [ctypes.c_char_p],
+    "xp_prof_reset": [],
+    "xp_prof_count": [],
+    "xp_prof_get": [c_i, ctypes.c_char_p, c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i),
+                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
 # size queries: (restype size_t / int, argtypes)
 _SIZE_QUERIES = {
@@ -76,6 +82,10 @@ def load():
         raise XPointHipError(
             f"{LIB_PATH} not found: build it with `python -m xpoint_amd.build` (hipcc, gfx950). "
             "xpoint_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64: it must be the HIP runtime of this process, so import torch BEFORE
+    # the dynamic loader resolves our library's libamdhip64.so dependency (otherwise two runtimes coexist and
+    # every launch fails with "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     lib.xp_last_error.restype = ctypes.c_char_p
     lib.xp_last_error.argtypes = []

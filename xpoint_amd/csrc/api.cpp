@@ -27,3 +27,71 @@ extern "C" int xp_device_info(int device, int* cu_count, int* wave_size, char* a
     }
     return XP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// In-library kernel timing with HIP events, recorded on the stream each kernel is launched on
+// (bench.py's roofline leg).  Off by default: when disabled a scope costs one branch.
+// ------------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+struct ProfRec { std::string tag; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfAcc { double ms = 0, flops = 0, bytes = 0; int count = 0; };
+std::mutex g_pm;
+bool g_prof_on = false;
+std::string g_prof_filter;
+std::vector<ProfRec> g_pending;
+std::vector<hipEvent_t> g_free_events;
+std::map<std::string, ProfAcc> g_acc;
+
+hipEvent_t get_event() {
+    if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void collect_locked() {
+    for (auto& r : g_pending) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            ProfAcc& a = g_acc[r.tag];
+            a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.count += 1;
+        }
+        g_free_events.push_back(r.e0); g_free_events.push_back(r.e1);
+    }
+    g_pending.clear();
+}
+}  // namespace
+
+XpProfScope::XpProfScope(const char* tag, hipStream_t s, double flops, double bytes) : active_(false), stream_(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_pm);
+    if (!g_prof_filter.empty() && g_prof_filter != tag) return;
+    active_ = true;
+    ProfRec r{tag, flops, bytes, get_event(), get_event()};
+    (void)hipEventRecord(r.e0, s);
+    g_pending.push_back(r);
+    index_ = g_pending.size() - 1;
+}
+XpProfScope::~XpProfScope() {
+    if (!active_) return;
+    std::lock_guard<std::mutex> lk(g_pm);
+    if (index_ < g_pending.size()) (void)hipEventRecord(g_pending[index_].e1, stream_);
+}
+
+extern "C" int xp_prof_enable(int on) { std::lock_guard<std::mutex> lk(g_pm); g_prof_on = on != 0; return XP_OK; }
+extern "C" int xp_prof_filter(const char* tag) { std::lock_guard<std::mutex> lk(g_pm); g_prof_filter = tag ? tag : ""; return XP_OK; }
+extern "C" int xp_prof_reset(void) { std::lock_guard<std::mutex> lk(g_pm); collect_locked(); g_acc.clear(); return XP_OK; }
+extern "C" int xp_prof_count(void) { std::lock_guard<std::mutex> lk(g_pm); collect_locked(); return (int)g_acc.size(); }
+extern "C" int xp_prof_get(int index, char* tag, int tag_len, double* total_ms, int* launches, double* flops, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_pm);
+    collect_locked();
+    if (index < 0 || index >= (int)g_acc.size()) { xp_set_error("xp_prof_get: index out of range"); return XP_ERR_ARG; }
+    auto it = g_acc.begin(); std::advance(it, index);
+    if (tag && tag_len > 0) { strncpy(tag, it->first.c_str(), tag_len - 1); tag[tag_len - 1] = 0; }
+    if (total_ms) *total_ms = it->second.ms; if (launches) *launches = it->second.count;
+    if (flops) *flops = it->second.flops; if (bytes) *bytes = it->second.bytes;
+    return XP_OK;
+}

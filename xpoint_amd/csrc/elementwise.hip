@@ -257,6 +257,7 @@ extern "C" int xp_layernorm(const float* x, float* y, const float* w, const floa
     XP_CHECK_ARG(x && y && w && b, "xp_layernorm: null pointer");
     XP_CHECK_ARG(C > 0 && C <= 1024, "xp_layernorm: C must be in [1,1024] (got %d)", C);
     if (rows == 0) return XP_OK;
+    XpProfScope prof("layernorm", (hipStream_t)stream, 8.0 * rows * C, 8.0 * rows * C);
     hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b, rows, C, eps, gelu);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -266,6 +267,7 @@ extern "C" int xp_dwconv3x3_silu(const float* x, const float* w9c, float* y, int
     XP_CHECK_ARG(x && w9c && y, "xp_dwconv3x3_silu: null pointer");
     XP_CHECK_ARG(C % 4 == 0, "xp_dwconv3x3_silu: C %% 4 != 0");
     const int64_t total = (int64_t)batch * H * W * (C / 4);
+    XpProfScope prof("dwconv3x3_silu", (hipStream_t)stream, 22.0 * total * 4, 8.0 * total * 4);
     hipLaunchKernelGGL(dwconv3x3_silu_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w9c, y, batch, H, W, C);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -278,6 +280,7 @@ extern "C" int xp_stem_conv_ln_gelu(const float* img, const float* w9co, const f
     const int64_t total = (int64_t)batch * Ho * Wo;
     dim3 grid(xp_cdiv(total, 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
+    XpProfScope prof("stem_conv_ln_gelu", (hipStream_t)stream, (double)total * Co * 30.0, 4.0 * ((double)batch * H * W + (double)total * Co));
     if (Co == 48) hipLaunchKernelGGL(stem_conv_ln_gelu_kernel<48>, grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
     else if (Co == 16) hipLaunchKernelGGL(stem_conv_ln_gelu_kernel<16>, grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
     else { xp_set_error("xp_stem_conv_ln_gelu: Co must be 48 or 16 (EMBED_DIM 96 / 32), got %d", Co); return XP_ERR_ARG; }
@@ -288,6 +291,7 @@ extern "C" int xp_stem_conv_ln_gelu(const float* img, const float* w9co, const f
 extern "C" int xp_depth_to_space_nhwc(const float* x, float* y, int batch, int H, int W, int C, int bs, void* stream) {
     XP_CHECK_ARG(x && y && C % (bs * bs) == 0, "xp_depth_to_space_nhwc: bad args");
     const int64_t total = (int64_t)batch * H * W * C;
+    XpProfScope prof("depth_to_space", (hipStream_t)stream, 0.0, 8.0 * total);
     hipLaunchKernelGGL(depth_to_space_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C, bs);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -297,6 +301,7 @@ extern "C" int xp_softmax_shuffle(const float* logits, float* prob, int batch, i
     XP_CHECK_ARG(logits && prob, "xp_softmax_shuffle: null pointer");
     XP_CHECK_ARG(r * r + 1 <= 128 && ld >= r * r + 1, "xp_softmax_shuffle: r*r+1 must be <= 128 and <= ld");
     const int64_t cells = (int64_t)batch * Hc * Wc;
+    XpProfScope prof("softmax_shuffle", (hipStream_t)stream, (double)cells * 4.0 * (r * r + 1), 4.0 * cells * (2.0 * r * r + 1));
     hipLaunchKernelGGL(softmax_shuffle_kernel, dim3(xp_cdiv(cells, 4)), dim3(256), 0, (hipStream_t)stream, logits, prob, batch, Hc, Wc, r, ld, mode);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -305,6 +310,7 @@ extern "C" int xp_softmax_shuffle(const float* logits, float* prob, int batch, i
 extern "C" int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
     XP_CHECK_ARG(x && y, "xp_l2norm_rows: null pointer");
     if (rows == 0) return XP_OK;
+    XpProfScope prof("l2norm_rows", (hipStream_t)stream, 3.0 * rows * C, 8.0 * rows * C);
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, C, eps);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -313,6 +319,7 @@ extern "C" int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, flo
 extern "C" int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int C, void* stream) {
     XP_CHECK_ARG(x && y, "xp_nhwc_to_nchw: null pointer");
     dim3 grid(xp_cdiv(HW, 32), xp_cdiv(C, 32), batch);
+    XpProfScope prof("nhwc_to_nchw", (hipStream_t)stream, 0.0, 8.0 * batch * HW * C);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -321,6 +328,7 @@ extern "C" int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int 
 extern "C" int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_t n, void* stream) {
     XP_CHECK_ARG(x && mask && y, "xp_mul_mask: null pointer");
     if (n == 0) return XP_OK;
+    XpProfScope prof("mul_mask", (hipStream_t)stream, 1.0 * n, 9.0 * n);
     hipLaunchKernelGGL(mul_mask_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, y, n);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -329,6 +337,7 @@ extern "C" int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_
 extern "C" int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream) {
     XP_CHECK_ARG(x && y, "xp_maxpool2_nhwc: null pointer");
     const int64_t total = (int64_t)batch * (H / 2) * (W / 2) * C;
+    XpProfScope prof("maxpool2", (hipStream_t)stream, 3.0 * total, 20.0 * total);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C);
     XP_LAUNCH_CHECK();
     return XP_OK;

@@ -6,6 +6,8 @@
 //   epilogue(v) = (act(v + bias[n]) * scale[n] + shift[n]) + res[m, n]
 //
 // Tile engine: gemm_core.h.  MFMA-bound for the deep stages, HBM-bound at stage 0 (K = N = 96).
+#include <string>
+
 #include "gemm_core.h"
 
 namespace {
@@ -113,6 +115,10 @@ void launch(const GemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(xp_cdiv(p.N, T::BN), xp_cdiv(p.M, T::BM));
+    static const std::string tag = "gemm_f32_mfma_" + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
+    XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K,
+                     4.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
     hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), T::kLdsBytes, s, p);
 }
 

@@ -272,6 +272,7 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     p.ccnt = (int*)w; w += 4 * b;
     p.rcand = (int*)w; w += 4 * CAND_CAP * a;
     p.ccand = (int*)w;
+    XpProfScope prof("match_mnn", s, 0.0, 0.0);   // work depends on device-side counts: bench.py prices it from the fetched counts
     hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, counts, cnt_stride, which1, cap1, D, p.na, p.rowkey, p.rcnt);
     hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, counts, cnt_stride, which2, cap2, D, p.nb, p.colkey, p.ccnt);
     using T = GemmTile<2, 2, 2, 2>;

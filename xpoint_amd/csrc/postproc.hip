@@ -279,6 +279,7 @@ static int box_nms_enqueue(const float* prob, float* out, void* workspace, int b
     const int64_t n = (int64_t)batch * H * W;
     uint8_t* state = (uint8_t*)workspace;
     int* counters = (int*)((char*)workspace + ((n + 255) / 256 * 256));
+    XpProfScope prof("box_nms", s, 0.0, 8.0 * n);   // 8*H*W bytes per image (read prob, write prob_nms)
     if (init) hipLaunchKernelGGL(nms_init_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, s, prob, state, n, min_prob, counters);
     dim3 grid(xp_cdiv(W, NMS_TILE), xp_cdiv(H, NMS_TILE), batch);
     for (int i = 0; i < sweeps; ++i) {
@@ -350,6 +351,7 @@ extern "C" int xp_extract_keypoints(const float* prob, const uint8_t* mask, floa
                                     int H, int W, int cap, void* stream) {
     XP_CHECK_ARG(prob && kp && counts, "xp_extract_keypoints: null pointer");
     XP_CHECK_ARG(batch > 0 && cap > 0, "xp_extract_keypoints: bad batch/cap");
+    XpProfScope prof("extract_keypoints", (hipStream_t)stream, 0.0, 4.0 * batch * H * W);
     hipLaunchKernelGGL(extract_keypoints_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, prob, mask, thr, kp, counts, H, W, cap);
     XP_LAUNCH_CHECK();
     return XP_OK;
@@ -360,6 +362,7 @@ extern "C" int xp_sample_descriptors(const int* kp, const int* counts, const flo
     XP_CHECK_ARG(kp && counts && desc_nhwc && out, "xp_sample_descriptors: null pointer");
     XP_CHECK_ARG(D > 0 && D <= 512, "xp_sample_descriptors: D must be in [1,512] (got %d)", D);
     dim3 grid(xp_cdiv(cap, 4), batch);
+    XpProfScope prof("sample_descriptors", (hipStream_t)stream, 0.0, 0.0);
     hipLaunchKernelGGL(sample_descriptors_kernel, grid, dim3(256), 0, (hipStream_t)stream, kp, counts, desc_nhwc, out, cap, Hc, Wc, D, H, W);
     XP_LAUNCH_CHECK();
     return XP_OK;

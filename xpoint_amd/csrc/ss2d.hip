@@ -243,11 +243,25 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const size_t sm1 = sizeof(int) * npx + sizeof(float) * npx * XW;
     const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * p.C;
     dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
-    hipLaunchKernelGGL(ss2d_pass1<R>, grid1, dim3(threads), sm1, s, p);
+    const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * XW;
+    const double el = 4.0 * MC;   // (pixel, channel, direction) scan elements of the whole core
+    {   // reads u + its half of xdbl for each of the two route pairs
+        XpProfScope prof("ss2d_pass1", s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
+        hipLaunchKernelGGL(ss2d_pass1<R>, grid1, dim3(threads), sm1, s, p);
+    }
     const int64_t n2 = (int64_t)p.Bn * 4 * p.C;
-    hipLaunchKernelGGL(ss2d_pass2, dim3(xp_cdiv(n2, 256)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL((ss2d_pass3<R, false>), grid3, dim3(threads), sm3, s, p);
-    hipLaunchKernelGGL((ss2d_pass3<R, true>), grid3, dim3(threads), sm3, s, p);
+    {
+        XpProfScope prof("ss2d_pass2", s, 0.0, 4.0 * 3.0 * (double)p.Bn * 4 * p.nc * p.C);
+        hipLaunchKernelGGL(ss2d_pass2, dim3(xp_cdiv(n2, 256)), dim3(256), 0, s, p);
+    }
+    {   // read u, xdbl half; write ya
+        XpProfScope prof("ss2d_pass3_row", s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
+        hipLaunchKernelGGL((ss2d_pass3<R, false>), grid3, dim3(threads), sm3, s, p);
+    }
+    {   // read u, ya, xdbl half; write out (after out_norm)
+        XpProfScope prof("ss2d_pass3_col_ln", s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (3.0 * MC + MX));
+        hipLaunchKernelGGL((ss2d_pass3<R, true>), grid3, dim3(threads), sm3, s, p);
+    }
     XP_LAUNCH_CHECK();
     return XP_OK;
 }

@@ -38,6 +38,18 @@ void xp_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+// Optional HIP-event timing of one launch (see api.cpp); a no-op unless xp_prof_enable(1).
+// flops / bytes are the ALGORITHMIC work of the launch (roofline numerators).
+class XpProfScope {
+public:
+    XpProfScope(const char* tag, hipStream_t s, double flops, double bytes);
+    ~XpProfScope();
+private:
+    bool active_;
+    hipStream_t stream_;
+    size_t index_ = 0;
+};
+
 static inline int xp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
