@@ -21,95 +21,121 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int NMS_TILE = 32;
 constexpr int NMS_MAXR = 15;
+constexpr int NMS_MAX_SWEEPS = 64;        // counters[] slots (one per sweep of a round)
 
-struct NmsTable { uint32_t ovl[NMS_MAXR + 1]; int reach; };
+struct NmsTable { unsigned long long win[NMS_MAXR + 1]; int reach; };   // win[|dy|]: bit (reach + dx) set iff overlap
 
 enum : int { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2 };
 
-__global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__ prob, uint8_t* __restrict__ state, int64_t n,
-                                                       float min_prob, int* __restrict__ counters) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { counters[0] = 1; counters[1] = 0; }   // [0] = undecided seen by the previous sweep, [1] = accumulator
-    if (i < n) state[i] = prob[i] > min_prob ? ST_UNDECIDED : ST_NONE;
-}
-
-__global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict__ prob, uint8_t* __restrict__ state, int H, int W,
-                                                        NmsTable tab, int* __restrict__ counters, int local_iters) {
-    if (counters[0] == 0) return;   // converged in an earlier launch (uniform early exit)
-    __shared__ float s_sc[(NMS_TILE + 2 * NMS_MAXR) * (NMS_TILE + 2 * NMS_MAXR)];
-    __shared__ int s_st[(NMS_TILE + 2 * NMS_MAXR) * (NMS_TILE + 2 * NMS_MAXR)];
-    __shared__ int s_flag[2];
+// One sweep over every active 32x32 tile.  Tile state lives in LDS as per-row 64-bit masks (undecided / kept)
+// plus the scores; the owned undecided candidates are compacted into a list so that lanes work on candidates,
+// not pixels.  A candidate's test is 2R+1 mask tests for a kept neighbour and a walk over the set bits of the
+// undecided neighbours (few) for the priority test.
+//   first != 0: states are derived from prob (> min_prob) instead of being read; every tile is active.
+//   sweep k > 0 exits at once when sweep k-1 left nothing undecided, and skips tiles with no undecided pixel.
+// Each active tile writes its owned part of `out` (kept ? score : 0) and of `state`.
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict__ prob, uint8_t* __restrict__ state,
+                                                        float* __restrict__ out, uint8_t* __restrict__ tile_active, int H, int W,
+                                                        NmsTable tab, float min_prob, int* __restrict__ counters, int sweep,
+                                                        int first, int local_iters) {
+    if (sweep > 0 && counters[sweep - 1] == 0) return;   // converged in an earlier sweep (uniform early exit)
+    const int tile_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (!first && !tile_active[tile_id]) return;
+    constexpr int TWMAX = NMS_TILE + 2 * NMS_MAXR;
+    __shared__ float s_sc[TWMAX * TWMAX];
+    __shared__ unsigned long long m_und[TWMAX], m_kept[TWMAX];
+    __shared__ unsigned short s_list[NMS_TILE * NMS_TILE];
+    __shared__ int s_n, s_changed;
     const int R = tab.reach;
     const int TW = NMS_TILE + 2 * R;
     const int b = blockIdx.z;
     const int y0 = blockIdx.y * NMS_TILE - R, x0 = blockIdx.x * NMS_TILE - R;
     const float* pb = prob + (int64_t)b * H * W;
     uint8_t* sb = state + (int64_t)b * H * W;
-    if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    float* ob = out + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < TW; i += 256) { m_und[i] = 0ull; m_kept[i] = 0ull; }
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    int any = 0;
     for (int i = threadIdx.x; i < TW * TW; i += 256) {
         const int ty = i / TW, tx = i - ty * TW;
         const int y = y0 + ty, x = x0 + tx;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const int st = in ? sb[(int64_t)y * W + x] : ST_NONE;
-        s_st[i] = st;
-        s_sc[i] = in ? pb[(int64_t)y * W + x] : 0.f;
-        const bool own = ty >= R && ty < R + NMS_TILE && tx >= R && tx < R + NMS_TILE;
-        any |= (own && st == ST_UNDECIDED);
+        const float sc = in ? pb[(int64_t)y * W + x] : 0.f;
+        int st = ST_NONE;
+        if (in) st = first ? (sc > min_prob ? ST_UNDECIDED : ST_NONE) : sb[(int64_t)y * W + x];
+        s_sc[i] = sc;
+        if (st == ST_UNDECIDED) {
+            atomicOr(&m_und[ty], 1ull << tx);
+            const bool own = ty >= R && ty < R + NMS_TILE && tx >= R && tx < R + NMS_TILE;
+            if (own) { const int pos = atomicAdd(&s_n, 1); s_list[pos] = (unsigned short)(ty * 64 + tx); }
+        } else if (st == ST_KEPT) {
+            atomicOr(&m_kept[ty], 1ull << tx);
+        }
     }
-    if (any) s_flag[0] = 1;
     __syncthreads();
-    if (!s_flag[0]) return;
-    for (int it = 0; it < local_iters; ++it) {
-        if (threadIdx.x == 0) s_flag[1] = 0;
-        __syncthreads();
-        for (int o = threadIdx.x; o < NMS_TILE * NMS_TILE; o += 256) {
-            const int ty = R + o / NMS_TILE, tx = R + o % NMS_TILE;
-            const int c = ty * TW + tx;
-            if (s_st[c] != ST_UNDECIDED) continue;
-            const float sc = s_sc[c];
-            bool suppressed = false, blocked = false;
-            for (int dy = -R; dy <= R && !suppressed; ++dy) {
-                const uint32_t row = tab.ovl[dy < 0 ? -dy : dy];
-                for (int dx = -R; dx <= R; ++dx) {
-                    if (!((row >> (dx < 0 ? -dx : dx)) & 1u) || (dy == 0 && dx == 0)) continue;
-                    const int q = c + dy * TW + dx;
-                    const int st = s_st[q];
-                    if (st == ST_KEPT) { suppressed = true; break; }
-                    if (st == ST_UNDECIDED) {
-                        const float sq = s_sc[q];
+    const int n = s_n;
+    if (n > 0) {
+        for (int it = 0; it < local_iters; ++it) {
+            if (threadIdx.x == 0) s_changed = 0;
+            __syncthreads();
+            for (int li = threadIdx.x; li < n; li += 256) {
+                const int ty = s_list[li] >> 6, tx = s_list[li] & 63;
+                const unsigned long long mybit = 1ull << tx;
+                if (!(m_und[ty] & mybit)) continue;
+                const float sc = s_sc[ty * TW + tx];
+                const int sh = tx - R;
+                // Concurrent lanes flip bits while we look.  A lane that keeps q sets q's KEPT bit BEFORE clearing its
+                // UNDECIDED bit, so reading UNDECIDED first and KEPT afterwards can never miss q in both.  Order:
+                // (1) cheap filter on KEPT, (2) priority walk over UNDECIDED, (3) KEPT again (the authoritative read).
+                const volatile unsigned long long* vk = m_kept;
+                const volatile unsigned long long* vu = m_und;
+                bool suppressed = false;
+                for (int dy = -R; dy <= R; ++dy)
+                    if (vk[ty + dy] & (tab.win[dy < 0 ? -dy : dy] << sh)) { suppressed = true; break; }
+                if (suppressed) { atomicAnd(&m_und[ty], ~mybit); s_changed = 1; continue; }
+                bool blocked = false;
+                for (int dy = -R; dy <= R && !blocked; ++dy) {
+                    unsigned long long u = vu[ty + dy] & (tab.win[dy < 0 ? -dy : dy] << sh);
+                    if (dy == 0) u &= ~mybit;
+                    while (u) {
+                        const int bx = __ffsll((long long)u) - 1;
+                        u &= u - 1;
+                        const float sq = s_sc[(ty + dy) * TW + bx];
                         // q has higher priority: larger score, or equal score and earlier row-major index
-                        if (sq > sc || (sq == sc && (dy < 0 || (dy == 0 && dx < 0)))) blocked = true;
+                        if (sq > sc || (sq == sc && (dy < 0 || (dy == 0 && bx < tx)))) { blocked = true; break; }
                     }
                 }
+                if (blocked) continue;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (int dy = -R; dy <= R; ++dy)
+                    if (vk[ty + dy] & (tab.win[dy < 0 ? -dy : dy] << sh)) { suppressed = true; break; }
+                if (suppressed) { atomicAnd(&m_und[ty], ~mybit); s_changed = 1; continue; }
+                atomicOr(&m_kept[ty], mybit);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                atomicAnd(&m_und[ty], ~mybit);
+                s_changed = 1;
             }
-            if (suppressed) { s_st[c] = ST_NONE; s_flag[1] = 1; }
-            else if (!blocked) { s_st[c] = ST_KEPT; s_flag[1] = 1; }
+            __syncthreads();
+            if (!s_changed) break;
+            __syncthreads();
         }
-        __syncthreads();
-        if (!s_flag[1]) break;
-        __syncthreads();
     }
     int left = 0;
     for (int o = threadIdx.x; o < NMS_TILE * NMS_TILE; o += 256) {
         const int ty = R + o / NMS_TILE, tx = R + o % NMS_TILE;
         const int y = y0 + ty, x = x0 + tx;
         if (y < H && x < W) {
-            const int st = s_st[ty * TW + tx];
-            sb[(int64_t)y * W + x] = (uint8_t)st;
-            left |= (st == ST_UNDECIDED);
+            const bool kept = (m_kept[ty] >> tx) & 1ull, und = (m_und[ty] >> tx) & 1ull;
+            sb[(int64_t)y * W + x] = (uint8_t)(kept ? ST_KEPT : (und ? ST_UNDECIDED : ST_NONE));
+            ob[(int64_t)y * W + x] = kept ? s_sc[ty * TW + tx] : 0.f;
+            left |= und;
         }
     }
-    if (left) atomicAdd(&counters[1], 1);
-}
-
-__global__ void nms_roll_counter_kernel(int* counters) { counters[0] = counters[1]; counters[1] = 0; }
-
-__global__ __launch_bounds__(256) void nms_write_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ state,
-                                                        float* __restrict__ out, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = state[i] == ST_KEPT ? prob[i] : 0.f;
+    left = __syncthreads_or(left);
+    if (threadIdx.x == 0) {
+        tile_active[tile_id] = left ? 1 : 0;
+        if (left) atomicAdd(&counters[sweep], 1);
+    }
 }
 
 // keep_top_k: rank of every survivor among the survivors of its image under (score desc, index asc);
@@ -245,6 +271,7 @@ bool make_nms_table(float size, float iou, NmsTable* t) {
     if (!(size > 0.f) || size > (float)(NMS_MAXR + 1) || (2.f * size) != floorf(2.f * size)) return false;
     const float half = size * 0.5f;
     const float area = ((0.f + half) - (0.f - half)) * ((0.f + half) - (0.f - half));
+    uint32_t ovl[NMS_MAXR + 1];
     int reach = 0;
     for (int dy = 0; dy <= NMS_MAXR; ++dy) {
         uint32_t bits = 0;
@@ -257,36 +284,51 @@ bool make_nms_table(float size, float iou, NmsTable* t) {
             const float ovr = inter / (area + area - inter);
             if (ovr > iou) { bits |= (1u << dx); if (dy > reach) reach = dy; if (dx > reach) reach = dx; }
         }
-        t->ovl[dy] = bits;
+        ovl[dy] = bits;
     }
     t->reach = reach;
+    for (int dy = 0; dy <= NMS_MAXR; ++dy) {
+        unsigned long long m = 0;
+        for (int dx = -reach; dx <= reach; ++dx)
+            if ((ovl[dy] >> (dx < 0 ? -dx : dx)) & 1u) m |= 1ull << (reach + dx);
+        t->win[dy] = m;
+    }
     return true;
 }
 
 }  // namespace
 
+namespace {
+struct NmsWs { uint8_t* state; uint8_t* tile_active; int* counters; int* kp; };
+NmsWs nms_ws(void* workspace, int batch, int H, int W) {
+    const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
+    const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TILE) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
+    NmsWs w;
+    w.state = (uint8_t*)workspace;
+    w.tile_active = w.state + n;
+    w.counters = (int*)(w.tile_active + nt);
+    w.kp = w.counters + NMS_MAX_SWEEPS;
+    return w;
+}
+}  // namespace
+
 extern "C" size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap) {
-    // state bytes + counters + (top-k) keypoint list, counts, ranks
-    size_t n = (size_t)batch * H * W;
-    n = (n + 255) / 256 * 256;
-    return n + 256 + sizeof(int) * ((size_t)batch * cap * 3 + batch + 64);
+    // state bytes + tile flags + counters + (top-k) keypoint list, counts, ranks
+    const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
+    const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TILE) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
+    return n + nt + sizeof(int) * (NMS_MAX_SWEEPS + (size_t)batch * cap * 3 + batch + 64);
 }
 
-// Enqueue-only form: runs `sweeps` sweep launches (each exits immediately once converged).  After the
-// stream is synchronised, workspace[ state_bytes .. ] holds counters; *converged is NOT written here.
+// Enqueue `sweeps` sweep launches (each exits at once when the previous one left nothing undecided).
 static int box_nms_enqueue(const float* prob, float* out, void* workspace, int batch, int H, int W, const NmsTable& tab,
-                           float min_prob, int sweeps, bool init, hipStream_t s) {
-    const int64_t n = (int64_t)batch * H * W;
-    uint8_t* state = (uint8_t*)workspace;
-    int* counters = (int*)((char*)workspace + ((n + 255) / 256 * 256));
-    XpProfScope prof("box_nms", s, 0.0, 8.0 * n);   // 8*H*W bytes per image (read prob, write prob_nms)
-    if (init) hipLaunchKernelGGL(nms_init_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, s, prob, state, n, min_prob, counters);
+                           float min_prob, int sweeps, bool first_round, hipStream_t s) {
+    const NmsWs w = nms_ws(workspace, batch, H, W);
+    XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
+    XP_HIP(hipMemsetAsync(w.counters, 0, sizeof(int) * NMS_MAX_SWEEPS, s));
     dim3 grid(xp_cdiv(W, NMS_TILE), xp_cdiv(H, NMS_TILE), batch);
-    for (int i = 0; i < sweeps; ++i) {
-        hipLaunchKernelGGL(nms_sweep_kernel, grid, dim3(256), 0, s, prob, state, H, W, tab, counters, 8);
-        hipLaunchKernelGGL(nms_roll_counter_kernel, dim3(1), dim3(1), 0, s, counters);
-    }
-    hipLaunchKernelGGL(nms_write_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, s, prob, state, out, n);
+    for (int i = 0; i < sweeps; ++i)
+        hipLaunchKernelGGL(nms_sweep_kernel, grid, dim3(256), 0, s, prob, w.state, out, w.tile_active, H, W, tab, min_prob, w.counters,
+                           i, (first_round && i == 0) ? 1 : 0, 8);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -303,20 +345,23 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
     NmsTable tab;
     XP_CHECK_ARG(make_nms_table(size, iou, &tab), "xp_box_nms: size must be a positive multiple of 0.5 and <= %d (got %f)", NMS_MAXR + 1, size);
     hipStream_t s = (hipStream_t)stream;
-    const int64_t n = (int64_t)batch * H * W;
-    int* counters = (int*)((char*)workspace + ((n + 255) / 256 * 256));
+    XP_CHECK_ARG(max_sweeps_async <= NMS_MAX_SWEEPS, "xp_box_nms: at most %d async sweeps", NMS_MAX_SWEEPS);
+    const NmsWs w = nms_ws(workspace, batch, H, W);
     if (max_sweeps_async > 0) {
-        // fire-and-forget: the caller checks counters later (xp_box_nms_check)
+        // fire-and-forget: the caller checks the last counter later (xp_box_nms_check)
         int rc = box_nms_enqueue(prob, out, workspace, batch, H, W, tab, min_prob, max_sweeps_async, true, s);
         if (rc) return rc;
+        if (max_sweeps_async != NMS_MAX_SWEEPS)
+            XP_HIP(hipMemcpyAsync(w.counters + NMS_MAX_SWEEPS - 1, w.counters + max_sweeps_async - 1, sizeof(int), hipMemcpyDeviceToDevice, s));
     } else {
-        bool init = true;
-        for (int round = 0; round < 4096; ++round) {
-            int rc = box_nms_enqueue(prob, out, workspace, batch, H, W, tab, min_prob, 4, init, s);
+        bool first = true;
+        const int per_round = 4;
+        for (int round = 0; round < 100000; ++round) {
+            int rc = box_nms_enqueue(prob, out, workspace, batch, H, W, tab, min_prob, per_round, first, s);
             if (rc) return rc;
-            init = false;
+            first = false;
             int left = 0;
-            XP_HIP(hipMemcpyAsync(&left, counters, sizeof(int), hipMemcpyDeviceToHost, s));
+            XP_HIP(hipMemcpyAsync(&left, w.counters + per_round - 1, sizeof(int), hipMemcpyDeviceToHost, s));
             XP_HIP(hipStreamSynchronize(s));
             if (left == 0) break;
         }
@@ -324,7 +369,7 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
     }
     if (keep_top_k > 0) {
         XP_CHECK_ARG(cap > 0, "xp_box_nms: keep_top_k needs cap > 0");
-        int* kp = counters + 64;
+        int* kp = w.kp;
         int* counts = kp + (size_t)batch * cap * 2;
         int* rank = counts + batch;
         int rc = xp_extract_keypoints(out, nullptr, 0.f, kp, counts, batch, H, W, cap, stream);
@@ -340,9 +385,8 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
 // After the stream has been synchronised: did the async NMS converge?  (device->host copy of one int)
 extern "C" int xp_box_nms_check(const void* workspace, int batch, int H, int W, int* undecided_tiles, void* stream) {
     XP_CHECK_ARG(workspace && undecided_tiles, "xp_box_nms_check: null pointer");
-    const int64_t n = (int64_t)batch * H * W;
-    const int* counters = (const int*)((const char*)workspace + ((n + 255) / 256 * 256));
-    XP_HIP(hipMemcpyAsync(undecided_tiles, counters, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    const NmsWs w = nms_ws(const_cast<void*>(workspace), batch, H, W);
+    XP_HIP(hipMemcpyAsync(undecided_tiles, w.counters + NMS_MAX_SWEEPS - 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     XP_HIP(hipStreamSynchronize((hipStream_t)stream));
     return XP_OK;
 }
