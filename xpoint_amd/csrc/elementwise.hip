@@ -1,6 +1,10 @@
 // HBM-bound glue kernels of the encoder and heads, NHWC layout (channels contiguous):
 // LayerNorm, depthwise 3x3 + SiLU, the 1-channel stem convolution (+LN+GELU), depth-to-space,
 // detector softmax + pixel shuffle, descriptor L2 normalisation, NHWC->NCHW export.
+#include <stdlib.h>
+
+#include <string>
+
 #include "xp_common.h"
 
 namespace {
@@ -257,7 +261,8 @@ extern "C" int xp_layernorm(const float* x, float* y, const float* w, const floa
     XP_CHECK_ARG(x && y && w && b, "xp_layernorm: null pointer");
     XP_CHECK_ARG(C > 0 && C <= 1024, "xp_layernorm: C must be in [1,1024] (got %d)", C);
     if (rows == 0) return XP_OK;
-    XpProfScope prof("layernorm", (hipStream_t)stream, 8.0 * rows * C, 8.0 * rows * C);
+    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
+    XpProfScope prof(by_shape ? ("layernorm_C" + std::to_string(C)).c_str() : "layernorm", (hipStream_t)stream, 8.0 * rows * C, 8.0 * rows * C);
     hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b, rows, C, eps, gelu);
     XP_LAUNCH_CHECK();
     return XP_OK;

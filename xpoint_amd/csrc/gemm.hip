@@ -6,6 +6,8 @@
 //   epilogue(v) = (act(v + bias[n]) * scale[n] + shift[n]) + res[m, n]
 //
 // Tile engine: gemm_core.h.  MFMA-bound for the deep stages, HBM-bound at stage 0 (K = N = 96).
+#include <stdlib.h>
+
 #include <string>
 
 #include "gemm_core.h"
@@ -115,7 +117,9 @@ void launch(const GemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(xp_cdiv(p.N, T::BN), xp_cdiv(p.M, T::BM));
-    static const std::string tag = "gemm_f32_mfma_" + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
+    std::string tag = "gemm_f32_mfma_" + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    if (by_shape) tag += (p.mode ? "_conv_M" : "_M") + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
     const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K,
                      4.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));

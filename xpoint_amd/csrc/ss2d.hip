@@ -16,6 +16,10 @@
 //           in the reference's order (y0 + y2) + (y1 + y3) (csm_triton.py:60-62) and applies out_norm
 //           (LayerNorm over C, VMamba.py:644) before the single store.
 // Directions are stored in the order (0, 2, 1, 3) so that a pair's operands are adjacent.
+#include <stdlib.h>
+
+#include <string>
+
 #include "xp_common.h"
 
 namespace {
@@ -50,8 +54,8 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
     float dt = w[0] * xr[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dt = fmaf(w[r], xr[r], dt);
-    const float delta = xp_softplus(dt + bias);
-    a = expf(delta * A);
+    const float delta = xp_softplus_fast(dt + bias);
+    a = xp_exp_fast(delta * A);
     b = delta * xr[R] * u;
 }
 
@@ -244,22 +248,24 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * p.C;
     dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
     const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * XW;
+    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
+    const std::string sfx = by_shape ? "_C" + std::to_string(p.C) : std::string();
     const double el = 4.0 * MC;   // (pixel, channel, direction) scan elements of the whole core
     {   // reads u + its half of xdbl for each of the two route pairs
-        XpProfScope prof("ss2d_pass1", s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
+        XpProfScope prof(("ss2d_pass1" + sfx).c_str(), s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
         hipLaunchKernelGGL(ss2d_pass1<R>, grid1, dim3(threads), sm1, s, p);
     }
     const int64_t n2 = (int64_t)p.Bn * 4 * p.C;
     {
-        XpProfScope prof("ss2d_pass2", s, 0.0, 4.0 * 3.0 * (double)p.Bn * 4 * p.nc * p.C);
+        XpProfScope prof(("ss2d_pass2" + sfx).c_str(), s, 0.0, 4.0 * 3.0 * (double)p.Bn * 4 * p.nc * p.C);
         hipLaunchKernelGGL(ss2d_pass2, dim3(xp_cdiv(n2, 256)), dim3(256), 0, s, p);
     }
     {   // read u, xdbl half; write ya
-        XpProfScope prof("ss2d_pass3_row", s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
+        XpProfScope prof(("ss2d_pass3_row" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
         hipLaunchKernelGGL((ss2d_pass3<R, false>), grid3, dim3(threads), sm3, s, p);
     }
     {   // read u, ya, xdbl half; write out (after out_norm)
-        XpProfScope prof("ss2d_pass3_col_ln", s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (3.0 * MC + MX));
+        XpProfScope prof(("ss2d_pass3_col_ln" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (3.0 * MC + MX));
         hipLaunchKernelGGL((ss2d_pass3<R, true>), grid3, dim3(threads), sm3, s, p);
     }
     XP_LAUNCH_CHECK();

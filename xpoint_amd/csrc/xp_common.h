@@ -56,6 +56,26 @@ static inline int xp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 // softplus with torch semantics (beta 1, threshold 20): reference csms6s.py:49-50 /
 // selective_scan_fwd_kernel_oflex.cuh:124-127.
 __device__ __forceinline__ float xp_softplus(float x) { return x <= 20.f ? log1pf(expf(x)) : x; }
+// exp(x) on the hardware exp2 unit with the product x*log2(e) carried in two floats, so the relative error stays
+// ~2 ulp for any |x| (a plain exp2f(x*log2e) loses |x| * 6e-8): p = 2^t, t = fl(x*L), r = x*L - t (exact via fma).
+__device__ __forceinline__ float xp_exp_fast(float x) {
+    const float L_hi = 1.44269502162933349609375f, L_lo = 1.925963033500011e-08f;   // log2(e) = hi + lo
+    const float t = x * L_hi;
+    float r = fmaf(x, L_hi, -t);
+    r = fmaf(x, L_lo, r);
+    const float p = __builtin_amdgcn_exp2f(t);
+    return fmaf(p, r * 0.693147180559945309f, p);
+}
+// log1p(e) for e >= 0: log(u) with u = fl(1 + e), minus the first-order correction for the rounding of 1 + e
+// (Kahan).  v_log_f32 is accurate to ~1 ulp of its result, so the relative error is ~2e-7 down to e -> 0
+// (u == 1 gives exactly e).
+__device__ __forceinline__ float xp_log1p_fast(float e) {
+    const float u = 1.f + e;
+    const float l = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
+    const float c = ((u - 1.f) - e) * __builtin_amdgcn_rcpf(u);
+    return l - c;
+}
+__device__ __forceinline__ float xp_softplus_fast(float x) { return x <= 20.f ? xp_log1p_fast(xp_exp_fast(x)) : x; }
 __device__ __forceinline__ float xp_silu(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float xp_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
