@@ -1,0 +1,30 @@
+"""Micro-benchmark of xp_gemm_nt on the model's shapes (B=16 images, 480x640)."""
+import sys, torch
+sys.path.insert(0, ".")
+from xpoint_amd import _lib as L
+shapes = [  # (M, N, K, act, res)
+    (307200, 96, 96, 0, 0), (307200, 96, 96, 0, 1), (307200, 384, 96, 1, 0), (307200, 384, 96, 0, 0), (307200, 96, 384, 0, 1),
+    (307200, 32, 96, 0, 0),
+    (76800, 192, 192, 0, 0), (76800, 768, 192, 1, 0), (76800, 768, 192, 0, 0), (76800, 192, 768, 0, 1),
+    (19200, 384, 384, 0, 0), (19200, 1536, 384, 1, 0), (19200, 384, 1536, 0, 1),
+    (4800, 768, 768, 0, 0), (4800, 3072, 768, 1, 0), (4800, 768, 3072, 0, 1),
+    (76800, 65, 256, 0, 0), (76800, 256, 256, 0, 0),
+]
+torch.manual_seed(0)
+for (M, N, K, act, res) in shapes:
+    A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
+    C = torch.empty(M, N, device="cuda"); R = torch.randn(M, N, device="cuda") if res else None
+    st = L.current_stream()
+    def run():
+        L.call("xp_gemm_nt", L.ptr(A), L.ptr(W), L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    fl = 2.0 * M * N * K
+    by = 4.0 * (M * K + N * K + M * N * (2 if res else 1))
+    print(f"M{M:7d} N{N:5d} K{K:5d} act{act} res{res}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s  {by/ms/1e6:7.0f} GB/s", flush=True)

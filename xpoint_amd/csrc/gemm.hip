@@ -84,25 +84,45 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     f32x16 acc[TM][TN];
     T::run(lds, p.K, ldA, ldB, acc);
 
+    // epilogue, in two phases so that every residual load is in flight before the first store (C may alias res:
+    // a load-add-store chain per element would serialise ~16 L2 round trips per tile)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + T::col_of(j);
+            const bool cok = col < p.N;
+            const float bi = (p.bias && cok) ? p.bias[col] : 0.f;
+            const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
+            const float sh = (p.shift && cok) ? p.shift[col] : 0.f;
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + T::row_of(i, r);
+                    rv[r] = (cok && row < p.M) ? p.res[(int64_t)row * p.ldres + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bi;
+                if (p.act == 1) v = xp_gelu_fast(v);
+                else if (p.act == 2) v = fmaxf(v, 0.f);
+                if (p.scale) v = v * sc + sh;
+                if (p.res) v = rv[r] + v;
+                acc[i][j][r] = v;
+            }
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + T::col_of(j);
             if (col >= p.N) continue;
-            const float bi = p.bias ? p.bias[col] : 0.f;
-            const float sc = p.scale ? p.scale[col] : 1.f;
-            const float sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + T::row_of(i, r);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bi;
-                if (p.act == 1) v = xp_gelu(v);
-                else if (p.act == 2) v = fmaxf(v, 0.f);
-                if (p.scale) v = v * sc + sh;
-                if (p.res) v = p.res[(int64_t)row * p.ldres + col] + v;
-                p.C[(int64_t)row * p.ldc + col] = v;
+                if (row < p.M) p.C[(int64_t)row * p.ldc + col] = acc[i][j][r];
             }
         }
 }

@@ -127,22 +127,49 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     p.wsP[o + p.C] = Q1; p.wsS[o + p.C] = S1;
 }
 
-// pass 2: thread per (b, pair, dir, c); sequential over chunks.
-__global__ void ss2d_pass2(SS2DParams p) {
-    const int64_t n = (int64_t)p.Bn * 2 * 2 * p.C;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int c = (int)(t % p.C);
-    const int dir = (int)((t / p.C) % 2);
-    const int bp = (int)(t / (2 * p.C));   // b*2 + pair
-    float h = 0.f;
-    for (int jj = 0; jj < p.nc; ++jj) {
+// pass 2: carry over chunks, per (image, pair, direction, channel).  Two-level so that the sequential depth is
+// ~2*nc/G + G instead of nc: G groups of consecutive chunks are composed in parallel, a short serial pass gives the
+// state entering each group, then every group re-walks its chunks storing the state entering each chunk (over S).
+constexpr int P2_G = 16;
+__global__ __launch_bounds__(64 * P2_G) void ss2d_pass2(SS2DParams p) {
+    __shared__ float s_P[P2_G][64], s_S[P2_G][64];
+    const int lane = threadIdx.x, g = threadIdx.y;
+    const int c = blockIdx.x * 64 + lane;
+    const int bp = blockIdx.y >> 1, dir = blockIdx.y & 1;    // bp = b*2 + pair
+    const bool ok = c < p.C;
+    const int per = (p.nc + P2_G - 1) / P2_G;
+    const int j0 = g * per, j1 = min(p.nc, j0 + per);
+    auto off = [&](int jj) -> int64_t {
         const int j = dir ? (p.nc - 1 - jj) : jj;
-        const int64_t o = (((int64_t)bp * p.nc + j) * 2 + dir) * p.C + c;
-        const float P = p.wsP[o], S = p.wsS[o];
-        p.wsS[o] = h;
-        h = fmaf(P, h, S);
+        return (((int64_t)bp * p.nc + j) * 2 + dir) * p.C + c;
+    };
+    float P = 1.f, S = 0.f;
+    if (ok) {
+        int jj = j0;
+        for (; jj + 4 <= j1; jj += 4) {
+            float Pv[4], Sv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int64_t o = off(jj + k); Pv[k] = p.wsP[o]; Sv[k] = p.wsS[o]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { S = fmaf(Pv[k], S, Sv[k]); P *= Pv[k]; }
+        }
+        for (; jj < j1; ++jj) { const int64_t o = off(jj); const float Pj = p.wsP[o], Sj = p.wsS[o]; S = fmaf(Pj, S, Sj); P *= Pj; }
     }
+    s_P[g][lane] = P; s_S[g][lane] = S;
+    __syncthreads();
+    float h = 0.f;
+    for (int gg = 0; gg < g; ++gg) h = fmaf(s_P[gg][lane], h, s_S[gg][lane]);
+    if (!ok) return;
+    int jj = j0;
+    for (; jj + 4 <= j1; jj += 4) {
+        float Pv[4], Sv[4];
+        int64_t ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ov[k] = off(jj + k); Pv[k] = p.wsP[ov[k]]; Sv[k] = p.wsS[ov[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { p.wsS[ov[k]] = h; h = fmaf(Pv[k], h, Sv[k]); }
+    }
+    for (; jj < j1; ++jj) { const int64_t o = off(jj); const float Pj = p.wsP[o], Sj = p.wsS[o]; p.wsS[o] = h; h = fmaf(Pj, h, Sj); }
 }
 
 template <int R, bool COLPAIR>
@@ -255,10 +282,9 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
         XpProfScope prof(("ss2d_pass1" + sfx).c_str(), s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
         hipLaunchKernelGGL(ss2d_pass1<R>, grid1, dim3(threads), sm1, s, p);
     }
-    const int64_t n2 = (int64_t)p.Bn * 4 * p.C;
     {
         XpProfScope prof(("ss2d_pass2" + sfx).c_str(), s, 0.0, 4.0 * 3.0 * (double)p.Bn * 4 * p.nc * p.C);
-        hipLaunchKernelGGL(ss2d_pass2, dim3(xp_cdiv(n2, 256)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(ss2d_pass2, dim3(xp_cdiv(p.C, 64), p.Bn * 4), dim3(64, P2_G), 0, s, p);
     }
     {   // read u, xdbl half; write ya
         XpProfScope prof(("ss2d_pass3_row" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
@@ -275,9 +301,9 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C) {
-    // P and S: (B, 2, nc, 2, C) each with the smallest chunk (T = 16) -> upper bound; + ya (B,H,W,C)
+    // P and S: (B, 2, nc, 2, C) each with the smallest chunk (T = 8) -> upper bound; + ya (B,H,W,C)
     const int64_t L = (int64_t)H * W;
-    const int64_t nc = (L + 15) / 16;
+    const int64_t nc = (L + 7) / 8;
     return (size_t)(2 * (int64_t)batch * 2 * nc * 2 * C + (int64_t)batch * L * C) * sizeof(float);
 }
 
@@ -299,8 +325,10 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
     if (C < 192) { cpb = 192 / C; while ((cpb * C) % 64) ++cpb; }
     XP_CHECK_ARG((cpb * C) % 64 == 0 && cpb * C <= 768, "xp_ss2d_core_fwd: unsupported C=%d", C);
     p.cpb = cpb;
-    int T = 12288 / (cpb * C);
-    T = T >= 64 ? 64 : (T >= 32 ? 32 : 16);
+    // chunk length: keeps the pass-3 LDS tile (cpb*T*C floats) near 12 KB so that many workgroups share a CU (measured best on MI355X)
+    static const int t_budget = getenv("XP_SS2D_TBUDGET") ? atoi(getenv("XP_SS2D_TBUDGET")) : 3072;
+    int T = t_budget / (cpb * C);
+    T = T >= 64 ? 64 : (T >= 32 ? 32 : (T >= 16 ? 16 : 8));
     p.T = T;
     const int L = H * W;
     p.nc = xp_cdiv(L, T);

@@ -78,6 +78,19 @@ __device__ __forceinline__ float xp_log1p_fast(float e) {
 __device__ __forceinline__ float xp_softplus_fast(float x) { return x <= 20.f ? xp_log1p_fast(xp_exp_fast(x)) : x; }
 __device__ __forceinline__ float xp_silu(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float xp_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU(erf) with erfc(|z|) = poly(t) * exp(-z^2), t = 1/(1 + p|z|)  (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7):
+// x >= 0: 0.5 x (2 - erfc), x < 0: 0.5 x erfc — no cancellation on the negative side.  ~20 VALU ops instead of
+// libm erff's ~60; absolute error of the result <= ~2e-7 * max(1, |x|).
+__device__ __forceinline__ float xp_gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_abs = p * t * xp_exp_fast(-z * z);
+    return 0.5f * x * (x >= 0.f ? 2.f - erfc_abs : erfc_abs);
+}
 
 __device__ __forceinline__ float xp_wave_sum(float v) {
 #pragma unroll
