@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs in the bounded CPU-baseline sample")
+    ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (images uploaded from pinned host memory every step); never the headline value")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -82,20 +83,14 @@ def main():
     from xpoint_amd.predict import PairPipeline
     from xpoint_amd import _lib
 
+    from xpoint_amd import dist as xdist
     cfg = synth.xpoint_exp1_config(H, W)
     net = models.XPoint(cfg).eval()
-    # shared "pretrained" weights: rank 0 packs, RCCL broadcast over xGMI to the other ranks
-    if rank == 0:
-        net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
-        blob = net.pack_weights().to(dev)
-    else:
-        blob = torch.empty(net.weights_numel(), dtype=torch.float32, device=dev)
-    if world > 1:
-        dist.broadcast(blob, 0)
-    net.set_weight_blob(blob)
+    # shared "pretrained" weights: rank 0 packs, ONE RCCL broadcast over xGMI to the other ranks (no other collective)
+    xdist.broadcast_weights(net, (lambda: synth.make_torch_state_dict(cfg)), src=0, device=dev)
 
     B = args.pairs
-    first = rank * B                                      # every rank gets its own pairs (shard of the global batch)
+    first, _ = xdist.shard_pairs(world * B, world, rank)   # every rank owns its own contiguous block of pairs
     data = synth.to_torch(synth.make_pair_batch(first, B, H, W), dev)
     opt, thr = data["optical"]["image"], data["thermal"]["image"]
     mo, mt = data["optical"]["valid_mask"], data["thermal"]["valid_mask"]
@@ -142,6 +137,20 @@ def main():
         lib.xp_prof_enable(0)
         dom = [r for r in prof_table() if r["tag"] == dominant][0]
         pipe.verify()
+    pcie = None
+    if args.h2d:
+        ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
+        do, dth = torch.empty_like(opt), torch.empty_like(thr)
+        with torch.no_grad():
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                do.copy_(ho, non_blocking=True); dth.copy_(ht, non_blocking=True)
+                pipe.run(do, dth, mo, mt)
+                kc = pipe.counts.cpu(); mc = pipe.m["match_count"].cpu()      # results leave the device (counts + match lists)
+                mq = pipe.m["match_q"].cpu(); mtt = pipe.m["match_t"].cpu(); kk = pipe.kp.cpu()
+            sync_all()
+            pcie = world * B * args.steps / (time.perf_counter() - t1)
     res = pipe.fetch()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -183,6 +192,8 @@ def main():
                        "matches_per_pair_mean": round(sum(len(r["match_q"]) for r in res) / len(res), 1)},
             "roofline": roof,
         }
+        if pcie is not None:
+            out["pcie_inclusive_pairs_per_s"] = round(pcie, 2)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
