@@ -127,8 +127,9 @@ int xp_box_nms_check(const void* workspace, int batch, int H, int W, int* undeci
 
 /* torch.nonzero((prob > thr) [* mask]) per image (predict_align_image_pair.py:242-243, predict_keypoints.py:213-215):
  * kp (batch, cap, 2) int32 (y, x) in row-major order, counts (batch) int32 (may exceed cap: truncated list). */
+size_t xp_extract_keypoints_workspace_bytes(int batch, int H, int W);
 int xp_extract_keypoints(const float* prob, const uint8_t* mask, float thr, int* kp, int* counts, int batch, int H,
-                         int W, int cap, void* stream);
+                         int W, int cap, void* workspace, size_t workspace_bytes, void* stream);
 
 /* xpoint.utils.interpolate_descriptors (utils.py:229-238): bilinear grid_sample (align_corners=True) of the
  * NHWC descriptor volume (batch,Hc,Wc,D) at the keypoints + L2 normalisation -> out (batch, cap, D). */

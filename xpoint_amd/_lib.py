@@ -45,7 +45,7 @@ _SIGNATURES = {
     "xp_xpoint_forward": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p],
     "xp_box_nms": [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
     "xp_box_nms_check": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
-    "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p],
     "xp_sample_descriptors": [c_p] * 4 + [c_i] * 7 + [c_p],
     "xp_match_mnn": [c_p, c_p, c_p] + [c_i] * 8 + [c_p] * 9 + [c_sz, c_p],
     "xp_prof_enable": [c_i],
@@ -63,6 +63,7 @@ _SIZE_QUERIES = {
     "xp_ss2d_core_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_match_workspace_bytes": (c_sz, [c_i] * 3),
+    "xp_extract_keypoints_workspace_bytes": (c_sz, [c_i] * 3),
 }
 
 

@@ -29,56 +29,73 @@ struct GemmParams {
     int Hi, Wi, Ci, Ho, Wo, stride, reflect;
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     using T = GemmTile<WM, WN, TM, TN>;
     extern __shared__ __align__(16) float lds[];
-    const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so block b runs
+    // on XCD b % 8.  Give every XCD a contiguous range of logical tiles with the N-tiles of one M-tile adjacent, so
+    // the A rows shared by those tiles are fetched once per XCD instead of once per tile (bijective remap;
+    // placement only affects speed, never results).
+    const int ntn = (p.N + T::BN - 1) / T::BN;
+    const int total = gridDim.x;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int m0 = (logical / ntn) * T::BM, n0 = (logical % ntn) * T::BN;
 
-    int64_t a_base[T::A_LD];
+    // Staging loads are branch-free: out-of-range rows / k are redirected to a valid address and zeroed by a select,
+    // so the 8 loads of a slab issue back to back (divergent "if (ok) load" regions made hipcc serialise them).
+    const float* a_ptr[T::A_LD];     // plain: row base; conv: image base
     int a_oh[T::A_LD], a_ow[T::A_LD];
     bool a_ok[T::A_LD];
 #pragma unroll
     for (int s = 0; s < T::A_LD; ++s) {
         const int m = m0 + T::slot_row(s);
         a_ok[s] = m < p.M;
-        if (p.mode == 0) {
-            a_base[s] = (int64_t)m * p.lda; a_oh[s] = a_ow[s] = 0;
+        const int mc = a_ok[s] ? m : 0;
+        if (MODE == 0) {
+            a_ptr[s] = p.A + (int64_t)mc * p.lda; a_oh[s] = a_ow[s] = 0;
         } else {
             const int hw = p.Ho * p.Wo;
-            const int b = m / hw, r = m - b * hw;
-            a_oh[s] = (r / p.Wo) * p.stride - 1; a_ow[s] = (r % p.Wo) * p.stride - 1;
-            a_base[s] = (int64_t)b * p.Hi * p.Wi * p.Ci;
+            const int b = mc / hw, rr = mc - b * hw;
+            a_oh[s] = (rr / p.Wo) * p.stride - 1; a_ow[s] = (rr % p.Wo) * p.stride - 1;
+            a_ptr[s] = p.A + (int64_t)b * p.Hi * p.Wi * p.Ci;
         }
     }
     const float* wrow[T::B_LD];
+    bool w_ok[T::B_LD];
 #pragma unroll
     for (int s = 0; s < T::B_LD; ++s) {
         const int n = n0 + T::slot_row(s);
-        wrow[s] = (n < p.N) ? p.Wt + (int64_t)n * p.K : nullptr;
+        w_ok[s] = n < p.N;
+        wrow[s] = p.Wt + (int64_t)(w_ok[s] ? n : 0) * p.K;
     }
-    auto ldA = [&](int s, int k) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_ok[s] && k < p.K) {
-            if (p.mode == 0) {
-                v = *reinterpret_cast<const float4*>(p.A + a_base[s] + k);
+    const int kmax = p.K - 4;
+    auto ldA = [&](int s, int k, bool& ok) -> float4 {
+        ok = a_ok[s] && k < p.K;
+        const int kc = k < p.K ? k : kmax;
+        float4 v;
+        if (MODE == 0) {
+            v = *reinterpret_cast<const float4*>(a_ptr[s] + kc);
+        } else {
+            const int tap = kc / p.Ci, ci = kc - tap * p.Ci;
+            int ih = a_oh[s] + tap / 3, iw = a_ow[s] + tap % 3;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : (ih >= p.Hi ? 2 * p.Hi - 2 - ih : ih);
+                iw = iw < 0 ? -iw : (iw >= p.Wi ? 2 * p.Wi - 2 - iw : iw);
             } else {
-                const int tap = k / p.Ci, ci = k - tap * p.Ci;
-                int ih = a_oh[s] + tap / 3, iw = a_ow[s] + tap % 3;
-                bool ok = true;
-                if (p.reflect) {
-                    ih = ih < 0 ? -ih : (ih >= p.Hi ? 2 * p.Hi - 2 - ih : ih);
-                    iw = iw < 0 ? -iw : (iw >= p.Wi ? 2 * p.Wi - 2 - iw : iw);
-                } else {
-                    ok = ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
-                }
-                if (ok) v = *reinterpret_cast<const float4*>(p.A + a_base[s] + ((int64_t)ih * p.Wi + iw) * p.Ci + ci);
+                ok = ok && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+                ih = ih < 0 ? 0 : (ih >= p.Hi ? p.Hi - 1 : ih);
+                iw = iw < 0 ? 0 : (iw >= p.Wi ? p.Wi - 1 : iw);
             }
+            v = *reinterpret_cast<const float4*>(a_ptr[s] + ((int64_t)ih * p.Wi + iw) * p.Ci + ci);
         }
         return v;
     };
-    auto ldB = [&](int s, int k) -> float4 {
-        return (wrow[s] && k < p.K) ? *reinterpret_cast<const float4*>(wrow[s] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ldB = [&](int s, int k, bool& ok) -> float4 {
+        ok = w_ok[s] && k < p.K;
+        return *reinterpret_cast<const float4*>(wrow[s] + (k < p.K ? k : kmax));
     };
 
     f32x16 acc[TM][TN];
@@ -132,18 +149,21 @@ void launch(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, TM, TN>;
     static bool attr_set = false;
     if (!attr_set && T::kLdsBytes > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
         attr_set = true;
     }
-    dim3 grid(xp_cdiv(p.N, T::BN), xp_cdiv(p.M, T::BM));
+    dim3 grid(xp_cdiv(p.N, T::BN) * xp_cdiv(p.M, T::BM));
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     std::string tag = "gemm_f32_mfma_" + std::to_string(T::BM) + "x" + std::to_string(T::BN);
     if (by_shape) tag += (p.mode ? "_conv_M" : "_M") + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
     const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K,
                      4.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+    if (p.mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, 0>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), T::kLdsBytes, s, p);
 }
 
 int dispatch(const GemmParams& p, hipStream_t s) {

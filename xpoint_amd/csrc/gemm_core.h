@@ -29,7 +29,10 @@ struct GemmTile {
     __device__ static __forceinline__ int slot_row(int s) { return (threadIdx.x + s * NT) / (XP_BK / 4); }
     __device__ static __forceinline__ int slot_kq(int s) { return (threadIdx.x + s * NT) % (XP_BK / 4); }
 
-    // ldA(slot, k) / ldB(slot, k): float4 of 4 consecutive k starting at absolute k (zero past the edge).
+    // ldA(slot, k, ok) / ldB(slot, k, ok): float4 of 4 consecutive k starting at absolute k, loaded UNCONDITIONALLY
+    // from a valid (possibly redirected) address; ok = whether the value is real.  Invalid values are zeroed when the
+    // registers are written to LDS, i.e. AFTER the MFMAs of the current slab: the loads stay in flight behind the
+    // matrix work (a select right after the load would make hipcc wait for the data before the MFMAs).
     template <class LA, class LB>
     __device__ static __forceinline__ void run(float* lds, int K, LA ldA, LB ldB, f32x16 (&acc)[TM][TN]) {
         float* As = lds;
@@ -38,19 +41,27 @@ struct GemmTile {
         const int wm = wave / WN, wn = wave % WN;
         const int fr = lane & 31, fh = lane >> 5;
         float4 ra[A_LD], rb[B_LD];
+        bool oka[A_LD], okb[B_LD];
         auto gload = [&](int k0) {
 #pragma unroll
-            for (int s = 0; s < A_LD; ++s) ra[s] = ldA(s, k0 + slot_kq(s) * 4);
+            for (int s = 0; s < A_LD; ++s) ra[s] = ldA(s, k0 + slot_kq(s) * 4, oka[s]);
 #pragma unroll
-            for (int s = 0; s < B_LD; ++s) rb[s] = ldB(s, k0 + slot_kq(s) * 4);
+            for (int s = 0; s < B_LD; ++s) rb[s] = ldB(s, k0 + slot_kq(s) * 4, okb[s]);
         };
         auto lstore = [&](int buf) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the selects (first use of the loaded registers) below the MFMAs
 #pragma unroll
-            for (int s = 0; s < A_LD; ++s)
-                *reinterpret_cast<float4*>(As + (buf * BM + slot_row(s)) * XP_LDS_STRIDE + slot_kq(s) * 4) = ra[s];
+            for (int s = 0; s < A_LD; ++s) {
+                float4 v = ra[s];
+                v.x = oka[s] ? v.x : 0.f; v.y = oka[s] ? v.y : 0.f; v.z = oka[s] ? v.z : 0.f; v.w = oka[s] ? v.w : 0.f;
+                *reinterpret_cast<float4*>(As + (buf * BM + slot_row(s)) * XP_LDS_STRIDE + slot_kq(s) * 4) = v;
+            }
 #pragma unroll
-            for (int s = 0; s < B_LD; ++s)
-                *reinterpret_cast<float4*>(Bs + (buf * BN + slot_row(s)) * XP_LDS_STRIDE + slot_kq(s) * 4) = rb[s];
+            for (int s = 0; s < B_LD; ++s) {
+                float4 v = rb[s];
+                v.x = okb[s] ? v.x : 0.f; v.y = okb[s] ? v.y : 0.f; v.z = okb[s] ? v.z : 0.f; v.w = okb[s] ? v.w : 0.f;
+                *reinterpret_cast<float4*>(Bs + (buf * BN + slot_row(s)) * XP_LDS_STRIDE + slot_kq(s) * 4) = v;
+            }
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i)

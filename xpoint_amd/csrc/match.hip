@@ -70,12 +70,14 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
     const float* A = p.d1 + (int64_t)pair * p.cap1 * p.D;
     const float* B = p.d2 + (int64_t)pair * p.cap2 * p.D;
     const float* arow[T::A_LD]; const float* brow[T::B_LD];
+    bool aok[T::A_LD], bok[T::B_LD];
 #pragma unroll
-    for (int s = 0; s < T::A_LD; ++s) { const int m = m0 + T::slot_row(s); arow[s] = m < n1 ? A + (int64_t)m * p.D : nullptr; }
+    for (int s = 0; s < T::A_LD; ++s) { const int m = m0 + T::slot_row(s); aok[s] = m < n1; arow[s] = A + (int64_t)(aok[s] ? m : 0) * p.D; }
 #pragma unroll
-    for (int s = 0; s < T::B_LD; ++s) { const int n = n0 + T::slot_row(s); brow[s] = n < n2 ? B + (int64_t)n * p.D : nullptr; }
-    auto ldA = [&](int s, int k) -> float4 { return (arow[s] && k < p.D) ? *reinterpret_cast<const float4*>(arow[s] + k) : make_float4(0.f, 0.f, 0.f, 0.f); };
-    auto ldB = [&](int s, int k) -> float4 { return (brow[s] && k < p.D) ? *reinterpret_cast<const float4*>(brow[s] + k) : make_float4(0.f, 0.f, 0.f, 0.f); };
+    for (int s = 0; s < T::B_LD; ++s) { const int n = n0 + T::slot_row(s); bok[s] = n < n2; brow[s] = B + (int64_t)(bok[s] ? n : 0) * p.D; }
+    const int kmax = p.D - 4;
+    auto ldA = [&](int s, int k, bool& ok) -> float4 { ok = aok[s] && k < p.D; return *reinterpret_cast<const float4*>(arow[s] + (k < p.D ? k : kmax)); };
+    auto ldB = [&](int s, int k, bool& ok) -> float4 { ok = bok[s] && k < p.D; return *reinterpret_cast<const float4*>(brow[s] + (k < p.D ? k : kmax)); };
     for (int i = threadIdx.x; i < T::BM; i += 256) s_row[i] = ~0ull;
     for (int i = threadIdx.x; i < T::BN; i += 256) s_col[i] = ~0ull;
     f32x16 acc[2][2];

@@ -4,6 +4,8 @@
 //   sample_descriptors reference xpoint/utils/utils.py:229-238  (F.grid_sample bilinear, align_corners)
 #include "xp_common.h"
 
+extern "C" size_t xp_extract_keypoints_workspace_bytes(int batch, int H, int W);
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -178,42 +180,65 @@ __global__ __launch_bounds__(256) void topk_zero_kernel(float* __restrict__ out,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Keypoint extraction: row-major (y, x) list of pixels with prob > thr (and mask != 0), per image.
-// One 1024-thread workgroup per image walks the image in order with a running offset, so the list
-// order equals torch.nonzero's — it defines the match index space.
+// Keypoint extraction: row-major (y, x) list of pixels with prob > thr (and mask != 0), per image — the order of
+// torch.nonzero, which defines the match index space.  Ordered compaction in three stream-ordered launches:
+// per-segment counts (1024 pixels per workgroup), exclusive scan of the segment counts per image, ordered write.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void extract_keypoints_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask,
-                                                                 float thr, int* __restrict__ kp, int* __restrict__ counts,
-                                                                 int H, int W, int cap) {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    const int b = blockIdx.x;
-    const int64_t HW = (int64_t)H * W;
-    const float* pb = prob + b * HW;
-    const uint8_t* mb = mask ? mask + b * HW : nullptr;
-    int* kb = kp + (int64_t)b * cap * 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = 0;
+constexpr int KP_SEG = 1024;
+
+__device__ __forceinline__ bool kp_hit(const float* __restrict__ pb, const uint8_t* __restrict__ mb, int64_t i, int64_t HW, float thr) {
+    return i < HW && pb[i] > thr && (!mb || mb[i]);
+}
+
+__global__ __launch_bounds__(KP_SEG) void kp_count_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask, float thr,
+                                                           int* __restrict__ seg_counts, int64_t HW, int nseg) {
+    __shared__ int s_wave[KP_SEG / 64];
+    const int b = blockIdx.y, seg = blockIdx.x;
+    const int64_t i = (int64_t)seg * KP_SEG + threadIdx.x;
+    const bool hit = kp_hit(prob + b * HW, mask ? mask + b * HW : nullptr, i, HW, thr);
+    const unsigned long long bal = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
-    for (int64_t i0 = 0; i0 < HW; i0 += 1024) {
-        const int64_t i = i0 + threadIdx.x;
-        bool hit = false;
-        if (i < HW) hit = (pb[i] > thr) && (!mb || mb[i]);
-        const unsigned long long bal = __ballot(hit);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wave] = __popcll(bal);
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < KP_SEG / 64; ++w) t += s_wave[w]; seg_counts[b * nseg + seg] = t; }
+}
+
+// one workgroup per image: exclusive scan of the segment counts in place; total -> counts[b]
+__global__ __launch_bounds__(1024) void kp_scan_kernel(int* __restrict__ seg_counts, int* __restrict__ counts, int nseg) {
+    __shared__ int s_part[1024];
+    const int b = blockIdx.x;
+    int* sc = seg_counts + b * nseg;
+    const int per = (nseg + 1023) / 1024;
+    const int j0 = threadIdx.x * per, j1 = min(nseg, j0 + per);
+    int t = 0;
+    for (int j = j0; j < j1; ++j) t += sc[j];
+    s_part[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan over the 1024 partials
+        const int v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
         __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (hit) {
-            const int pos = off + before;
-            if (pos < cap) { kb[2 * pos] = (int)(i / W); kb[2 * pos + 1] = (int)(i % W); }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_wave[w]; s_base += t; }
+        s_part[threadIdx.x] += v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[b] = s_base;   // may exceed cap: the caller checks
+    int run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
+    for (int j = j0; j < j1; ++j) { const int c = sc[j]; sc[j] = run; run += c; }
+    if (threadIdx.x == 1023) counts[b] = s_part[1023];   // may exceed cap: the caller checks
+}
+
+__global__ __launch_bounds__(KP_SEG) void kp_write_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask, float thr,
+                                                           const int* __restrict__ seg_offsets, int* __restrict__ kp, int64_t HW, int W,
+                                                           int nseg, int cap) {
+    __shared__ int s_wave[KP_SEG / 64];
+    const int b = blockIdx.y, seg = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)seg * KP_SEG + threadIdx.x;
+    const bool hit = kp_hit(prob + b * HW, mask ? mask + b * HW : nullptr, i, HW, thr);
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    if (!hit) return;
+    int pos = seg_offsets[b * nseg + seg] + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+    if (pos < cap) { int* kb = kp + ((int64_t)b * cap + pos) * 2; kb[0] = (int)(i / W); kb[1] = (int)(i % W); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,7 +341,7 @@ extern "C" size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap) {
     // state bytes + tile flags + counters + (top-k) keypoint list, counts, ranks
     const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
     const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TILE) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
-    return n + nt + sizeof(int) * (NMS_MAX_SWEEPS + (size_t)batch * cap * 3 + batch + 64);
+    return n + nt + sizeof(int) * (NMS_MAX_SWEEPS + (size_t)batch * cap * 3 + batch + 64) + xp_extract_keypoints_workspace_bytes(batch, H, W);
 }
 
 // Enqueue `sweeps` sweep launches (each exits at once when the previous one left nothing undecided).
@@ -333,8 +358,9 @@ static int box_nms_enqueue(const float* prob, float* out, void* workspace, int b
     return XP_OK;
 }
 
+extern "C" size_t xp_extract_keypoints_workspace_bytes(int batch, int H, int W);
 extern "C" int xp_extract_keypoints(const float* prob, const uint8_t* mask, float thr, int* kp, int* counts, int batch,
-                                    int H, int W, int cap, void* stream);
+                                    int H, int W, int cap, void* workspace, size_t workspace_bytes, void* stream);
 
 extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t workspace_bytes, int batch, int H, int W,
                           float size, float min_prob, float iou, int keep_top_k, int cap, int max_sweeps_async,
@@ -372,7 +398,8 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
         int* kp = w.kp;
         int* counts = kp + (size_t)batch * cap * 2;
         int* rank = counts + batch;
-        int rc = xp_extract_keypoints(out, nullptr, 0.f, kp, counts, batch, H, W, cap, stream);
+        void* ews = rank + (size_t)batch * cap;
+        int rc = xp_extract_keypoints(out, nullptr, 0.f, kp, counts, batch, H, W, cap, ews, xp_extract_keypoints_workspace_bytes(batch, H, W), stream);
         if (rc) return rc;
         dim3 grid(xp_cdiv(cap, 256), batch);
         hipLaunchKernelGGL(topk_rank_kernel, grid, dim3(256), 0, s, out, kp, counts, rank, cap, W, (int64_t)H * W);
@@ -391,12 +418,23 @@ extern "C" int xp_box_nms_check(const void* workspace, int batch, int H, int W, 
     return XP_OK;
 }
 
+extern "C" size_t xp_extract_keypoints_workspace_bytes(int batch, int H, int W) {
+    return sizeof(int) * (size_t)batch * (size_t)xp_cdiv((int64_t)H * W, KP_SEG) + 256;
+}
+
 extern "C" int xp_extract_keypoints(const float* prob, const uint8_t* mask, float thr, int* kp, int* counts, int batch,
-                                    int H, int W, int cap, void* stream) {
-    XP_CHECK_ARG(prob && kp && counts, "xp_extract_keypoints: null pointer");
+                                    int H, int W, int cap, void* workspace, size_t workspace_bytes, void* stream) {
+    XP_CHECK_ARG(prob && kp && counts && workspace, "xp_extract_keypoints: null pointer");
     XP_CHECK_ARG(batch > 0 && cap > 0, "xp_extract_keypoints: bad batch/cap");
-    XpProfScope prof("extract_keypoints", (hipStream_t)stream, 0.0, 4.0 * batch * H * W);
-    hipLaunchKernelGGL(extract_keypoints_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, prob, mask, thr, kp, counts, H, W, cap);
+    XP_CHECK_ARG(workspace_bytes >= xp_extract_keypoints_workspace_bytes(batch, H, W), "xp_extract_keypoints: workspace too small");
+    const int64_t HW = (int64_t)H * W;
+    const int nseg = xp_cdiv(HW, KP_SEG);
+    int* seg = (int*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    XpProfScope prof("extract_keypoints", s, 0.0, 8.0 * batch * H * W);
+    hipLaunchKernelGGL(kp_count_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, HW, nseg);
+    hipLaunchKernelGGL(kp_scan_kernel, dim3(batch), dim3(1024), 0, s, seg, counts, nseg);
+    hipLaunchKernelGGL(kp_write_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, kp, HW, W, nseg, cap);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }

@@ -96,6 +96,7 @@ class PairPipeline:
         self.nms_ws = torch.empty(lib.xp_box_nms_workspace_bytes(n, H, W, self.cap), dtype=torch.uint8, device=dev)
         self.kp = torch.zeros((n, self.cap, 2), dtype=torch.int32, device=dev)
         self.counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.kp_ws = torch.empty(lib.xp_extract_keypoints_workspace_bytes(n, H, W), dtype=torch.uint8, device=dev)
         D = int(net.config['descriptor_size'])
         self.D = D
         self.desc = torch.zeros((n, self.cap, D), device=dev)
@@ -127,7 +128,8 @@ class PairPipeline:
                                       float(self.pred['nms']), thr, 0.1, int(self.pred['topk']), self.cap, self.sweeps, None, st),
                        "xp_box_nms")
             prob = self.prob_nms
-        _lib.check(lib.xp_extract_keypoints(ptr(prob), None, thr, ptr(self.kp), ptr(self.counts), n, H, W, self.cap, st),
+        _lib.check(lib.xp_extract_keypoints(ptr(prob), None, thr, ptr(self.kp), ptr(self.counts), n, H, W, self.cap, ptr(self.kp_ws),
+                                            self.kp_ws.numel(), st),
                    "xp_extract_keypoints")
         d = raw["desc_nhwc"]
         _lib.check(lib.xp_sample_descriptors(ptr(self.kp), ptr(self.counts), ptr(d), ptr(self.desc), n, self.cap, d.shape[1],

@@ -88,7 +88,9 @@ def extract_keypoints(prob, thr, mask=None, cap=None):
     m = None
     if mask is not None:
         m = mask.contiguous().to(torch.uint8)
-    _lib.call("xp_extract_keypoints", ptr(p), ptr(m), float(thr), ptr(kp), ptr(counts), B, H, W, cap, _lib.current_stream())
+    ws = torch.empty(_lib.load().xp_extract_keypoints_workspace_bytes(B, H, W), dtype=torch.uint8, device=p.device)
+    _lib.call("xp_extract_keypoints", ptr(p), ptr(m), float(thr), ptr(kp), ptr(counts), B, H, W, cap, ptr(ws), ws.numel(),
+              _lib.current_stream())
     return kp, counts
 
 
