@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, int idx) {
 __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_stride) {
     using T = GemmTile<2, 2, 2, 2>;
     extern __shared__ __align__(16) float lds[];
-    __shared__ unsigned long long s_row[T::BM], s_col[T::BN];
+    __shared__ unsigned long long s_col[T::BN];
     const int pair = blockIdx.z;
     const int n1 = count_of(p.n1p, pair * cnt_stride + p.which1, p.cap1);
     const int n2 = count_of(p.n2p, pair * cnt_stride + p.which2, p.cap2);
@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
     const int kmax = p.D - 4;
     auto ldA = [&](int s, int k, bool& ok) -> float4 { ok = aok[s] && k < p.D; return *reinterpret_cast<const float4*>(arow[s] + (k < p.D ? k : kmax)); };
     auto ldB = [&](int s, int k, bool& ok) -> float4 { ok = bok[s] && k < p.D; return *reinterpret_cast<const float4*>(brow[s] + (k < p.D ? k : kmax)); };
-    for (int i = threadIdx.x; i < T::BM; i += 256) s_row[i] = ~0ull;
     for (int i = threadIdx.x; i < T::BN; i += 256) s_col[i] = ~0ull;
     f32x16 acc[2][2];
     T::run(lds, p.D, ldA, ldB, acc);   // ends with a barrier, so s_row/s_col init is visible
@@ -89,77 +88,105 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
     float nbv[2]; int colg[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { colg[j] = n0 + T::col_of(j); nbv[j] = colg[j] < n2 ? nb[colg[j]] : 0.f; }
-    // distances in place; invalid entries -> +inf
+    // distances in place; invalid entries -> +inf.  The K-loop's LDS is free now: the tile is also written there
+    // ([128][TS] floats) so that ROW minima become in-lane scans (the MFMA layout keeps a row spread over 32 lanes,
+    // a column in one lane's registers).
+    constexpr int TS = 136;   // row stride: conflict-free for the b128 row scans below
+    float* tile = lds;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + T::row_of(i, r);
+            const int rl = T::row_of(i, r), row = m0 + rl;
             const float nav = row < n1 ? na[row] : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float d = fmaxf(nav + nbv[j] - 2.f * acc[i][j][r], 0.f);
                 if (row >= n1 || colg[j] >= n2) d = INFINITY;
                 acc[i][j][r] = d;
+                tile[rl * TS + T::col_of(j)] = d;
             }
         }
-    // row minima: over j in-lane, then over the 32 lanes of a half (same row), then LDS across waves
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            unsigned long long k = pack_key(acc[i][0][r], colg[0]);
-            const unsigned long long k1 = pack_key(acc[i][1][r], colg[1]);
-            k = k1 < k ? k1 : k;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(k, o, 64); k = t < k ? t : k; }
-            if ((lane & 31) == 0) atomicMin(&s_row[T::row_of(i, r)], k);
-        }
-    // column minima: over i, r in-lane, then across the two halves, then LDS across waves
+    // column minima: in-lane over the 32 rows a lane holds, then the other lane half, then LDS across the two wave rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        unsigned long long k = ~0ull;
+        float best = INFINITY; int bi = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned long long t = pack_key(acc[i][j][r], m0 + T::row_of(i, r));
-                k = t < k ? t : k;
+            for (int r = 0; r < 16; ++r) {   // rows ascend with (i, r>>2, lane half, r&3): strict < keeps the first minimum
+                const float d = acc[i][j][r];
+                const int rg = m0 + T::row_of(i, r);
+                if (d < best || (d == best && rg < bi)) { best = d; bi = rg; }
             }
+        unsigned long long k = pack_key(best, bi);
         const unsigned long long t = __shfl_xor(k, 32, 64);
         k = t < k ? t : k;
         if (lane < 32) atomicMin(&s_col[T::col_of(j)], k);
     }
     __syncthreads();
-    // merge with the other tiles; keep the running minimum (old min mine) for the nomination threshold
+    // row minima: thread t scans 64 columns (interleaved 4-wide) of row t/2
     unsigned long long* rk = p.rowkey + (int64_t)pair * p.cap1;
     unsigned long long* ck = p.colkey + (int64_t)pair * p.cap2;
-    for (int i = threadIdx.x; i < T::BM; i += 256)
-        if (m0 + i < n1) { const unsigned long long mine = s_row[i]; const unsigned long long old = atomicMin(&rk[m0 + i], mine); s_row[i] = old < mine ? old : mine; }
+    int* rcnt = p.rcnt + (int64_t)pair * p.cap1; int* rcand = p.rcand + (int64_t)pair * p.cap1 * CAND_CAP;
+    int* ccnt = p.ccnt + (int64_t)pair * p.cap2; int* ccand = p.ccand + (int64_t)pair * p.cap2 * CAND_CAP;
+    {
+        const int rl = threadIdx.x >> 1, hf = threadIdx.x & 1, row = m0 + rl;
+        const float* trow = tile + rl * TS + 4 * hf;
+        float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(trow + 8 * m);
+            const int c0 = n0 + 8 * m + 4 * hf;
+            if (v.x < best) { best = v.x; bi = c0; }
+            if (v.y < best) { best = v.y; bi = c0 + 1; }
+            if (v.z < best) { best = v.z; bi = c0 + 2; }
+            if (v.w < best) { best = v.w; bi = c0 + 3; }
+        }
+        unsigned long long k = pack_key(best, bi);
+        const unsigned long long t = __shfl_xor(k, 1, 64);
+        k = t < k ? t : k;
+        unsigned long long run = k;
+        if (hf == 0 && row < n1) { const unsigned long long old = atomicMin(&rk[row], k); run = old < k ? old : k; }
+        run = __shfl(run, lane & ~1, 64);
+        if (row < n1) {
+            const float rmin = __uint_as_float((unsigned int)(run >> 32));
+            const float nav = na[row];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const float4 v = *reinterpret_cast<const float4*>(trow + 8 * m);
+                const float dv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = n0 + 8 * m + 4 * hf + e;
+                    if (c < n2 && dv[e] <= rmin + MATCH_EPS * (nav + nb[c] + 1e-30f)) {
+                        const int pos = atomicAdd(&rcnt[row], 1);
+                        if (pos < CAND_CAP) rcand[(int64_t)row * CAND_CAP + pos] = c;
+                    }
+                }
+            }
+        }
+    }
+    // merge column minima with the other tiles, then nominate column candidates from the registers
     for (int i = threadIdx.x; i < T::BN; i += 256)
         if (n0 + i < n2) { const unsigned long long mine = s_col[i]; const unsigned long long old = atomicMin(&ck[n0 + i], mine); s_col[i] = old < mine ? old : mine; }
     __syncthreads();
-    // nominate candidates within EPS of the running minima
-    int* rcnt = p.rcnt + (int64_t)pair * p.cap1; int* rcand = p.rcand + (int64_t)pair * p.cap1 * CAND_CAP;
-    int* ccnt = p.ccnt + (int64_t)pair * p.cap2; int* ccand = p.ccand + (int64_t)pair * p.cap2 * CAND_CAP;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+        if (colg[j] >= n2) continue;
+        const float cmin = __uint_as_float((unsigned int)(s_col[T::col_of(j)] >> 32));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = T::row_of(i, r), row = m0 + rl;
-            if (row >= n1) continue;
-            const float rmin = __uint_as_float((unsigned int)(s_row[rl] >> 32));
-            const float nav = na[row];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (colg[j] >= n2) continue;
-                const float d = acc[i][j][r];
-                const float eps = MATCH_EPS * (nav + nbv[j] + 1e-30f);
-                if (d <= rmin + eps) { const int pos = atomicAdd(&rcnt[row], 1); if (pos < CAND_CAP) rcand[(int64_t)row * CAND_CAP + pos] = colg[j]; }
-                const float cmin = __uint_as_float((unsigned int)(s_col[T::col_of(j)] >> 32));
-                if (d <= cmin + eps) { const int pos = atomicAdd(&ccnt[colg[j]], 1); if (pos < CAND_CAP) ccand[(int64_t)colg[j] * CAND_CAP + pos] = row; }
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + T::row_of(i, r);
+                if (row >= n1) continue;
+                if (acc[i][j][r] <= cmin + MATCH_EPS * (na[row] + nbv[j] + 1e-30f)) {
+                    const int pos = atomicAdd(&ccnt[colg[j]], 1);
+                    if (pos < CAND_CAP) ccand[(int64_t)colg[j] * CAND_CAP + pos] = row;
+                }
             }
-        }
+    }
 }
 
 // Exact nearest neighbour among the nominated candidates (fp64 direct form); one wave per query.
