@@ -59,7 +59,8 @@ int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers (nn.Linear / nn.Conv2d of VMamba.py:110-128,649,663,1405-1440 and XPoint.py:112-138).
  *   C[m,n] = (act(sum_k A[m,k] Wt[n,k] + bias[n]) * scale[n] + shift[n]) + res[m,n]
- *   act: 0 none, 1 GELU(erf), 2 ReLU;  bias/scale/shift/res may be NULL (scale and shift together);
+ *   act: 0 none, 1 GELU(erf), 2 ReLU, 3 = ReLU applied after scale/shift (conv -> BN -> ReLU);
+ *   bias/scale/shift/res may be NULL (scale and shift together);
  *   K and lda multiples of 4.  xp_conv3x3_nhwc: NHWC input, weight (Co, 3, 3, Ci), pad 1 (zero or
  *   reflection), stride 1 or 2, output NHWC (batch, Ho, Wo, Co). */
 int xp_gemm_nt(const float* A, const float* Wt, float* C, const float* bias, const float* scale, const float* shift,

@@ -47,3 +47,15 @@ def build_reference_superpoint(state_dict=None):
     if state_dict is not None:
         net.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=True)
     return net
+
+
+def build_reference_conv_xpoint(cfg: dict, state_dict=None):
+    """Conv-encoder XPoint (model_weights/multipoint/params.yaml): no VMamba yaml needed."""
+    stubs.install()
+    import xpoint.models as ref_models
+    net = ref_models.XPoint(copy.deepcopy(cfg))
+    net.eval()
+    if state_dict is not None:
+        missing, unexpected = net.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=True)
+        assert not missing and not unexpected
+    return net

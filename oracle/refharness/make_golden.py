@@ -39,6 +39,28 @@ SCAN_CASES = [(2, 4, 24, 1, 64), (1, 4, 96, 1, 300), (1, 4, 48, 1, 1200), (1, 2,
               (1, 4, 8, 1, 4800), (1, 1, 4, 8, 512), (2, 2, 6, 4, 65)]
 
 
+def gen_g12():
+    """G12: conv-encoder XPoint (BASELINE config 1 reading A; model_weights/multipoint/params.yaml), real reference."""
+    torch.set_num_threads(1)
+    cfg = synth.multipoint_config()
+    sdn = synth.make_conv_xpoint_state_dict(cfg)
+    net = build_ref.build_reference_conv_xpoint(cfg, sdn)
+    assert net.takes_pair() is False
+    out = {}
+    for (H, W) in [(64, 96), (240, 320)]:
+        img = torch.from_numpy(synth.make_image(0, "optical", H, W)[None])
+        with torch.no_grad():
+            r = net({"image": img, "is_optical": torch.ones(1, 1, dtype=torch.bool)})
+        if H == 64:
+            for k in ("prob", "desc", "encoder_output"):
+                out[f"64x96/{k}"] = r[k].numpy()
+        else:
+            out["240x320/prob"] = r["prob"].numpy()
+            out["240x320/desc_sum"] = np.array([r["desc"].double().sum().item(), r["desc"].double().abs().sum().item()])
+            print("conv xpoint 240x320: pmax", float(r["prob"].max()), "cand frac", float((r["prob"] > 0.015).float().mean()))
+    np.savez_compressed(os.path.join(OUT, "g12_conv_xpoint.npz"), **out)
+
+
 def main():
     torch.set_num_threads(1)
     stubs.install()
@@ -179,6 +201,8 @@ def main():
             g11[f"{H}x{W}/prob"] = r["prob"].numpy()
             g11[f"{H}x{W}/desc_sum"] = np.array([r["desc"].double().sum().item(), r["desc"].double().abs().sum().item()])
     np.savez_compressed(os.path.join(OUT, "g11_superpoint.npz"), **g11)
+
+    gen_g12()
 
     # ---- G10: full size 480x640 pair: summaries only ----
     H, W = 480, 640

@@ -228,9 +228,21 @@ def descriptor_head(x, sd):
     return F.normalize(d, p=2, dim=1)                             # XPoint.py:365-366
 
 
+def conv_encoder_forward(image, sd, pre="encoder."):
+    """XPoint.py:331-336,451-466: 4 x [pad, conv3x3, ReLU, BN] x 2 with 3 max-pools (channel_version 0)."""
+    x = image
+    for li, idx in enumerate([1, 5, 10, 14, 19, 23, 28, 32]):
+        x = F.pad(x, (1, 1, 1, 1), mode="reflect")
+        x = F.relu(F.conv2d(x, sd[f"{pre}{idx}.weight"], sd[f"{pre}{idx}.bias"]))
+        x = _bn(x, sd, f"{pre}{idx + 2}.")
+        if li in (1, 3, 5):
+            x = F.max_pool2d(x, 2, 2)
+    return x
+
+
 def forward_impl(image, sd, force_return_logits=False):
-    """XPoint.py:283-323 with multispectral False."""
-    enc = vssm_forward(image, sd)
+    """XPoint.py:283-323 with multispectral False (VMamba encoder, or the conv encoder when the state dict has one)."""
+    enc = conv_encoder_forward(image, sd) if "encoder.1.weight" in sd else vssm_forward(image, sd)
     prob, logits = detector_head(enc, sd, force_return_logits)
     return {"prob": prob, "logits": logits, "desc": descriptor_head(enc, sd), "encoder_output": enc}
 

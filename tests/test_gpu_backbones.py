@@ -1,0 +1,103 @@
+"""GPU parity of the BASELINE config-1 backbones (conv-encoder XPoint, SuperPointMagicLeap) and the RegNet
+homography head (config 5, valid at 256x256 only) against goldens produced by the REAL reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xpoint_oracle as xo
+from xpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def test_conv_xpoint_vs_reference(gpu_lib, golden):
+    from xpoint_amd import models
+    g = golden("g12_conv_xpoint.npz")
+    cfg = synth.multipoint_config()
+    net = models.XPoint(cfg)
+    net.load_state_dict(_t(synth.make_conv_xpoint_state_dict(cfg)), strict=True)
+    net.to("cuda").eval()
+    assert net.takes_pair() is False
+    img = torch.from_numpy(synth.make_image(0, "optical", 64, 96)[None]).cuda()
+    with torch.no_grad():
+        r = net({"image": img, "is_optical": torch.ones(1, 1, dtype=torch.bool)})
+    for k in ("prob", "desc", "encoder_output"):
+        assert r[k].shape == g[f"64x96/{k}"].shape
+        assert float(np.abs(r[k].cpu().numpy() - g[f"64x96/{k}"]).max()) < TOL, k
+    img = torch.from_numpy(synth.make_image(0, "optical", 240, 320)[None]).cuda()      # BASELINE config 1 size
+    with torch.no_grad():
+        r = net({"image": img})
+    assert float(np.abs(r["prob"].cpu().numpy() - g["240x320/prob"]).max()) < TOL
+    assert abs(float(r["desc"].double().abs().sum()) - g["240x320/desc_sum"][1]) < 1e-5 * g["240x320/desc_sum"][1]
+
+
+def test_config1_pair_flow_conv_backbone(gpu_lib):
+    """BASELINE configs[0]: conv backbone, one synthetic 240x320 optical/thermal pair through the reference's
+    non-pair call sequence (net(data['optical']), net(data['thermal'])) + NMS + sampling + matching."""
+    from xpoint_amd import models
+    from xpoint_amd.predict import predict_align_image_pair
+    cfg = synth.multipoint_config()
+    sd = _t(synth.make_conv_xpoint_state_dict(cfg))
+    net = models.XPoint(cfg); net.load_state_dict(sd); net.to("cuda").eval()
+    H, W = 240, 320
+    data = synth.to_torch(synth.make_pair_batch(0, 1, H, W), "cuda")
+    with torch.no_grad():
+        o, t, res = predict_align_image_pair(net, data)
+        # oracle on the same inputs: forward, NMS, keypoints, descriptors, exact matches
+        dc = synth.to_torch(synth.make_pair_batch(0, 1, H, W))
+        oo = xo.forward_impl(dc["optical"]["image"], sd); ot = xo.forward_impl(dc["thermal"]["image"], sd)
+    po = xo.box_nms(oo["prob"] * dc["optical"]["valid_mask"], 8, 0.015)
+    ko = xo.extract_keypoints(po[0, 0], 0.015)
+    r = res[0]
+    mine, ref = {tuple(x) for x in r["kp_optical"].cpu().tolist()}, {tuple(x) for x in ko.tolist()}
+    assert len(mine ^ ref) <= max(2, len(ref) // 100), (len(mine), len(ref))
+    oms = xo.get_matches(r["desc_optical"].cpu().numpy(), r["desc_thermal"].cpu().numpy())
+    assert [(m.queryIdx, m.trainIdx) for m in r["matches"]] == [(m.queryIdx, m.trainIdx) for m in oms]
+    assert r["desc_optical"].shape[1] == 64
+
+
+def test_superpoint_vs_reference(gpu_lib, golden):
+    from xpoint_amd import models
+    g = golden("g11_superpoint.npz")
+    net = models.SuperPointMagicLeap()
+    net.load_state_dict(_t(synth.make_superpoint_state_dict()), strict=True)
+    net.to("cuda").eval()
+    assert net.takes_pair() is False
+    img = torch.from_numpy(synth.make_image(0, "optical", 64, 96)[None]).cuda()
+    with torch.no_grad():
+        r = net({"image": img})
+    for k in ("logits", "desc", "prob"):
+        assert r[k].shape == g[f"64x96/{k}"].shape, k
+        err = float(np.abs(r[k].cpu().numpy() - g[f"64x96/{k}"]).max())
+        assert err < (5e-4 if k == "logits" else TOL), (k, err)     # logits carry the x4 detector gain
+    img = torch.from_numpy(synth.make_image(0, "optical", 240, 320)[None]).cuda()
+    with torch.no_grad():
+        r = net({"image": img})
+    assert float(np.abs(r["prob"].cpu().numpy() - g["240x320/prob"]).max()) < TOL
+    with pytest.raises(RuntimeError):
+        net({"image": torch.zeros(1, 1, 64, 96)})
+
+
+def test_regnet_head_256(gpu_lib, golden):
+    """RegNet head: stage-wise (reference encoder outputs in) and end to end through XPoint.forward at 256x256."""
+    from xpoint_amd import models
+    from xpoint_amd.convmodels import regnet_forward, regnet_weights
+    g = golden("g9_regnet.npz")
+    cfg = synth.xpoint_exp1_config(256, 256, hm_head=True)
+    sd = synth.make_torch_state_dict(cfg)
+    w = regnet_weights(sd, torch.device("cuda"))
+    e1 = torch.from_numpy(g["enc_optical"]).permute(0, 2, 3, 1).contiguous().cuda()
+    e2 = torch.from_numpy(g["enc_thermal"]).permute(0, 2, 3, 1).contiguous().cuda()
+    hm = regnet_forward(w, e1, e2)
+    assert hm.shape == (1, 8) and float(np.abs(hm.cpu().numpy() - g["hm"]).max()) < TOL
+    net = models.XPoint(cfg); net.load_state_dict(sd, strict=True); net.to("cuda").eval()
+    with torch.no_grad():
+        o, t, hm2 = net(synth.to_torch(synth.make_pair_batch(7, 1, 256, 256), "cuda"))
+    assert float(np.abs(hm2.cpu().numpy() - g["hm"]).max()) < 5e-4           # includes the encoder's own 1e-5-level error
+    with pytest.raises(RuntimeError):                                          # 480x640: the reference fails too
+        regnet_forward(w, torch.zeros(1, 60, 80, 48, device="cuda"), torch.zeros(1, 60, 80, 48, device="cuda"))

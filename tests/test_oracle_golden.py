@@ -199,3 +199,14 @@ def _known():
 
 
 KNOWN_PROBE = _known()
+
+
+def test_g12_conv_xpoint(golden):
+    g = golden("g12_conv_xpoint.npz")
+    cfg = synth.multipoint_config()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_conv_xpoint_state_dict(cfg).items()}
+    img = torch.from_numpy(synth.make_image(0, "optical", 64, 96)[None])
+    with torch.no_grad():
+        r = xo.forward_impl(img, sd)
+    for k in ("prob", "desc", "encoder_output"):
+        np.testing.assert_allclose(r[k].numpy(), g[f"64x96/{k}"], atol=2e-6, err_msg=k)

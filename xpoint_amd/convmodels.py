@@ -1,0 +1,173 @@
+"""Conv backbones of BASELINE config 1 and the RegNet homography head (config 5), orchestrated op by op from
+Python over the C ABI (implicit-GEMM 3x3 convolutions on the fp32 MFMA engine, max-pool, softmax/shuffle, L2
+normalisation).  They are small networks run at small sizes; the fused single-call path is the VMamba one.
+
+  ConvEncoderXPoint     reference xpoint/models/XPoint.py:331-336,451-466 + heads :112-138
+                        (model_weights/multipoint/params.yaml)
+  SuperPointMagicLeap   reference xpoint/models/SuperPointMagicLeap.py:9-88 (model_weights/superpoint/params.yaml)
+  regnet_forward        reference xpoint/models/RegNet.py:7-52 (valid at 256x256 input only)
+"""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+import torch
+
+from . import nnops as ops
+
+_LoadResult = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+
+def _load_into(store, spec, state_dict, strict):
+    sd = dict(state_dict)
+    missing = [k for k in spec if k not in sd]
+    unexpected = [k for k in sd if k not in spec]
+    for k, (shape, _) in spec.items():
+        if k in sd and tuple(sd[k].shape) != tuple(shape):
+            raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(shape)}")
+    if strict and (missing or unexpected):
+        raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+    for k in spec:
+        if k in sd:
+            t = sd[k]
+            t = torch.from_numpy(np.array(t, copy=True)) if isinstance(t, np.ndarray) else t
+            store[k] = t.detach().to("cpu").clone()
+    return _LoadResult(missing, unexpected)
+
+
+class ConvEncoderXPointImpl:
+    """Device side of xpoint_amd.models.XPoint when the config selects the conv encoder."""
+    CONVS = [1, 5, 10, 14, 19, 23, 28, 32]
+
+    def __init__(self, ref_state, device):
+        s = ref_state
+        self.layers = []
+        for li, idx in enumerate(self.CONVS):
+            sc, sh = ops.bn_affine(s, f"encoder.{idx + 2}.")
+            self.layers.append(dict(w=ops.conv_w(s[f"encoder.{idx}.weight"]).to(device), b=s[f"encoder.{idx}.bias"].float().to(device),
+                                    sc=sc.to(device), sh=sh.to(device), pool=li in (1, 3, 5)))
+        det, dsc = "detector_head_convolutions.", "descriptor_head_convolutions."
+        self.head_w = ops.conv_w(torch.cat([s[det + "1.weight"], s[dsc + "1.weight"]], 0)).to(device)
+        self.head_b = torch.cat([s[det + "1.bias"], s[dsc + "1.bias"]]).float().to(device)
+        a, b = ops.bn_affine(s, det + "3."), ops.bn_affine(s, dsc + "3.")
+        self.head_sc = torch.cat([a[0], b[0]]).to(device); self.head_sh = torch.cat([a[1], b[1]]).to(device)
+        self.hc = s[det + "1.weight"].shape[0]
+        self.det_w = s[det + "4.weight"].reshape(s[det + "4.weight"].shape[0], -1).float().contiguous().to(device)
+        self.det_b = s[det + "4.bias"].float().to(device)
+        self.det_sc, self.det_sh = [t.to(device) for t in ops.bn_affine(s, det + "5.")]
+        self.desc_w = s[dsc + "4.weight"].reshape(s[dsc + "4.weight"].shape[0], -1).float().contiguous().to(device)
+        self.desc_b = s[dsc + "4.bias"].float().to(device)
+        self.desc_sc, self.desc_sh = [t.to(device) for t in ops.bn_affine(s, dsc + "5.")]
+
+    def forward_raw(self, images, want_logits=False):
+        x = ops.gray_to_nhwc4(images.contiguous().float())
+        for L in self.layers:       # [pad(reflect), conv3x3, ReLU, BN] (+ MaxPool2d after every second conv of blocks 1-3)
+            x = ops.conv3x3(x, L["w"], L["b"], L["sc"], L["sh"], 1, True, "relu")
+            if L["pool"]:
+                x = ops.maxpool2(x)
+        enc = x
+        B, Hc, Wc, _ = enc.shape
+        t = ops.conv3x3(enc, self.head_w, self.head_b, self.head_sc, self.head_sh, 1, True, "relu")     # both head trunks
+        t2 = t.view(B * Hc * Wc, 2 * self.hc)
+        logits = ops.linear(t2, self.det_w, self.det_b, self.det_sc, self.det_sh, lda=2 * self.hc).view(B, Hc, Wc, -1)
+        desc_raw = ops.linear(t2[:, self.hc:], self.desc_w, self.desc_b, self.desc_sc, self.desc_sh, lda=2 * self.hc)
+        desc = ops.l2norm_rows(desc_raw, 1e-12).view(B, Hc, Wc, -1)
+        prob = None if want_logits else ops.softmax_shuffle(logits, 8, 0)
+        return {"prob": prob, "desc_nhwc": desc, "enc_nhwc": enc, "logits_nhwc": logits}
+
+
+class SuperPointMagicLeap(torch.nn.Module):
+    """Drop-in for xpoint.models.SuperPointMagicLeap: forward(data) -> {'logits','desc','prob'}; takes_pair() False."""
+    _ENC = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"]
+
+    def __init__(self, config=None):
+        super().__init__()
+        self.config = config or {}
+        self._ref_state = collections.OrderedDict()
+        self._dev = None
+        self._w = None
+
+    def takes_pair(self):
+        return False
+
+    def expected_keys(self):
+        from .synth import superpoint_state_spec
+        return superpoint_state_spec()
+
+    def state_dict(self, *a, **k):
+        return collections.OrderedDict(self._ref_state)
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._w = None
+        return _load_into(self._ref_state, self.expected_keys(), state_dict, strict)
+
+    def to(self, device=None, *a, **k):
+        return self
+
+    def _weights(self, device):
+        if self._w is None or self._dev != device:
+            s = self._ref_state
+            if len(s) != len(self.expected_keys()):
+                raise RuntimeError("SuperPointMagicLeap: weights not loaded")
+            w = {}
+            for n in self._ENC + ["convPa", "convDa"]:
+                w[n] = (ops.conv_w(s[n + ".weight"]).to(device), s[n + ".bias"].float().to(device))
+            for n in ("convPb", "convDb"):
+                w[n] = (s[n + ".weight"].reshape(s[n + ".weight"].shape[0], -1).float().contiguous().to(device), s[n + ".bias"].float().to(device))
+            self._w, self._dev = w, device
+        return self._w
+
+    def forward(self, data):
+        img = data["image"]
+        if not img.is_cuda:
+            raise RuntimeError("xpoint_amd.SuperPointMagicLeap runs on the GPU only (no CPU fallback)")
+        w = self._weights(img.device)
+        x = ops.gray_to_nhwc4(img.contiguous().float())
+        for i, n in enumerate(self._ENC):                      # zero-padded 3x3 + ReLU, pools after 1b/2b/3b (:38-48)
+            x = ops.conv3x3(x, w[n][0], w[n][1], None, None, 1, False, "relu")
+            if i in (1, 3, 5):
+                x = ops.maxpool2(x)
+        B, Hc, Wc, C = x.shape
+        cPa = ops.conv3x3(x, w["convPa"][0], w["convPa"][1], None, None, 1, False, "relu")
+        semi = ops.linear(cPa.view(B * Hc * Wc, -1), w["convPb"][0], w["convPb"][1]).view(B, Hc, Wc, -1)
+        cDa = ops.conv3x3(x, w["convDa"][0], w["convDa"][1], None, None, 1, False, "relu")
+        desc = ops.linear(cDa.view(B * Hc * Wc, -1), w["convDb"][0], w["convDb"][1])
+        desc = ops.l2norm_rows(desc, -1.0).view(B, Hc, Wc, -1)             # desc / ||desc||, no eps (:59-60)
+        prob = ops.softmax_shuffle(semi, 8, 1)                              # exp(x) / (sum + 1e-5) (:73-74)
+        return {"logits": ops.nchw(semi), "desc": ops.nchw(desc), "prob": prob.unsqueeze(1), "desc_nhwc": desc}
+
+
+def regnet_weights(ref_state, device):
+    s = ref_state
+    p = "hm_regressor."
+    w = {"c1": ops.conv_w(s[p + "layer1.0.weight"]).to(device), "c2": ops.conv_w(s[p + "layer1.3.weight"]).to(device)}
+    w["bn1"] = [t.to(device) for t in ops.bn_affine(s, p + "layer1.1.")]
+    w["bn2"] = [t.to(device) for t in ops.bn_affine(s, p + "layer1.4.")]
+    w["fc1"] = (s[p + "fc.1.weight"].float().contiguous().to(device), s[p + "fc.1.bias"].float().to(device))
+    w["fc2"] = (s[p + "fc.4.weight"].float().contiguous().to(device), s[p + "fc.4.bias"].float().to(device))
+    return w
+
+
+def regnet_forward(w, enc1_nhwc, enc2_nhwc):
+    """RegNet.forward (RegNet.py:32-52), eval mode.  enc (B, H', W', 48) NHWC -> (B, 8).  The cost volume's channel count
+    must equal fc.1's input (256), i.e. (H'/2)*(W'/2) == 256 <=> a 256x256 image: raises otherwise, like the
+    reference's Linear does."""
+    def layer1(x):      # conv (no bias) -> BN -> ReLU, twice, then MaxPool2d(2)
+        x = ops.conv3x3(x, w["c1"], None, w["bn1"][0], w["bn1"][1], 1, False, "relu_after_affine")
+        x = ops.conv3x3(x, w["c2"], None, w["bn2"][0], w["bn2"][1], 1, False, "relu_after_affine")
+        return ops.maxpool2(x)
+    a, b = layer1(enc1_nhwc.contiguous()), layer1(enc2_nhwc.contiguous())
+    B, Hh, Wh, C = a.shape
+    hw = Hh * Wh
+    if hw != w["fc1"][0].shape[1]:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{hw} and {w['fc1'][0].shape[1]}x{w['fc1'][0].shape[0]})")
+    an = ops.l2norm_rows(a.view(B * hw, C), 1e-12).view(B, hw, C)      # F.normalize over channels
+    bn = ops.l2norm_rows(b.view(B * hw, C), 1e-12).view(B, hw, C)
+    mean_w = torch.full((1, hw), 1.0 / hw, device=a.device)            # adaptive_avg_pool2d over the (H', W') axes of cv
+    v = torch.empty((B, hw), device=a.device)
+    for i in range(B):
+        cv = ops.linear(an[i], bn[i])                                  # bmm(x1^T, x2): (hw, hw), RegNet.py:50
+        ops.linear(cv, mean_w, out=v[i].view(hw, 1), ldc=1)
+    h = ops.linear(v, w["fc1"][0], w["fc1"][1], act="relu")            # Dropout = identity in eval
+    return ops.linear(h, w["fc2"][0], w["fc2"][1])

@@ -24,7 +24,7 @@ struct GemmParams {
     const float* res;     // (M, ldres) or null
     int M, N, K;
     int lda, ldc, ldres;
-    int act;              // 0 none, 1 GELU(erf), 2 ReLU
+    int act;              // 0 none, 1 GELU(erf), 2 ReLU (before scale/shift), 3 ReLU after scale/shift
     int mode;             // 0: plain A; 1: implicit 3x3 conv over NHWC (K order = kh, kw, ci)
     int Hi, Wi, Ci, Ho, Wo, stride, reflect;
 };
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
                 if (p.act == 1) v = xp_gelu_fast(v);
                 else if (p.act == 2) v = fmaxf(v, 0.f);
                 if (p.scale) v = v * sc + sh;
+                if (p.act == 3) v = fmaxf(v, 0.f);
                 if (p.res) v = rv[r] + v;
                 acc[i][j][r] = v;
             }
@@ -187,7 +188,7 @@ extern "C" int xp_gemm_nt(const float* A, const float* Wt, float* C, const float
     XP_CHECK_ARG(M > 0 && N > 0 && K > 0, "xp_gemm_nt: bad shape %d %d %d", M, N, K);
     XP_CHECK_ARG(K % 4 == 0 && lda % 4 == 0, "xp_gemm_nt: K and lda must be multiples of 4 (got %d, %d)", K, lda);
     XP_CHECK_ARG((scale == nullptr) == (shift == nullptr), "xp_gemm_nt: scale and shift go together");
-    XP_CHECK_ARG(act >= 0 && act <= 2, "xp_gemm_nt: bad act %d", act);
+    XP_CHECK_ARG(act >= 0 && act <= 3, "xp_gemm_nt: bad act %d", act);
     GemmParams p{};
     p.A = A; p.Wt = Wt; p.C = C; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.act = act; p.mode = 0;

@@ -19,6 +19,7 @@ import torch
 from . import _lib
 from ._lib import c_i, ptr
 from .utils import dict_update
+from .convmodels import SuperPointMagicLeap  # noqa: F401  (reference: xpoint.models.SuperPointMagicLeap)
 
 
 class _ModelCfg(ctypes.Structure):
@@ -50,9 +51,10 @@ class XPoint(torch.nn.Module):
         else:
             self.config = copy.deepcopy(self.default_config)
         ua = self.config['use_attention']
-        if not (ua['check'] and ua['type'] == 'VMamba'):
-            raise NotImplementedError("xpoint_amd.models.XPoint implements the VMamba encoder (use_attention.type 'VMamba', "
-                                      "model_weights/XPoint-EXP1/params.yaml); conv / SwinV2 encoders are out of scope")
+        self._kind = "vmamba" if (ua['check'] and ua['type'] == 'VMamba') else ("conv" if not ua['check'] else None)
+        if self._kind is None:
+            raise NotImplementedError("xpoint_amd.models.XPoint implements the VMamba encoder (model_weights/XPoint-EXP1/params.yaml) "
+                                      "and the conv encoder (model_weights/multipoint/params.yaml); SwinV2 is out of scope")
         if self.config['multispectral']:
             raise NotImplementedError("multispectral two-encoder routing (XPoint.py:284-305) is out of scope; XPoint-EXP1 uses one shared encoder")
         for k, v in (('reflection_pad', True), ('bn_first', False), ('final_batchnorm', True), ('descriptor_head', True),
@@ -61,12 +63,24 @@ class XPoint(torch.nn.Module):
                 raise NotImplementedError(f"config['{k}'] = {self.config[k]!r} is not implemented (XPoint-EXP1 uses {v!r})")
         if self.config['homography_regression_head']['check']:
             assert self.config['takes_pair'], "RegNet can only be used with takes_pair=True"       # XPoint.py:103
-        vssm = ua['model_parameters']['MODEL']['VSSM']
-        if vssm.get('SSM_FORWARDTYPE', 'v05_noz') != 'v05_noz' or float(vssm.get('SSM_RATIO', 1.0)) != 1.0:
-            raise NotImplementedError("only SSM_FORWARDTYPE v05_noz / SSM_RATIO 1.0 (the XPoint config) is implemented")
+        self._ref_state: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
+        self._blob: Optional[torch.Tensor] = None        # device-format weights (one float32 tensor)
+        self._device = torch.device("cpu")
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._conv_impl = None
+        self._regnet_w = None
         self.encoder_downsample_ratio = 8
         self.detector_head_last_dim = 65
         self.head_channels = 256
+        self._ctx = None
+        if self._kind == "conv":
+            if self.config['channel_version'] != 0 or not self.config['double_convolution']:
+                raise NotImplementedError("conv encoder: only channel_version 0 with double_convolution (multipoint params)")
+            self.n_channels = [1, 64, 64, 128, 128]
+            return
+        vssm = ua['model_parameters']['MODEL']['VSSM']
+        if vssm.get('SSM_FORWARDTYPE', 'v05_noz') != 'v05_noz' or float(vssm.get('SSM_RATIO', 1.0)) != 1.0:
+            raise NotImplementedError("only SSM_FORWARDTYPE v05_noz / SSM_RATIO 1.0 (the XPoint config) is implemented")
         depths = list(vssm['DEPTHS'])
         cfg = _ModelCfg()
         cfg.embed_dim = int(vssm['EMBED_DIM']); cfg.n_stages = len(depths)
@@ -80,10 +94,6 @@ class XPoint(torch.nn.Module):
         self._ctx = ctypes.c_void_p()
         _lib.check(_lib.load().xp_ctx_create(ctypes.byref(cfg), ctypes.byref(self._ctx)), "xp_ctx_create")
         self._layout = self._read_layout()
-        self._ref_state: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
-        self._blob: Optional[torch.Tensor] = None        # device-format weights (one float32 tensor)
-        self._device = torch.device("cpu")
-        self._ws: Dict[tuple, torch.Tensor] = {}
         self.n_channels = [1, 64, 64, 128, cfg.embed_dim // 2]
 
     # ------------------------------------------------------------------ reference surface
@@ -100,7 +110,7 @@ class XPoint(torch.nn.Module):
 
     def __del__(self):
         try:
-            if self._ctx:
+            if getattr(self, "_ctx", None):
                 _lib.load().xp_ctx_destroy(self._ctx)
         except Exception:
             pass
@@ -117,8 +127,8 @@ class XPoint(torch.nn.Module):
         return out
 
     def expected_keys(self):
-        from .synth import xpoint_state_spec
-        return xpoint_state_spec(self.config)
+        from .synth import conv_xpoint_state_spec, xpoint_state_spec
+        return conv_xpoint_state_spec(self.config) if self._kind == "conv" else xpoint_state_spec(self.config)
 
     def state_dict(self, *a, **k):
         return collections.OrderedDict(self._ref_state)
@@ -145,6 +155,8 @@ class XPoint(torch.nn.Module):
                 t = torch.from_numpy(np.array(t, copy=True)) if isinstance(t, np.ndarray) else t
                 self._ref_state[k] = t.detach().to("cpu").clone()
         self._blob = None
+        self._conv_impl = None
+        self._regnet_w = None
         return _LoadResult(missing, unexpected)
 
     def _bn_affine(self, pre, eps=1e-5):
@@ -257,6 +269,14 @@ class XPoint(torch.nn.Module):
             raise RuntimeError("image must be (B,1,H,W)")
         images = images.contiguous().float()
         dev = images.device
+        if self._kind == "conv":
+            if self._conv_impl is None:
+                from .convmodels import ConvEncoderXPointImpl
+                missing = [k for k, (_, kind) in self.expected_keys().items() if k not in self._ref_state and kind != "bn_count"]
+                if missing:
+                    raise RuntimeError(f"XPoint: weights not loaded ({len(missing)} tensors missing, e.g. {missing[:3]})")
+                self._conv_impl = ConvEncoderXPointImpl(self._ref_state, dev)
+            return self._conv_impl.forward_raw(images, want_logits=want_logits)
         if self._blob is None or self._blob.device != dev:
             self._blob = self.pack_weights().to(dev)
         n, _, H, W = images.shape
@@ -310,6 +330,10 @@ class XPoint(torch.nn.Module):
         pred_thermal = self._export(raw, slice(B, B + it.shape[0]))
         pred_hm = None
         if self.config["homography_regression_head"]["check"]:
-            from .regnet import regnet_forward
-            pred_hm = regnet_forward(self, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
+            from .convmodels import regnet_forward, regnet_weights
+            if self.config["homography_regression_head"]["type"] != "RegNet":
+                raise NotImplementedError("only homography_regression_head.type 'RegNet' (XPoint-EXP1 params) is implemented")
+            if self._regnet_w is None:
+                self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
+            pred_hm = regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
         return pred_optical, pred_thermal, pred_hm

@@ -231,6 +231,66 @@ def make_torch_state_dict(cfg: dict, **kw):
 
 
 # ------------------------------------------------------------------------------------------
+# conv-encoder XPoint (BASELINE config 1, reference XPoint.py:451-466, model_weights/multipoint/params.yaml)
+# ------------------------------------------------------------------------------------------
+
+def multipoint_config(descriptor_size=64) -> dict:
+    """`model:` block of reference model_weights/multipoint/params.yaml (conv encoder, takes_pair False)."""
+    return {"type": "XPoint", "bn_first": False, "descriptor_head": True, "descriptor_size": descriptor_size,
+            "final_batchnorm": True, "intepolation_mode": "bilinear", "multispectral": False,
+            "normalize_descriptors": True, "reflection_pad": True}
+
+
+CONV_XPOINT_CONVS = [1, 5, 10, 14, 19, 23, 28, 32]      # nn.Sequential indices (SURVEY.md App. B)
+CONV_XPOINT_CHANNELS = [1, 64, 64, 64, 64, 128, 128, 128, 128]   # channel_version 0: [1,64,64,128,128], double convolution
+
+
+def conv_xpoint_state_spec(cfg: dict):
+    spec = OrderedDict()
+    ch = CONV_XPOINT_CHANNELS
+    for li, idx in enumerate(CONV_XPOINT_CONVS):
+        ci, co = ch[li], ch[li + 1]
+        spec[f"encoder.{idx}.weight"] = ((co, ci, 3, 3), "conv_w")
+        spec[f"encoder.{idx}.bias"] = ((co,), "conv_b:%d" % (9 * ci))
+        b = f"encoder.{idx + 2}"
+        spec[b + ".weight"] = ((co,), "bn_w"); spec[b + ".bias"] = ((co,), "bn_b")
+        spec[b + ".running_mean"] = ((co,), "bn_mean"); spec[b + ".running_var"] = ((co,), "bn_var")
+        spec[b + ".num_batches_tracked"] = ((), "bn_count")
+    enc_c, head_c, dsz = 128, 256, int(cfg.get("descriptor_size", 256))
+    for hname, outc in (("detector_head_convolutions", 65), ("descriptor_head_convolutions", dsz)):
+        spec[f"{hname}.1.weight"] = ((head_c, enc_c, 3, 3), "conv_w")
+        spec[f"{hname}.1.bias"] = ((head_c,), "conv_b:%d" % (9 * enc_c))
+        for bi, c in ((3, head_c), (5, outc)):
+            b = f"{hname}.{bi}"
+            spec[b + ".weight"] = ((c,), "bn_w"); spec[b + ".bias"] = ((c,), "bn_b")
+            spec[b + ".running_mean"] = ((c,), "bn_mean"); spec[b + ".running_var"] = ((c,), "bn_var")
+            spec[b + ".num_batches_tracked"] = ((), "bn_count")
+            if bi == 3:
+                spec[f"{hname}.4.weight"] = ((outc, head_c, 1, 1), "conv_w")
+                spec[f"{hname}.4.bias"] = ((outc,), "conv_b:%d" % head_c)
+    # reorder to the reference's registration order (1, 3, 4, 5 per head)
+    ordered = OrderedDict()
+    for k in spec:
+        if k.startswith("encoder."):
+            ordered[k] = spec[k]
+    for hname in ("detector_head_convolutions", "descriptor_head_convolutions"):
+        for bi in (1, 3, 4, 5):
+            for k in spec:
+                if k.startswith(f"{hname}.{bi}."):
+                    ordered[k] = spec[k]
+    return ordered
+
+
+def make_conv_xpoint_state_dict(cfg: dict, tag: str = "convxpoint-synth-v1", detector_gain: float = 24.0):
+    sd = OrderedDict()
+    for name, (shape, kind) in conv_xpoint_state_spec(cfg).items():
+        sd[name] = _gen(name, shape, kind, tag)
+    k = "detector_head_convolutions.4.weight"
+    sd[k] = (sd[k] * np.float32(detector_gain)).astype(np.float32)
+    return sd
+
+
+# ------------------------------------------------------------------------------------------
 # SuperPointMagicLeap (BASELINE config 1, reference SuperPointMagicLeap.py:16-29)
 # ------------------------------------------------------------------------------------------
 
