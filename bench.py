@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (roofline events are then taken in a separate eager pass)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (images uploaded from pinned host memory every step); never the headline value")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -126,12 +127,20 @@ def main():
         lib.xp_prof_enable(0)
         breakdown = sorted(prof_table(), key=lambda r: -r["ms"])
         dominant = breakdown[0]["tag"]
-        # timed region: only the dominant kernel's launches carry events (on their launch stream)
-        lib.xp_prof_reset(); lib.xp_prof_filter(dominant.encode()); lib.xp_prof_enable(1)
+        if args.graph:
+            step = pipe.capture(opt, thr, mo, mt)
+            lib.xp_prof_reset(); lib.xp_prof_filter(dominant.encode()); lib.xp_prof_enable(1)
+            for _ in range(3):
+                pipe.run(opt, thr, mo, mt)          # eager passes: HIP events cannot be recorded inside a replayed graph
+            torch.cuda.synchronize(); lib.xp_prof_enable(0)
+        else:
+            step = lambda: pipe.run(opt, thr, mo, mt)
+            # timed region: only the dominant kernel's launches carry events (on their launch stream)
+            lib.xp_prof_reset(); lib.xp_prof_filter(dominant.encode()); lib.xp_prof_enable(1)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            pipe.run(opt, thr, mo, mt)
+            step()
         sync_all()
         dt = time.perf_counter() - t0
         lib.xp_prof_enable(0)

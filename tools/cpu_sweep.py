@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from oracle import xpoint_oracle as xo
 from xpoint_amd import synth
 H, W = 480, 640

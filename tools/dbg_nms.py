@@ -1,5 +1,5 @@
 import numpy as np, torch, sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from xpoint_amd import synth
 from xpoint_amd.utils import box_nms
 from oracle import xpoint_oracle as xo

@@ -1,6 +1,6 @@
 """Micro-benchmark of xp_gemm_nt on the model's shapes (B=16 images, 480x640)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from xpoint_amd import _lib as L
 shapes = [  # (M, N, K, act, res)
     (307200, 96, 96, 0, 0), (307200, 96, 96, 0, 1), (307200, 384, 96, 1, 0), (307200, 384, 96, 0, 0), (307200, 96, 384, 0, 1),
@@ -10,6 +10,9 @@ shapes = [  # (M, N, K, act, res)
     (4800, 768, 768, 0, 0), (4800, 3072, 768, 1, 0), (4800, 768, 3072, 0, 1),
     (76800, 65, 256, 0, 0), (76800, 256, 256, 0, 0),
 ]
+import os
+if os.environ.get('GB_ONLY'):
+    idx=[int(i) for i in os.environ['GB_ONLY'].split(',')]; shapes=[shapes[i] for i in idx]
 torch.manual_seed(0)
 for (M, N, K, act, res) in shapes:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")

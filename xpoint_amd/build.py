@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libxpoint_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-I", os.path.join(HERE, "..", "include"), "-I", CSRC]
+         "-I", os.path.join(HERE, "..", "include"), "-I", CSRC] + os.environ.get("XP_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _sources():

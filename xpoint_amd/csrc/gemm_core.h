@@ -15,14 +15,22 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int XP_BK = 32;
+#ifndef XP_BK_VALUE
+#define XP_BK_VALUE 32
+#endif
+constexpr int XP_BK = XP_BK_VALUE;
 constexpr int XP_LDS_STRIDE = XP_BK + 4;
+#ifndef XP_STORE_AT_Q
+#define XP_STORE_AT_Q (-1)   /* -1: after the last MFMA group (measured best); q: before MFMA group q */
+#endif
 
 template <int WM, int WN, int TM, int TN>
 struct GemmTile {
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-    static constexpr int A_LD = BM * (XP_BK / 4) / NT, B_LD = BN * (XP_BK / 4) / NT;
-    static_assert(BM * (XP_BK / 4) % NT == 0 && BN * (XP_BK / 4) % NT == 0, "tile/threads mismatch");
+    static constexpr int A_TOT = BM * (XP_BK / 4), B_TOT = BN * (XP_BK / 4);      // float4 staging slots per slab
+    static constexpr int A_LD = (A_TOT + NT - 1) / NT, B_LD = (B_TOT + NT - 1) / NT;
+    __device__ static __forceinline__ bool a_slot_ok(int s) { return A_TOT % NT == 0 || (int)threadIdx.x + s * NT < A_TOT; }
+    __device__ static __forceinline__ bool b_slot_ok(int s) { return B_TOT % NT == 0 || (int)threadIdx.x + s * NT < B_TOT; }
     static constexpr size_t kLdsBytes = sizeof(float) * 2 * (BM + BN) * XP_LDS_STRIDE;
 
     // staging slot s of this thread covers tile row slot_row(s), k-quad slot_kq(s)
@@ -44,24 +52,27 @@ struct GemmTile {
         bool oka[A_LD], okb[B_LD];
         auto gload = [&](int k0) {
 #pragma unroll
-            for (int s = 0; s < A_LD; ++s) ra[s] = ldA(s, k0 + slot_kq(s) * 4, oka[s]);
+            for (int s = 0; s < A_LD; ++s) if (a_slot_ok(s)) ra[s] = ldA(s, k0 + slot_kq(s) * 4, oka[s]);
 #pragma unroll
-            for (int s = 0; s < B_LD; ++s) rb[s] = ldB(s, k0 + slot_kq(s) * 4, okb[s]);
+            for (int s = 0; s < B_LD; ++s) if (b_slot_ok(s)) rb[s] = ldB(s, k0 + slot_kq(s) * 4, okb[s]);
         };
         auto lstore = [&](int buf) {
-            __builtin_amdgcn_sched_barrier(0);   // keep the selects (first use of the loaded registers) below the MFMAs
+            __builtin_amdgcn_sched_barrier(0);   // keep the selects (first use of the loaded registers) below the earlier MFMAs
 #pragma unroll
             for (int s = 0; s < A_LD; ++s) {
+                if (!a_slot_ok(s)) continue;
                 float4 v = ra[s];
                 v.x = oka[s] ? v.x : 0.f; v.y = oka[s] ? v.y : 0.f; v.z = oka[s] ? v.z : 0.f; v.w = oka[s] ? v.w : 0.f;
                 *reinterpret_cast<float4*>(As + (buf * BM + slot_row(s)) * XP_LDS_STRIDE + slot_kq(s) * 4) = v;
             }
 #pragma unroll
             for (int s = 0; s < B_LD; ++s) {
+                if (!b_slot_ok(s)) continue;
                 float4 v = rb[s];
                 v.x = okb[s] ? v.x : 0.f; v.y = okb[s] ? v.y : 0.f; v.z = okb[s] ? v.z : 0.f; v.w = okb[s] ? v.w : 0.f;
                 *reinterpret_cast<float4*>(Bs + (buf * BN + slot_row(s)) * XP_LDS_STRIDE + slot_kq(s) * 4) = v;
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -81,6 +92,10 @@ struct GemmTile {
             const float* Bb = Bs + (buf * BN + wn * TN * 32 + fr) * XP_LDS_STRIDE + 4 * fh;
 #pragma unroll
             for (int q = 0; q < XP_BK / 8; ++q) {
+                // The prefetched slab goes to LDS BEFORE the last MFMA group (its buffer was released by the barrier
+                // that ended the previous slab), so the selects, the ds_writes and their latency sit under 16 MFMAs
+                // instead of between the last MFMA and the barrier.
+                if (XP_STORE_AT_Q >= 0 && q == XP_STORE_AT_Q && t + 1 < nt) lstore(buf ^ 1);
                 float4 af[TM], bf[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * XP_LDS_STRIDE + q * 8);
@@ -96,7 +111,7 @@ struct GemmTile {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                     }
             }
-            if (t + 1 < nt) lstore(buf ^ 1);
+            if (XP_STORE_AT_Q < 0 && t + 1 < nt) lstore(buf ^ 1);
             __syncthreads();
         }
     }

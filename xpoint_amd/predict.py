@@ -141,6 +141,18 @@ class PairPipeline:
                                     ptr(self.match_ws), self.match_ws.numel(), st), "xp_match_mnn")
         return self
 
+    def capture(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        """Capture run() into a hipGraph (fixed shapes, preallocated buffers) and return a replay callable.  The inputs
+        are copied into the pipeline's own image buffer by the graph itself, so refill `optical` / `thermal` in place
+        (same storage) between replays."""
+        self.run(optical, thermal, mask_optical, mask_thermal)          # warm-up outside capture (one-time attribute calls)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(optical, thermal, mask_optical, mask_thermal)
+        self._graph = g
+        return g.replay
+
     def verify(self):
         """After a synchronisation point: the async NMS must have reached its fixed point and no list may have
         overflowed its capacity.  Raises otherwise (the caller can re-run with more sweeps / capacity)."""
