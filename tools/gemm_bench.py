@@ -9,6 +9,7 @@ shapes = [  # (M, N, K, act, res)
     (19200, 384, 384, 0, 0), (19200, 1536, 384, 1, 0), (19200, 384, 1536, 0, 1),
     (4800, 768, 768, 0, 0), (4800, 3072, 768, 1, 0), (4800, 768, 3072, 0, 1),
     (76800, 65, 256, 0, 0), (76800, 256, 256, 0, 0),
+    (19200, 96, 96, 0, 0), (65536, 96, 96, 0, 0),
 ]
 import os
 if os.environ.get('GB_ONLY'):

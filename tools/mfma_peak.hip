@@ -1,35 +1,36 @@
-// Register-only fp32 MFMA throughput probe (what the chip sustains on v_mfma_f32_32x32x2_f32 with nothing else going on).
+// Register-only fp32 MFMA throughput probe: what the chip sustains on v_mfma_f32_32x32x2_f32 for different
+// accumulator interleaving patterns (NACC independent accumulators used round-robin).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NACC>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float b0) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float a = a0 + threadIdx.x * 1e-3f, b = b0 - threadIdx.x * 1e-3f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        for (int u = 0; u < 32; ++u) acc[u % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u % NACC], 0, 0, 0);
         a += 1e-6f;
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+template <int NACC> void run(float* d, int blocks) {
+    int iters = 4000;
+    hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, d, 100, 1.f, 2.f);
+    (void)hipDeviceSynchronize();
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.f, 2.f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double flop = (double)blocks * 4 * iters * 32.0 * (32.0 * 32 * 2 * 2);
+    printf("nacc %d blocks %4d: %.3f ms  %.1f TFLOP/s\n", NACC, blocks, ms, flop / ms / 1e9);
+}
 int main() {
-    float* d; hipMalloc(&d, 256 * 4096 * 4);
-    for (int blocks : {256, 512, 1024, 2048}) {
-        int iters = 4000;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, 100, 1.f, 2.f);
-        hipDeviceSynchronize();
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, iters, 1.f, 2.f);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        double flop = (double)blocks * 4 /*waves*/ * iters * 32.0 * (32.0 * 32 * 2 * 2);
-        printf("blocks %4d: %.3f ms  %.1f TFLOP/s\n", blocks, ms, flop / ms / 1e9);
-    }
+    float* d; (void)hipMalloc(&d, 256 * 4096 * 4);
+    for (int blocks : {256, 512}) { run<1>(d, blocks); run<2>(d, blocks); run<4>(d, blocks); }
     return 0;
 }

@@ -8,7 +8,10 @@
 // Tile engine: gemm_core.h.  MFMA-bound for the deep stages, HBM-bound at stage 0 (K = N = 96).
 #include <stdlib.h>
 
+#include <algorithm>
+#include <type_traits>
 #include <string>
+#include <vector>
 
 #include "gemm_core.h"
 
@@ -27,6 +30,8 @@ struct GemmParams {
     int act;              // 0 none, 1 GELU(erf), 2 ReLU (before scale/shift), 3 ReLU after scale/shift
     int mode;             // 0: plain A; 1: implicit 3x3 conv over NHWC (K order = kh, kw, ci)
     int Hi, Wi, Ci, Ho, Wo, stride, reflect;
+    int stagger_cycles;   // start-up delay of the second workgroup slot of every CU (see gemm_kernel)
+    unsigned long long* stamps;   // debug (XP_GEMM_STAMPS): 4 s_memtime stamps per workgroup, else null
 };
 
 template <int WM, int WN, int TM, int TN, int MODE>
@@ -44,6 +49,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     const int m0 = (logical / ntn) * T::BM, n0 = (logical % ntn) * T::BN;
 
+    // De-phase the two workgroups that share a CU.  Co-resident workgroups start together and take equal time, so they
+    // run in lockstep: both in their MFMA phase (sharing the matrix pipe), then both in their epilogue (pipe idle).
+    // Delaying the second resident wave of workgroups (ids 256..511 fill the second slot of the 256 CUs) by about half
+    // a workgroup period makes one's epilogue overlap the other's MFMAs; later workgroups inherit the offset because
+    // slots are refilled as workgroups retire.  Timing only — results do not depend on it.
+    if (p.stagger_cycles > 0 && bid < 1024) {
+        const long long delay = ((long long)((bid * 40503u) & 0xffffu) * p.stagger_cycles) >> 16;   // pseudo-random phase in [0, stagger)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < delay) __builtin_amdgcn_s_sleep(8);
+    }
+
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
     // Staging loads are branch-free: out-of-range rows / k are redirected to a valid address and zeroed by a select,
     // so the 8 loads of a slab issue back to back (divergent "if (ok) load" regions made hipcc serialise them).
     const float* a_ptr[T::A_LD];     // plain: row base; conv: image base
@@ -100,49 +118,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
     f32x16 acc[TM][TN];
     T::run(lds, p.K, ldA, ldB, acc);
+    if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
 
-    // epilogue, in two phases so that every residual load is in flight before the first store (C may alias res:
-    // a load-add-store chain per element would serialise ~16 L2 round trips per tile)
+    // Epilogue, straight-line: the activation is a compile-time tag and interior tiles skip every bounds test (per-element
+    // runtime switches made hipcc emit ~3 scalar branches per element: ~190 cycles per stored value).  Absent scale /
+    // shift / residual are the exact identities (x*1+0, +0).  Two phases so that every residual load is in flight before
+    // the first store (C may alias res: a load-add-store chain per element would serialise the L2 round trips).
+    const bool interior = (m0 + T::BM <= p.M) && (n0 + T::BN <= p.N);
+    auto epilogue = [&](auto act_tag, auto interior_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + T::col_of(j);
-            const bool cok = col < p.N;
-            const float bi = (p.bias && cok) ? p.bias[col] : 0.f;
-            const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
-            const float sh = (p.shift && cok) ? p.shift[col] : 0.f;
-            float rv[16];
-            if (p.res) {
+            for (int j = 0; j < TN; ++j) {
+                // one 32x32 accumulator tile at a time: its 16 residual loads are in flight together, then its 16 stores
+                // (keeps the live registers at one tile; C may alias res, so loads of the next tile stay behind these stores)
+                // addresses = uniform 64-bit tile base (SGPRs) + 32-bit lane offset: no 64-bit VALU per element
+                const int cl = T::col_of(j), col = n0 + cl;
+                const bool cok = INTERIOR || col < p.N;
+                const int clc = cok ? cl : 0;
+                const float bi = p.bias ? p.bias[n0 + clc] : 0.f;
+                const float sc = p.scale ? p.scale[n0 + clc] : 1.f;
+                const float sh = p.shift ? p.shift[n0 + clc] : 0.f;
+                const float* resb = p.res ? p.res + (int64_t)m0 * p.ldres + n0 : nullptr;
+                float* cb = p.C + (int64_t)m0 * p.ldc + n0;
+                float rv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + T::row_of(i, r);
-                    rv[r] = (cok && row < p.M) ? p.res[(int64_t)row * p.ldres + col] : 0.f;
+                    const int rl = T::row_of(i, r);
+                    const int rlc = (INTERIOR || m0 + rl < p.M) ? rl : 0;
+                    rv[r] = resb ? resb[rlc * p.ldres + clc] : 0.f;
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bi;
-                if (p.act == 1) v = xp_gelu_fast(v);
-                else if (p.act == 2) v = fmaxf(v, 0.f);
-                if (p.scale) v = v * sc + sh;
-                if (p.act == 3) v = fmaxf(v, 0.f);
-                if (p.res) v = rv[r] + v;
-                acc[i][j][r] = v;
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bi;
+                    if (ACT == 1) v = xp_gelu_fast(v);
+                    if (ACT == 2) v = fmaxf(v, 0.f);
+                    v = v * sc + sh;
+                    if (ACT == 3) v = fmaxf(v, 0.f);
+                    rv[r] = rv[r] + v;
+                }
+                if (cok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = T::row_of(i, r);
+                        if (INTERIOR || m0 + rl < p.M) cb[rl * p.ldc + cl] = rv[r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+    };
+    auto by_act = [&](auto interior_tag) {
+        switch (p.act) {
+            case 1: epilogue(std::integral_constant<int, 1>{}, interior_tag); break;
+            case 2: epilogue(std::integral_constant<int, 2>{}, interior_tag); break;
+            case 3: epilogue(std::integral_constant<int, 3>{}, interior_tag); break;
+            default: epilogue(std::integral_constant<int, 0>{}, interior_tag); break;
         }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + T::col_of(j);
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + T::row_of(i, r);
-                if (row < p.M) p.C[(int64_t)row * p.ldc + col] = acc[i][j][r];
-            }
+    };
+    if (interior) by_act(std::true_type{}); else by_act(std::false_type{});
+    if (p.stamps) {
+        st2 = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */;
         }
+    }
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -163,11 +205,32 @@ void launch(const GemmParams& p, hipStream_t s) {
     const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K,
                      4.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
-    if (p.mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, 0>), grid, dim3(T::NT), T::kLdsBytes, s, p);
-    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+    GemmParams q = p;
+    static const bool want_stamps = getenv("XP_GEMM_STAMPS") != nullptr;
+    static unsigned long long* stamp_buf = nullptr;
+    if (want_stamps) {
+        if (!stamp_buf) (void)hipMalloc(&stamp_buf, sizeof(unsigned long long) * 4 * 65536);
+        if (grid.x <= 65536) q.stamps = stamp_buf;
+    }
+    if (p.mode == 0) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, 0>), grid, dim3(T::NT), T::kLdsBytes, s, q);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), T::kLdsBytes, s, q);
+    if (q.stamps) {   // debug only: synchronises
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t)grid.x * 4);
+        (void)hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
+        double kloop = 0, epi = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (unsigned b = 0; b < grid.x; ++b) {
+            kloop += (double)(h[b * 4 + 1] - h[b * 4]); epi += (double)(h[b * 4 + 2] - h[b * 4 + 1]);
+            tmin = std::min(tmin, h[b * 4]); tmax = std::max(tmax, h[b * 4 + 2]);
+        }
+        fprintf(stderr, "[stamps] %s grid %u: prologue+K-loop %.0f cyc, epilogue %.0f cyc per workgroup; kernel span %.0f cyc (s_memtime ticks)\n",
+                tag.c_str(), grid.x, kloop / grid.x, epi / grid.x, (double)(tmax - tmin));
+    }
 }
 
-int dispatch(const GemmParams& p, hipStream_t s) {
+int dispatch(GemmParams p, hipStream_t s) {
+    static const int stagger_env = getenv("XP_GEMM_STAGGER") ? atoi(getenv("XP_GEMM_STAGGER")) : -1;
+    if (stagger_env >= 0) p.stagger_cycles = stagger_env;
     // tile choice by N (the encoder's N are 32..3072; M is large except at the last stage)
     const int N = p.N;
     if (N <= 32) launch<4, 1, 1, 1>(p, s);                                   // 128 x 32
