@@ -168,7 +168,7 @@ def main():
 
     if rank == 0:
         avg_s = dom["ms"] / max(dom["launches"], 1) * 1e-3
-        if dom["flops"] > 0 and dominant.startswith("gemm"):
+        if dom["flops"] > 0 and (dominant.startswith("gemm") or dominant.startswith("conv3x3")):
             ach = dom["flops"] / dom["launches"] / avg_s / 1e12
             roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,

@@ -49,38 +49,111 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Vectorised form for C % 4 == 0: LPR lanes (a power of two) share a row, each lane owns NV float4s, so a wave handles
+// 64/LPR rows per pass with 16-byte accesses (C = 96: two rows per wave, 24 of 32 lanes active, instead of one row on
+// 24 scalar lanes).  Same two-pass mean / variance.
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            int64_t M, int C, float eps, int gelu) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int C4 = C >> 2;
+    const bool rok = row < M;
+    const float4* xr = reinterpret_cast<const float4*>(x + (rok ? row : 0) * C);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = sub + i * LPR;
+        v[i] = (c4 < C4) ? xr[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (sub + i * LPR < C4) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q = fmaf(dx, dx, q); q = fmaf(dy, dy, q); q = fmaf(dz, dz, q); q = fmaf(dw, dw, q);
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.f / sqrtf(q / (float)C + eps);
+    if (!rok) return;
+    float4* yr = reinterpret_cast<float4*>(y + row * C);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = sub + i * LPR;
+        if (c4 < C4) {
+            const float4 wv = reinterpret_cast<const float4*>(w)[c4], bv = reinterpret_cast<const float4*>(b)[c4];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * wv.x + bv.x; o.y = (v[i].y - mean) * rstd * wv.y + bv.y;
+            o.z = (v[i].z - mean) * rstd * wv.z + bv.z; o.w = (v[i].w - mean) * rstd * wv.w + bv.w;
+            if (gelu) { o.x = xp_gelu(o.x); o.y = xp_gelu(o.y); o.z = xp_gelu(o.z); o.w = xp_gelu(o.w); }
+            yr[c4] = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Depthwise 3x3 (zero pad 1, no bias) + SiLU, NHWC.  Reference VMamba.py:655-658.
 // weight layout [9][C] (tap-major) so that a lane's 4 channels are one 16-B load.
 // ---------------------------------------------------------------------------------------------
+// Each thread produces PW = 4 horizontally adjacent pixels x 4 channels from a 3 x 6 window of float4 loads
+// (18 loads per 4 outputs instead of 36).
+constexpr int DW_PW = 4;
 __global__ __launch_bounds__(256) void dwconv3x3_silu_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, int B, int H, int W, int C) {
     const int C4 = C >> 2;
-    const int64_t total = (int64_t)B * H * W * C4;
+    const int WG = (W + DW_PW - 1) / DW_PW;
+    const int64_t total = (int64_t)B * H * WG * C4;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c4 = (int)(idx % C4);
-    const int64_t pix = idx / C4;
-    const int ww = (int)(pix % W);
-    const int hh = (int)((pix / W) % H);
-    const int64_t b = pix / ((int64_t)W * H);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t g = idx / C4;
+    const int w0 = (int)(g % WG) * DW_PW;
+    const int hh = (int)((g / WG) % H);
+    const int64_t b = g / ((int64_t)WG * H);
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    float4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = reinterpret_cast<const float4*>(w)[t * C4 + c4];
+    float4 acc[DW_PW];
+#pragma unroll
+    for (int p = 0; p < DW_PW; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = hh + kh - 1;
-        if (ih < 0 || ih >= H) continue;
+        if (ih < 0 || ih >= H) continue;          // zero padding: a skipped row adds nothing (same sum order for the rest)
+        float4 col[DW_PW + 2];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ww + kw - 1;
-            if (iw < 0 || iw >= W) continue;
-            const float4 xv = *reinterpret_cast<const float4*>(x + (((b * H + ih) * W + iw) * C4 + c4) * 4);
-            const float4 wv = *reinterpret_cast<const float4*>(w + ((kh * 3 + kw) * C4 + c4) * 4);
-            acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
-            acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+        for (int cx = 0; cx < DW_PW + 2; ++cx) {
+            const int iw = w0 + cx - 1;
+            col[cx] = (iw >= 0 && iw < W) ? xv[((b * H + ih) * W + iw) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int p = 0; p < DW_PW; ++p)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = w0 + p + kw - 1;
+                if (iw < 0 || iw >= W) continue;   // keep the reference's accumulation order: padded taps are skipped, not added as 0
+                const float4 xin = col[p + kw], wv = wt[kh * 3 + kw];
+                acc[p].x = fmaf(xin.x, wv.x, acc[p].x); acc[p].y = fmaf(xin.y, wv.y, acc[p].y);
+                acc[p].z = fmaf(xin.z, wv.z, acc[p].z); acc[p].w = fmaf(xin.w, wv.w, acc[p].w);
+            }
     }
-    acc.x = xp_silu(acc.x); acc.y = xp_silu(acc.y); acc.z = xp_silu(acc.z); acc.w = xp_silu(acc.w);
-    *reinterpret_cast<float4*>(y + idx * 4) = acc;
+#pragma unroll
+    for (int p = 0; p < DW_PW; ++p) {
+        if (w0 + p >= W) break;
+        float4 o = acc[p];
+        o.x = xp_silu(o.x); o.y = xp_silu(o.y); o.z = xp_silu(o.z); o.w = xp_silu(o.w);
+        reinterpret_cast<float4*>(y)[((b * H + hh) * W + w0 + p) * C4 + c4] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,7 +336,20 @@ extern "C" int xp_layernorm(const float* x, float* y, const float* w, const floa
     if (rows == 0) return XP_OK;
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     XpProfScope prof(by_shape ? ("layernorm_C" + std::to_string(C)).c_str() : "layernorm", (hipStream_t)stream, 8.0 * rows * C, 8.0 * rows * C);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, w, b, rows, C, eps, gelu);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
+    const int C4 = C / 4;
+#define XP_LN_LAUNCH(LPR, NV) hipLaunchKernelGGL((layernorm_vec_kernel<LPR, NV>), dim3(xp_cdiv(rows, 4 * (64 / LPR))), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu)
+    if (!vec) hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu);
+    else if (C4 <= 4) XP_LN_LAUNCH(4, 1);
+    else if (C4 <= 8) XP_LN_LAUNCH(8, 1);
+    else if (C4 <= 16) XP_LN_LAUNCH(16, 1);
+    else if (C4 <= 32) XP_LN_LAUNCH(32, 1);
+    else if (C4 <= 64) XP_LN_LAUNCH(64, 1);
+    else if (C4 <= 128) XP_LN_LAUNCH(64, 2);
+    else if (C4 <= 192) XP_LN_LAUNCH(64, 3);
+    else XP_LN_LAUNCH(64, 4);
+#undef XP_LN_LAUNCH
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -271,8 +357,8 @@ extern "C" int xp_layernorm(const float* x, float* y, const float* w, const floa
 extern "C" int xp_dwconv3x3_silu(const float* x, const float* w9c, float* y, int batch, int H, int W, int C, void* stream) {
     XP_CHECK_ARG(x && w9c && y, "xp_dwconv3x3_silu: null pointer");
     XP_CHECK_ARG(C % 4 == 0, "xp_dwconv3x3_silu: C %% 4 != 0");
-    const int64_t total = (int64_t)batch * H * W * (C / 4);
-    XpProfScope prof("dwconv3x3_silu", (hipStream_t)stream, 22.0 * total * 4, 8.0 * total * 4);
+    const int64_t total = (int64_t)batch * H * ((W + DW_PW - 1) / DW_PW) * (C / 4);
+    XpProfScope prof("dwconv3x3_silu", (hipStream_t)stream, 22.0 * batch * H * W * C, 8.0 * batch * H * W * C);
     hipLaunchKernelGGL(dwconv3x3_silu_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w9c, y, batch, H, W, C);
     XP_LAUNCH_CHECK();
     return XP_OK;

@@ -90,6 +90,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         wrow[s] = p.Wt + (int64_t)(w_ok[s] ? n : 0) * p.K;
     }
     const int kmax = p.K - 4;
+    // conv mode: (tap, ci) of each staging slot advance by one slab per call — no integer division in the K loop
+    int a_tap[T::A_LD], a_ci[T::A_LD];
+#pragma unroll
+    for (int s = 0; s < T::A_LD; ++s) {
+        const int k = T::slot_kq(s) * 4;
+        a_tap[s] = (MODE == 1) ? k / p.Ci : 0;
+        a_ci[s] = (MODE == 1) ? k - a_tap[s] * p.Ci : 0;
+    }
     auto ldA = [&](int s, int k, bool& ok) -> float4 {
         ok = a_ok[s] && k < p.K;
         const int kc = k < p.K ? k : kmax;
@@ -97,7 +105,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         if (MODE == 0) {
             v = *reinterpret_cast<const float4*>(a_ptr[s] + kc);
         } else {
-            const int tap = kc / p.Ci, ci = kc - tap * p.Ci;
+            int tap = a_tap[s], ci = a_ci[s];
+            if (k >= p.K) { tap = 8; ci = p.Ci - 4; }            // past the end: any valid address, value is zeroed
+            a_ci[s] += XP_BK;                                      // state for the next slab (calls come in slab order)
+            while (a_ci[s] >= p.Ci) { a_ci[s] -= p.Ci; ++a_tap[s]; }
             int ih = a_oh[s] + tap / 3, iw = a_ow[s] + tap % 3;
             if (p.reflect) {
                 ih = ih < 0 ? -ih : (ih >= p.Hi ? 2 * p.Hi - 2 - ih : ih);
@@ -200,8 +211,9 @@ void launch(const GemmParams& p, hipStream_t s) {
     }
     dim3 grid(xp_cdiv(p.N, T::BN) * xp_cdiv(p.M, T::BM));
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = "gemm_f32_mfma_" + std::to_string(T::BM) + "x" + std::to_string(T::BN);
-    if (by_shape) tag += (p.mode ? "_conv_M" : "_M") + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
+    // one tag per kernel instantiation (tile x mode), so the HIP-event averages line up with rocprofv3's per-kernel rows
+    std::string tag = std::string(p.mode ? "conv3x3_f32_mfma_" : "gemm_f32_mfma_") + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    if (by_shape) tag += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
     const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K,
                      4.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
@@ -235,7 +247,7 @@ int dispatch(GemmParams p, hipStream_t s) {
     const int N = p.N;
     if (N <= 32) launch<4, 1, 1, 1>(p, s);                                   // 128 x 32
     else if (N <= 64) launch<4, 1, 1, 2>(p, s);                              // 128 x 64
-    else if (N % 96 == 0 && (N / 96) % 4 != 0) launch<4, 1, 1, 3>(p, s);     // 128 x 96  (N = 96, 192)
+    else if (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) launch<4, 1, 1, 3>(p, s);   // 128 x 96  (N = 65..96, 192)
     else if (p.M <= 8192 && N >= 512) launch<2, 2, 1, 2>(p, s);              // 64 x 128: more blocks when M is small
     else launch<2, 2, 2, 2>(p, s);                                           // 128 x 128
     XP_LAUNCH_CHECK();

@@ -76,7 +76,7 @@ __device__ __forceinline__ float xp_log1p_fast(float e) {
     return l - c;
 }
 __device__ __forceinline__ float xp_softplus_fast(float x) { return x <= 20.f ? xp_log1p_fast(xp_exp_fast(x)) : x; }
-__device__ __forceinline__ float xp_silu(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float xp_silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + xp_exp_fast(-x)); }   // ~3 ulp
 __device__ __forceinline__ float xp_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 // GELU(erf) with erfc(|z|) = poly(t) * exp(-z^2), t = 1/(1 + p|z|)  (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7):
 // x >= 0: 0.5 x (2 - erfc), x < 0: 0.5 x erfc — no cancellation on the negative side.  ~20 VALU ops instead of
