@@ -48,15 +48,32 @@ __device__ __forceinline__ int pixel_of(int l, int L, int H, int W, bool colmajo
     return h * W + w;
 }
 
+// One scan step's operands for one route: xr = [dt_rank values, B, C] (R + 2 floats, 8-byte aligned in LDS; 16-byte
+// aligned when (R + 2) % 4 == 0).  Read with the widest aligned LDS loads (b128 / b64 broadcasts), not R + 2 b32 reads.
 template <int R>
 __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const float (&w)[R], float bias, float A,
-                                          float u, float& a, float& b) {
-    float dt = w[0] * xr[0];
+                                          float u, float& a, float& b, float& Cv) {
+    float xv[R + 2];
+    if constexpr ((R + 2) % 4 == 0) {
 #pragma unroll
-    for (int r = 1; r < R; ++r) dt = fmaf(w[r], xr[r], dt);
+        for (int q = 0; q < (R + 2) / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + 4 * q);
+            xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < (R + 2) / 2; ++q) {
+            const float2 t = *reinterpret_cast<const float2*>(xr + 2 * q);
+            xv[2 * q] = t.x; xv[2 * q + 1] = t.y;
+        }
+    }
+    float dt = w[0] * xv[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) dt = fmaf(w[r], xv[r], dt);
     const float delta = xp_softplus_fast(dt + bias);
     a = xp_exp_fast(delta * A);
-    b = delta * xr[R] * u;
+    b = delta * xv[R] * u;
+    Cv = xv[R + 1];
 }
 
 // Shared staging of one block's chunk(s): pixel indices and the xdbl rows of this route pair.
@@ -109,16 +126,19 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             px[k] = s_pix[cl * p.T + i0 + k];
-            uv[k] = (px[k] >= 0) ? ub[(int64_t)px[k] * p.C] : 0.f;
+            const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];     // 32-bit offsets (host checks B*L*C < 2^31)
+            uv[k] = (px[k] >= 0) ? t : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (px[k] < 0) continue;
+            // Pixels past the end of the last chunk run as u = 0 steps (their xdbl row is zero-filled): b = 0, and their
+            // decay factor only reaches states that nobody reads (forward: after the last pixel; backward: multiplied
+            // into the zero initial state), so no branch is needed.
             const float* xr = s_x + (cl * p.T + i0 + k) * XW;
-            float a, bb;
-            step_vals<R>(xr, w0, b0, A0, uv[k], a, bb);
+            float a, bb, cv;
+            step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
             S0 = a * S0 + bb; P0 *= a;
-            step_vals<R>(xr + (R + 2), w1, b1, A1, uv[k], a, bb);
+            step_vals<R>(xr + (R + 2), w1, b1, A1, uv[k], a, bb, cv);
             S1 = fmaf(Q1, bb, S1); Q1 *= a;     // backward route accumulated in forward order
         }
     }
@@ -206,17 +226,17 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_pix[cl * p.T + i0 + k];
-                uv[k] = (px[k] >= 0) ? ub[(int64_t)px[k] * p.C] : 0.f;
+                const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];
+                uv[k] = (px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (px[k] < 0) continue;
                 const int pi = cl * p.T + i0 + k;
                 const float* xr = s_x + pi * XW;
-                float a, bb;
-                step_vals<R>(xr, w0, b0, A0, uv[k], a, bb);
+                float a, bb, cv;
+                step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
                 h = a * h + bb;
-                s_y[pi * p.C + c] = xr[R + 1] * h + D0 * uv[k];   // y = C*h + D*u (csms6s.py:61,67)
+                s_y[pi * p.C + c] = cv * h + D0 * uv[k];   // y = C*h + D*u (csms6s.py:61,67); rows past the end are never read
             }
         }
         // backward route over the same pixels
@@ -229,21 +249,22 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
                 px[k] = s_pix[cl * p.T + i0 + k];
-                uv[k] = (px[k] >= 0) ? ub[(int64_t)px[k] * p.C] : 0.f;
-                if (COLPAIR) pv[k] = (px[k] >= 0) ? prev[(int64_t)px[k] * p.C] : 0.f;
+                const int po = (px[k] >= 0 ? px[k] : 0) * p.C;
+                const float t = ub[po];
+                uv[k] = (px[k] >= 0) ? t : 0.f;
+                if (COLPAIR) pv[k] = prev[po];
             }
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
-                if (px[k] < 0) continue;
                 const int pi = cl * p.T + i0 + k;
                 const float* xr = s_x + pi * XW + (R + 2);
-                float a, bb;
-                step_vals<R>(xr, w1, b1, A1, uv[k], a, bb);
-                h = a * h + bb;
-                const float y2 = xr[R + 1] * h + D1 * uv[k];
+                float a, bb, cv;
+                step_vals<R>(xr, w1, b1, A1, uv[k], a, bb, cv);
+                h = a * h + bb;                                      // u = 0 steps before the image's last pixel keep h = 0
+                const float y2 = cv * h + D1 * uv[k];
                 const float tot = s_y[pi * p.C + c] + y2;           // y_fwd + flip(y_bwd)
                 if (COLPAIR) s_y[pi * p.C + c] = pv[k] + tot;      // (y0+y2) + (y1+y3)
-                else dst[(int64_t)px[k] * p.C] = tot;
+                else if (px[k] >= 0) dst[px[k] * p.C] = tot;
             }
         }
     }
@@ -317,6 +338,7 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
     XP_CHECK_ARG(batch > 0 && H > 0 && W > 0, "xp_ss2d_core_fwd: bad shape");
     XP_CHECK_ARG(C % 32 == 0 && C >= 32 && C <= 768, "xp_ss2d_core_fwd: C must be a multiple of 32 in [32,768] (got %d)", C);
     XP_CHECK_ARG(workspace_bytes >= xp_ss2d_core_workspace_bytes(batch, H, W, C), "xp_ss2d_core_fwd: workspace too small");
+    XP_CHECK_ARG((int64_t)H * W * C < (1ll << 31), "xp_ss2d_core_fwd: one image plane (H*W*C) must stay below 2^31 elements");
     SS2DParams p;
     p.u = u; p.xdbl = xdbl; p.wdt = wdt; p.dtb = dt_bias; p.A = A; p.Dp = Ds; p.ln_w = ln_w; p.ln_b = ln_b;
     p.out = out; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
