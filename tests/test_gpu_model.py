@@ -152,3 +152,52 @@ def test_api_surface_and_errors(gpu_lib):
     assert r.missing_keys == ["encoder.patch_embed.0.bias"]
     with pytest.raises(NotImplementedError):
         models.XPoint({"use_attention": {"check": False}})
+
+
+def test_config4_1024_topk_4096_pipeline(gpu_lib):
+    """BASELINE configs[3]: 1024x1024 pair, keep_top_k = 4096 keypoints per image, dense 4k x 4k x 256 matching.
+    Size-independent properties: exactly <= 4096 keypoints sorted row-major, top-k = the k best NMS survivors, match
+    indices identical to the exact (fp64) matcher on the pipeline's own descriptors."""
+    from xpoint_amd.predict import PairPipeline
+    from xpoint_amd import utils
+    H = W = 1024
+    net = _net(synth.xpoint_exp1_config(H, W))
+    data = _data(3, 1, H, W)
+    with torch.no_grad():
+        pipe = PairPipeline(net, 1, H, W, cap=16384, cfg_prediction={"topk": 4096}, nms_sweeps=8)
+        out = pipe.run(data["optical"]["image"], data["thermal"]["image"]).fetch()[0]
+        prob = pipe.raw["prob"]
+        full = utils.box_nms(prob[0:1].unsqueeze(1), 8, 0.015)                       # all survivors (sync NMS)
+    n = len(out["kp_optical"])
+    assert 0 < n <= 4096 and len(out["kp_thermal"]) <= 4096
+    kp = out["kp_optical"]
+    lin = kp[:, 0] * W + kp[:, 1]
+    assert bool((lin[1:] > lin[:-1]).all())                                             # row-major order
+    surv = full[0, 0][full[0, 0] > 0.015]
+    if surv.numel() > 4096:
+        kth = torch.sort(surv, descending=True).values[4095]
+        kept = full[0, 0][kp[:, 0].cuda(), kp[:, 1].cuda()]
+        assert n == 4096 and float(kept.min()) >= float(kth)                            # the k best survivors
+    oms = xo.get_matches(out["desc_optical"].numpy(), out["desc_thermal"].numpy())
+    assert [(m.queryIdx, m.trainIdx) for m in oms] == list(zip(out["match_q"].tolist(), out["match_t"].tolist()))
+
+
+def test_hipgraph_replay_equals_eager(gpu_lib):
+    """BASELINE configs[4] asks for a hipGraph-captured forward: a captured PairPipeline step replays to the same
+    results as the eager step, also after the inputs are refilled in place."""
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 96, 128, 2
+    net = _net(synth.xpoint_exp1_config(H, W))
+    d0, d1 = _data(0, B, H, W), _data(9, B, H, W)
+    with torch.no_grad():
+        eager = PairPipeline(net, B, H, W, cap=2048)
+        ref1 = eager.run(d1["optical"]["image"], d1["thermal"]["image"]).fetch()
+        pipe = PairPipeline(net, B, H, W, cap=2048)
+        io, it = d0["optical"]["image"].clone(), d0["thermal"]["image"].clone()
+        replay = pipe.capture(io, it)
+        io.copy_(d1["optical"]["image"]); it.copy_(d1["thermal"]["image"])           # refill in place, replay
+        replay()
+        got = pipe.fetch()
+    for a, b in zip(got, ref1):
+        assert torch.equal(a["kp_optical"], b["kp_optical"]) and torch.equal(a["desc_thermal"], b["desc_thermal"])
+        assert a["match_q"].tolist() == b["match_q"].tolist() and a["match_t"].tolist() == b["match_t"].tolist()
