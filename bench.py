@@ -178,6 +178,17 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 3)}
+        # HBM traffic of that kernel from the committed rocprofv3 PMC run (cannot be collected from inside this process)
+        try:
+            tiles = dominant.rsplit("_", 1)[1].split("x")
+            cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2",
+                    ("128", "32"): "4, 1, 1, 1"}
+            kname = f"gemm_kernel<{cfgs[tuple(tiles)]}, {1 if dominant.startswith('conv3x3') else 0}>"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
+        except Exception:
+            pass
         roof.update({"avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom["launches"],
                      "share_of_step": round(dom["ms"] / (dt * 1e3), 4)})
         tot = sum(r["ms"] for r in breakdown)
