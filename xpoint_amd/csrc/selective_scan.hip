@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < kItems; ++i) {
             float t = dv[i] + bias;
-            dv[i] = softplus ? xp_softplus(t) : t;
+            dv[i] = softplus ? xp_softplus_fast(t) : t;
             ov[i] = Dval * uv[i];
         }
         for (int n = 0; n < N; ++n) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_kernel(
             float pa = 1.f, pb = 0.f;
 #pragma unroll
             for (int i = 0; i < kItems; ++i) {
-                float a = (i < rem) ? expf(dv[i] * An) : 1.f;   // identity past the end keeps last_state right
+                float a = (i < rem) ? xp_exp_fast(dv[i] * An) : 1.f;   // identity past the end keeps last_state right
                 float bb = (i < rem) ? dv[i] * bv[i] * uv[i] : 0.f;
                 pb = a * pb + bb;
                 pa = a * pa;
@@ -107,6 +107,74 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_kernel(
     }
 }
 
+
+// d_state == 1 (the XPoint configuration), software pipelined: the four 16-byte loads of chunk c+1 are issued before the
+// arithmetic of chunk c, so a wave always has a chunk of HBM traffic in flight behind its transcendental work.
+template <bool VEC>
+__global__ __launch_bounds__(256) void selective_scan_fwd_n1_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv,
+    const float* __restrict__ delta_bias, float* __restrict__ out, float* __restrict__ last_state,
+    int batch, int dim, int delta_dim, int L, int G, int softplus) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)batch * dim) return;
+    const int b = (int)(row / dim), d = (int)(row % dim);
+    const int g = d / (dim / G), dd = d / (dim / delta_dim);
+    const float* up = u + row * L;
+    const float* dp = delta + ((int64_t)b * delta_dim + dd) * L;
+    const float* Bp = Bm + ((int64_t)b * G + g) * L;
+    const float* Cp = Cm + ((int64_t)b * G + g) * L;
+    float* op = out + row * L;
+    const float Dval = Dv ? Dv[d] : 0.f, bias = delta_bias ? delta_bias[dd] : 0.f, An = A[d];
+    float h = 0.f;
+    float uv[kItems], dv[kItems], bv[kItems], cv[kItems];
+    auto fetch = [&](int c0) {
+        const int off = c0 + lane * kItems, rem = L - off;
+        load4<VEC>(up, off, rem, uv, 0.f); load4<VEC>(dp, off, rem, dv, 0.f);
+        load4<VEC>(Bp, off, rem, bv, 0.f); load4<VEC>(Cp, off, rem, cv, 0.f);
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < L; c0 += kChunk) {
+        const int off = c0 + lane * kItems, rem = L - off;
+        float cu[kItems], cd[kItems], cb[kItems], cc[kItems];
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) { cu[i] = uv[i]; cd[i] = dv[i]; cb[i] = bv[i]; cc[i] = cv[i]; }
+        if (c0 + kChunk < L) fetch(c0 + kChunk);           // next chunk in flight
+        float la[kItems], lb[kItems];
+        float pa = 1.f, pb = 0.f;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const float t = cd[i] + bias;
+            const float dl = softplus ? xp_softplus_fast(t) : t;
+            const float a = (i < rem) ? xp_exp_fast(dl * An) : 1.f;
+            const float bb = (i < rem) ? dl * cb[i] * cu[i] : 0.f;
+            pb = a * pb + bb; pa = a * pa;
+            la[i] = pa; lb[i] = pb;
+        }
+        float ta = pa, tb = pb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float ua = __shfl_up(ta, o, 64), ub = __shfl_up(tb, o, 64);
+            if (lane >= o) { tb = ta * ub + tb; ta = ta * ua; }
+        }
+        float ea = __shfl_up(ta, 1, 64), eb = __shfl_up(tb, 1, 64);
+        if (lane == 0) { ea = 1.f; eb = 0.f; }
+        const float hin = ea * h + eb;
+        float ov[kItems];
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) ov[i] = Dval * cu[i] + cc[i] * (la[i] * hin + lb[i]);
+        h = __shfl(ta, 63, 64) * h + __shfl(tb, 63, 64);
+        if (VEC && rem >= kItems) {
+            *reinterpret_cast<float4*>(op + off) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) if (i < rem) op[off + i] = ov[i];
+        }
+    }
+    if (last_state && lane == 0) last_state[row] = h;
+}
+
 }  // namespace
 
 extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
@@ -122,7 +190,16 @@ extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const f
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (seqlen % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)Bm | (uintptr_t)Cm | (uintptr_t)out) & 15) == 0);
-    if (vec)
+    XpProfScope prof("selective_scan_fwd", s, (9.0 * dstate + 1.0) * batch * dim * (double)seqlen,
+                     12.0 * batch * dim * (double)seqlen + 8.0 * batch * ngroups * dstate * (double)seqlen);
+    if (dstate == 1) {
+        if (vec)
+            hipLaunchKernelGGL(selective_scan_fwd_n1_kernel<true>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out, last_state,
+                               batch, dim, delta_dim, seqlen, ngroups, delta_softplus);
+        else
+            hipLaunchKernelGGL(selective_scan_fwd_n1_kernel<false>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out, last_state,
+                               batch, dim, delta_dim, seqlen, ngroups, delta_softplus);
+    } else if (vec)
         hipLaunchKernelGGL(selective_scan_fwd_kernel<true>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
                            last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
     else
