@@ -201,3 +201,39 @@ def test_hipgraph_replay_equals_eager(gpu_lib):
     for a, b in zip(got, ref1):
         assert torch.equal(a["kp_optical"], b["kp_optical"]) and torch.equal(a["desc_thermal"], b["desc_thermal"])
         assert a["match_q"].tolist() == b["match_q"].tolist() and a["match_t"].tolist() == b["match_t"].tolist()
+
+
+def test_pipeline_edge_cases(gpu_lib):
+    """Empty inputs (everything masked), capacity overflow and an under-iterated async NMS are detected, not silent."""
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 96, 128, 1
+    net = _net(synth.xpoint_exp1_config(H, W))
+    data = _data(2, B, H, W)
+    zero = torch.zeros_like(data["optical"]["valid_mask"])
+    with torch.no_grad():
+        out = PairPipeline(net, B, H, W, cap=512).run(data["optical"]["image"], data["thermal"]["image"], zero, zero).fetch()[0]
+        assert len(out["kp_optical"]) == 0 and len(out["kp_thermal"]) == 0 and len(out["match_q"]) == 0
+        half = data["thermal"]["valid_mask"].clone(); half[..., : W // 2] = False
+        out = PairPipeline(net, B, H, W, cap=512).run(data["optical"]["image"], data["thermal"]["image"], zero, half).fetch()[0]
+        assert len(out["kp_optical"]) == 0 and len(out["kp_thermal"]) > 0 and len(out["match_q"]) == 0
+        small = PairPipeline(net, B, H, W, cap=8).run(data["optical"]["image"], data["thermal"]["image"])
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="exceed capacity"):
+            small.verify()
+
+
+def test_async_nms_reports_non_convergence(gpu_lib):
+    import ctypes
+    from xpoint_amd import _lib as L
+    H, W = 64, 640
+    p = torch.zeros(1, H, W)
+    p[0, 30:34, :] = 0.5 + 0.4 * torch.arange(W) / W          # monotone ridge: needs many sweeps
+    pd = p.cuda(); out = torch.empty_like(pd)
+    lib = L.load()
+    ws = torch.empty(lib.xp_box_nms_workspace_bytes(1, H, W, 1), dtype=torch.uint8, device="cuda")
+    left = ctypes.c_int(-1)
+    L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 1, None, L.current_stream()), "nms")
+    L.check(lib.xp_box_nms_check(L.ptr(ws), 1, H, W, ctypes.byref(left), L.current_stream()), "check")
+    assert left.value > 0                                        # one sweep cannot finish a 640-long chain
+    L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 0, ctypes.byref(left), L.current_stream()), "nms")
+    assert torch.equal(out.cpu(), xo.box_nms(p.unsqueeze(1), 8, 0.015)[:, 0])      # the synchronous form iterates to the fixed point
