@@ -69,6 +69,21 @@ int xp_conv3x3_nhwc(const float* x, const float* Wt, float* y, const float* bias
                     const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
                     int act, void* stream);
 
+/* fp32-accurate variants on the bf16 matrix pipe ("x3": every f32 operand is the exact sum of three bf16
+ * values; six bf16 MFMA partial products per multiply, f32 accumulate; error below an f32 FMA chain —
+ * DESIGN.md §4).  Same semantics, epilogue and reference call sites as the two entry points above, but
+ * the weight matrix is passed pre-split: xp_split_weights_x3 converts a row-major (N, K) f32 matrix
+ * (for the conv: (Co, 3, 3, Ci) flattened, K = 9 Ci) into xp_split_weights_x3_bytes(N, K) bytes of
+ * slab-interleaved bf16 planes, once per weight upload.  K (resp. Ci) must be a multiple of 8. */
+size_t xp_split_weights_x3_bytes(int N, int K);
+int xp_split_weights_x3(const float* W, void* out, int N, int K, void* stream);
+int xp_gemm_nt_x3(const float* A, const void* Wx3, float* C, const float* bias, const float* scale,
+                  const float* shift, const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act,
+                  void* stream);
+int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* bias, const float* scale,
+                       const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
+                       int act, void* stream);
+
 /* Glue kernels (HBM-bound). */
 int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps, int gelu,
                  void* stream);
@@ -106,11 +121,19 @@ size_t xp_weights_numel(void* ctx);
 int xp_param_info(void* ctx, int index, char* name, int name_len, size_t* offset, size_t* numel);
 int xp_forward_shapes(void* ctx, int batch, int H, int W, int* Hc, int* Wc, int* enc_channels);
 size_t xp_forward_workspace_bytes(void* ctx, int batch, int H, int W);
+/* Split-bf16 copies of the GEMM / conv weights (xp_split_weights_x3 layout) for the fp32-accurate bf16-matrix-pipe
+ * kernels: a second caller-owned device buffer of xp_split_weights_bytes(ctx) bytes, derived from the f32 blob by
+ * xp_prepare_split_weights after every weight upload (the f32 blob stays the single source of truth, e.g. for the
+ * RCCL broadcast). */
+size_t xp_split_weights_bytes(void* ctx);
+int xp_prepare_split_weights(void* ctx, const float* weights, void* wsplit, size_t wsplit_bytes, void* stream);
 /* images (batch,1,H,W) in [0,1]; outputs: prob (batch,H,W) or NULL; desc_nhwc (batch,Hc,Wc,desc_size) or NULL;
- * enc_nhwc (batch,Hc,Wc,embed_dim/2) required; logits_nhwc (batch,Hc,Wc,65) or NULL. */
-int xp_xpoint_forward(void* ctx, const float* weights, const float* images, int batch, int H, int W, void* workspace,
-                      size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc, float* logits_nhwc,
-                      void* stream);
+ * enc_nhwc (batch,Hc,Wc,embed_dim/2) required; logits_nhwc (batch,Hc,Wc,65) or NULL.
+ * wsplit: the buffer prepared by xp_prepare_split_weights -> dense layers run on xp_gemm_nt_x3 / xp_conv3x3_nhwc_x3;
+ * NULL -> they run on the exact-f32 MFMA kernels (xp_gemm_nt / xp_conv3x3_nhwc).  Same results to f32 rounding. */
+int xp_xpoint_forward(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
+                      void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
+                      float* logits_nhwc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Post-processing.

@@ -71,6 +71,86 @@ def test_conv3x3(gpu_lib, B, H, W, Ci, Co, stride, reflect):
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
 
 
+# ---- split-bf16 ("x3") variants: same contracts; the 6-product split is at least as accurate as an f32 FMA chain
+def _split_x3(L, Wd):
+    N, K = Wd.shape
+    buf = torch.empty(L.load().xp_split_weights_x3_bytes(N, K), dtype=torch.uint8, device="cuda")
+    L.call("xp_split_weights_x3", L.ptr(Wd), ctypes.c_void_p(buf.data_ptr()), N, K, L.current_stream())
+    return buf
+
+
+def test_split_weights_x3_exact(gpu_lib):
+    """The three bf16 planes sum back to the f32 weight bit-for-bit; K tail is zero-padded; layout [n][slab][plane][16]."""
+    L = _lib()
+    N, K = 37, 72
+    W = _u("x3w", (N, K), -3.0, 3.0)
+    W[0, 0] = 1e-30; W[1, 1] = -123456.789; W[2, 2] = 0.0
+    buf = _split_x3(L, W.cuda())
+    nslab = (K + 15) // 16
+    planes = buf.cpu().view(torch.bfloat16).view(N, nslab, 3, 16).float()
+    rec = (planes[:, :, 0] + planes[:, :, 1] + planes[:, :, 2]).reshape(N, nslab * 16)
+    assert torch.equal(rec[:, :K], W)
+    assert float(rec[:, K:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(300, 96, 96, 0, True), (1000, 32, 96, 0, False), (517, 56, 192, 0, False),
+                                           (260, 384, 96, 1, False), (260, 96, 384, 0, True), (130, 768, 768, 0, False),
+                                           (4800, 3072, 768, 1, False), (333, 65, 256, 0, False), (200, 200, 768, 0, False),
+                                           (129, 192, 72, 0, False)])
+def test_gemm_nt_x3(gpu_lib, M, N, K, act, res):
+    L = _lib()
+    A = _u(f"A{M}{N}{K}", (M, K)); Wt = _u(f"W{M}{N}{K}", (N, K), -0.1, 0.1); bias = _u(f"b{M}{N}{K}", (N,))
+    R = _u(f"r{M}{N}{K}", (M, N)) if res else None
+    ref = F.linear(A.double(), Wt.double(), bias.double())
+    if act == 1:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), Wt.cuda(), bias.cuda()
+    Rd = R.cuda() if res else None
+    Wx = _split_x3(L, Wd)
+    C = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt_x3", L.ptr(Ad), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C), L.ptr(bd), None, None, L.ptr(Rd), M, N, K, K, N, N, act,
+           L.current_stream())
+    err = float((C.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    # and no worse than the exact-f32 MFMA kernel on the same inputs (f32 accumulation rounding dominates both)
+    C32 = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt", L.ptr(Ad), L.ptr(Wd), L.ptr(C32), L.ptr(bd), None, None, L.ptr(Rd), M, N, K, K, N, N, act, L.current_stream())
+    err32 = float((C32.cpu().double() - ref).abs().max())
+    assert err <= 2.0 * err32 + 1e-7, (err, err32)
+
+
+def test_gemm_x3_scale_shift_lda(gpu_lib):
+    L = _lib()
+    M, N, K, lda = 257, 65, 256, 512
+    A = _u("Als", (M, lda)); Wt = _u("Wls", (N, K), -0.1, 0.1); b = _u("bls", (N,)); sc = _u("scls", (N,), 0.5, 1.5); sh = _u("shls", (N,))
+    ref = F.relu(F.linear(A[:, 256:].double(), Wt.double(), b.double())) * sc.double() + sh.double()
+    Ad, Wd, bd, scd, shd = A.cuda(), Wt.cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    Wx = _split_x3(L, Wd)
+    C = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt_x3", ctypes.c_void_p(Ad.data_ptr() + 256 * 4), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C), L.ptr(bd), L.ptr(scd),
+           L.ptr(shd), None, M, N, K, lda, N, 0, 2, L.current_stream())
+    assert float((C.cpu().double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,reflect", [(2, 12, 20, 48, 96, 2, 0), (1, 15, 20, 96, 192, 2, 0), (2, 8, 12, 48, 512, 1, 1),
+                                                        (1, 9, 7, 16, 32, 2, 0), (1, 6, 5, 8, 40, 1, 0)])
+def test_conv3x3_x3(gpu_lib, B, H, W, Ci, Co, stride, reflect):
+    L = _lib()
+    x = _u(f"cx{Ci}{Co}", (B, Ci, H, W)); w = _u(f"cw{Ci}{Co}", (Co, Ci, 3, 3), -0.1, 0.1); b = _u(f"cb{Ci}{Co}", (Co,))
+    xin = F.pad(x.double(), (1, 1, 1, 1), mode="reflect") if reflect else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), stride=stride, padding=0 if reflect else 1)
+    Ho, Wo = ref.shape[2:]
+    y = torch.empty((B, Ho, Wo, Co), device="cuda")
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), b.cuda()
+    Wx = _split_x3(L, wd.view(Co, 9 * Ci))
+    L.call("xp_conv3x3_nhwc_x3", L.ptr(xd), ctypes.c_void_p(Wx.data_ptr()), L.ptr(y), L.ptr(bd), None, None, B, H, W, Ci, Co, stride, reflect, 0,
+           L.current_stream())
+    err = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
 # ------------------------------------------------------------------------------------------------ glue kernels
 @pytest.mark.parametrize("M,C", [(1000, 96), (77, 48), (50, 768), (33, 16)])
 def test_layernorm(gpu_lib, M, C):

@@ -24,11 +24,14 @@ def _data(first, B, H, W):
     return synth.to_torch(synth.make_pair_batch(first, B, H, W), "cuda")
 
 
+@pytest.mark.parametrize("gemm_mode", ["x3", "f32"])
 @pytest.mark.parametrize("tag,H,W,B,vssm", [("tiny32_64x96", 64, 96, 1, {"EMBED_DIM": 32}), ("full_64x96", 64, 96, 2, None)])
-def test_forward_vs_reference_golden(gpu_lib, golden, tag, H, W, B, vssm):
+def test_forward_vs_reference_golden(gpu_lib, golden, tag, H, W, B, vssm, gemm_mode):
+    """Both dense-layer back ends (split-bf16 on the bf16 matrix pipe = default, exact-f32 MFMA) against the reference."""
     g = golden("g345_model.npz")
     cfg = synth.xpoint_exp1_config(H, W, vssm=vssm)
     net = _net(cfg)
+    net.gemm_mode = gemm_mode
     with torch.no_grad():
         o, t, hm = net(_data(0, B, H, W))
     assert hm is None and o["logits"] is None
@@ -39,6 +42,23 @@ def test_forward_vs_reference_golden(gpu_lib, golden, tag, H, W, B, vssm):
             assert got.shape == ref.shape, (k, got.shape, ref.shape)
             err = float(np.abs(got - ref).max())
             assert err < TOL, (spec, k, err)
+
+
+def test_gemm_modes_agree_480x640(gpu_lib):
+    """Full-size forward: the split-bf16 and the exact-f32 dense layers give the same network outputs to f32 rounding
+    (both are f32-accurate; they differ only in summation order / sub-ulp truncation)."""
+    H, W = 480, 640
+    net = _net(synth.xpoint_exp1_config(H, W))
+    img = _data(0, 1, H, W)["optical"]["image"]
+    with torch.no_grad():
+        net.gemm_mode = "x3"
+        a = net.forward_raw(img, want_logits=True)
+        a = {k: v.clone() for k, v in a.items() if v is not None}
+        net.gemm_mode = "f32"
+        b = net.forward_raw(img, want_logits=True)
+    for k in ("prob", "desc_nhwc", "enc_nhwc", "logits_nhwc"):
+        err = float((a[k] - b[k]).abs().max())
+        assert err < 2e-5 * max(1.0, float(b[k].abs().max())), (k, err)
 
 
 def test_forward_224x320_and_end_to_end(gpu_lib, golden):

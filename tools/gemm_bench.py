@@ -19,8 +19,17 @@ for (M, N, K, act, res) in shapes:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
     C = torch.empty(M, N, device="cuda"); R = torch.randn(M, N, device="cuda") if res else None
     st = L.current_stream()
+    X3 = os.environ.get("GB_X3", "0") == "1"
+    if X3:
+        import ctypes
+        Wx = torch.empty(L.load().xp_split_weights_x3_bytes(N, K), dtype=torch.uint8, device="cuda")
+        L.call("xp_split_weights_x3", L.ptr(W), ctypes.c_void_p(Wx.data_ptr()), N, K, st)
+        wxp = ctypes.c_void_p(Wx.data_ptr())
     def run():
-        L.call("xp_gemm_nt", L.ptr(A), L.ptr(W), L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
+        if X3:
+            L.call("xp_gemm_nt_x3", L.ptr(A), wxp, L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
+        else:
+            L.call("xp_gemm_nt", L.ptr(A), L.ptr(W), L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -29,6 +29,9 @@ _SIGNATURES = {
     "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
     "xp_gemm_nt": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc": [c_p] * 6 + [c_i] * 8 + [c_p],
+    "xp_split_weights_x3": [c_p, c_p, c_i, c_i, c_p],
+    "xp_gemm_nt_x3": [c_p] * 7 + [c_i] * 7 + [c_p],
+    "xp_conv3x3_nhwc_x3": [c_p] * 6 + [c_i] * 8 + [c_p],
     "xp_layernorm": [c_p] * 4 + [c_l, c_i, c_f, c_i, c_p],
     "xp_dwconv3x3_silu": [c_p] * 3 + [c_i] * 4 + [c_p],
     "xp_stem_conv_ln_gelu": [c_p] * 6 + [c_i] * 4 + [c_f, c_p],
@@ -42,7 +45,8 @@ _SIGNATURES = {
     "xp_ctx_destroy": [c_p],
     "xp_param_info": [c_p, c_i, ctypes.c_char_p, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)],
     "xp_forward_shapes": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
-    "xp_xpoint_forward": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p],
+    "xp_xpoint_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p],
+    "xp_prepare_split_weights": [c_p, c_p, c_p, c_sz, c_p],
     "xp_box_nms": [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
     "xp_box_nms_check": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
     "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p],
@@ -61,6 +65,8 @@ _SIZE_QUERIES = {
     "xp_param_count": (c_i, [c_p]),
     "xp_forward_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "xp_ss2d_core_workspace_bytes": (c_sz, [c_i] * 4),
+    "xp_split_weights_x3_bytes": (c_sz, [c_i] * 2),
+    "xp_split_weights_bytes": (c_sz, [c_p]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_match_workspace_bytes": (c_sz, [c_i] * 3),
     "xp_extract_keypoints_workspace_bytes": (c_sz, [c_i] * 3),

@@ -14,25 +14,9 @@
 #include <vector>
 
 #include "gemm_core.h"
+#include "gemm_epilogue.h"
 
 namespace {
-
-struct GemmParams {
-    const float* A;
-    const float* Wt;      // (N, K) row-major
-    float* C;
-    const float* bias;    // (N) or null
-    const float* scale;   // (N) or null   (applied after the activation; eval-mode BatchNorm)
-    const float* shift;
-    const float* res;     // (M, ldres) or null
-    int M, N, K;
-    int lda, ldc, ldres;
-    int act;              // 0 none, 1 GELU(erf), 2 ReLU (before scale/shift), 3 ReLU after scale/shift
-    int mode;             // 0: plain A; 1: implicit 3x3 conv over NHWC (K order = kh, kw, ci)
-    int Hi, Wi, Ci, Ho, Wo, stride, reflect;
-    int stagger_cycles;   // start-up delay of the second workgroup slot of every CU (see gemm_kernel)
-    unsigned long long* stamps;   // debug (XP_GEMM_STAMPS): 4 s_memtime stamps per workgroup, else null
-};
 
 template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
@@ -131,64 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     T::run(lds, p.K, ldA, ldB, acc);
     if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
 
-    // Epilogue, straight-line: the activation is a compile-time tag and interior tiles skip every bounds test (per-element
-    // runtime switches made hipcc emit ~3 scalar branches per element: ~190 cycles per stored value).  Absent scale /
-    // shift / residual are the exact identities (x*1+0, +0).  Two phases so that every residual load is in flight before
-    // the first store (C may alias res: a load-add-store chain per element would serialise the L2 round trips).
-    const bool interior = (m0 + T::BM <= p.M) && (n0 + T::BN <= p.N);
-    auto epilogue = [&](auto act_tag, auto interior_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-        constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                // one 32x32 accumulator tile at a time: its 16 residual loads are in flight together, then its 16 stores
-                // (keeps the live registers at one tile; C may alias res, so loads of the next tile stay behind these stores)
-                // addresses = uniform 64-bit tile base (SGPRs) + 32-bit lane offset: no 64-bit VALU per element
-                const int cl = T::col_of(j), col = n0 + cl;
-                const bool cok = INTERIOR || col < p.N;
-                const int clc = cok ? cl : 0;
-                const float bi = p.bias ? p.bias[n0 + clc] : 0.f;
-                const float sc = p.scale ? p.scale[n0 + clc] : 1.f;
-                const float sh = p.shift ? p.shift[n0 + clc] : 0.f;
-                const float* resb = p.res ? p.res + (int64_t)m0 * p.ldres + n0 : nullptr;
-                float* cb = p.C + (int64_t)m0 * p.ldc + n0;
-                float rv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = T::row_of(i, r);
-                    const int rlc = (INTERIOR || m0 + rl < p.M) ? rl : 0;
-                    rv[r] = resb ? resb[rlc * p.ldres + clc] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bi;
-                    if (ACT == 1) v = xp_gelu_fast(v);
-                    if (ACT == 2) v = fmaxf(v, 0.f);
-                    v = v * sc + sh;
-                    if (ACT == 3) v = fmaxf(v, 0.f);
-                    rv[r] = rv[r] + v;
-                }
-                if (cok) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = T::row_of(i, r);
-                        if (INTERIOR || m0 + rl < p.M) cb[rl * p.ldc + cl] = rv[r];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    };
-    auto by_act = [&](auto interior_tag) {
-        switch (p.act) {
-            case 1: epilogue(std::integral_constant<int, 1>{}, interior_tag); break;
-            case 2: epilogue(std::integral_constant<int, 2>{}, interior_tag); break;
-            case 3: epilogue(std::integral_constant<int, 3>{}, interior_tag); break;
-            default: epilogue(std::integral_constant<int, 0>{}, interior_tag); break;
-        }
-    };
-    if (interior) by_act(std::true_type{}); else by_act(std::false_type{});
+    gemm_epilogue<T, TM, TN>(p, m0, n0, acc);
     if (p.stamps) {
         st2 = __builtin_amdgcn_s_memtime();
         if (threadIdx.x == 0) {

@@ -13,21 +13,34 @@
 namespace {
 
 struct Param { std::string name; size_t offset; size_t numel; };
+struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset; };   // a GEMM weight and its split-bf16 copy
 
 struct Ctx {
     xp_model_cfg cfg;
     int nstages;
     int dims[4], ranks[4];
     std::vector<Param> params;
-    size_t total;
+    std::vector<SplitW> split;
+    size_t total, split_bytes;
     size_t add(const std::string& n, size_t numel) {
         size_t off = total;
         params.push_back({n, off, numel});
         total += (numel + 3) / 4 * 4;   // keep every tensor 16-byte aligned inside the blob
         return off;
     }
+    // a (N, K) matrix consumed by a GEMM / 3x3 conv: also gets a slot in the split-weights buffer
+    size_t add_gemm(const std::string& n, int N, int K) {
+        const size_t off = add(n, (size_t)N * K);
+        split.push_back({n, off, N, K, split_bytes});
+        split_bytes += (xp_split_weights_x3_bytes(N, K) + 255) / 256 * 256;
+        return off;
+    }
     size_t off(const std::string& n) const {
         for (auto& p : params) if (p.name == n) return p.offset;
+        return (size_t)-1;
+    }
+    size_t split_off(const std::string& n) const {
+        for (auto& p : split) if (p.name == n) return p.byte_offset;
         return (size_t)-1;
     }
 };
@@ -36,34 +49,34 @@ int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1
 
 void build_layout(Ctx& c) {
     const int E = c.cfg.embed_dim, N = c.cfg.d_state;
-    c.total = 0;
+    c.total = 0; c.split_bytes = 0; c.split.clear();
     c.add("stem.w", 9 * (E / 2)); c.add("stem.b", E / 2); c.add("stem.ln_w", E / 2); c.add("stem.ln_b", E / 2);
-    c.add("pe2.w", (size_t)E * 9 * (E / 2)); c.add("pe2.b", E); c.add("pe2.ln_w", E); c.add("pe2.ln_b", E);
+    c.add_gemm("pe2.w", E, 9 * (E / 2)); c.add("pe2.b", E); c.add("pe2.ln_w", E); c.add("pe2.ln_b", E);
     for (int s = 0; s < c.nstages; ++s) {
         const size_t C = c.dims[s], R = c.ranks[s], H4 = (size_t)(C * c.cfg.mlp_ratio);
         for (int j = 0; j < c.cfg.depths[s]; ++j) {
             std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             c.add(b + "ln1_w", C); c.add(b + "ln1_b", C);
-            c.add(b + "in_w", C * C);
+            c.add_gemm(b + "in_w", (int)C, (int)C);
             c.add(b + "dw_w", 9 * C);
-            c.add(b + "xproj_w", 4 * (R + 2 * N) * C);
+            c.add_gemm(b + "xproj_w", (int)(4 * (R + 2 * N)), (int)C);
             c.add(b + "dt_w", 4 * C * R); c.add(b + "dt_b", 4 * C);
             c.add(b + "A", 4 * C * N); c.add(b + "D", 4 * C);
             c.add(b + "onorm_w", C); c.add(b + "onorm_b", C);
-            c.add(b + "out_w", C * C);
+            c.add_gemm(b + "out_w", (int)C, (int)C);
             c.add(b + "ln2_w", C); c.add(b + "ln2_b", C);
-            c.add(b + "fc1_w", H4 * C); c.add(b + "fc1_b", H4);
-            c.add(b + "fc2_w", C * H4); c.add(b + "fc2_b", C);
+            c.add_gemm(b + "fc1_w", (int)H4, (int)C); c.add(b + "fc1_b", H4);
+            c.add_gemm(b + "fc2_w", (int)C, (int)H4); c.add(b + "fc2_b", C);
         }
         if (s < c.nstages - 1) {
             std::string d = "s" + std::to_string(s) + ".ds.";
-            c.add(d + "w", 2 * C * 9 * C); c.add(d + "b", 2 * C); c.add(d + "ln_w", 2 * C); c.add(d + "ln_b", 2 * C);
+            c.add_gemm(d + "w", (int)(2 * C), (int)(9 * C)); c.add(d + "b", 2 * C); c.add(d + "ln_w", 2 * C); c.add(d + "ln_b", 2 * C);
         }
     }
     const size_t HC = c.cfg.head_channels, EC = E / 2, DS = c.cfg.desc_size, DET = c.cfg.det_channels;
-    c.add("head.w", 2 * HC * 9 * EC); c.add("head.b", 2 * HC); c.add("head.scale", 2 * HC); c.add("head.shift", 2 * HC);
-    c.add("det2.w", DET * HC); c.add("det2.b", DET); c.add("det2.scale", DET); c.add("det2.shift", DET);
-    c.add("desc2.w", DS * HC); c.add("desc2.b", DS); c.add("desc2.scale", DS); c.add("desc2.shift", DS);
+    c.add_gemm("head.w", (int)(2 * HC), (int)(9 * EC)); c.add("head.b", 2 * HC); c.add("head.scale", 2 * HC); c.add("head.shift", 2 * HC);
+    c.add_gemm("det2.w", (int)DET, (int)HC); c.add("det2.b", DET); c.add("det2.scale", DET); c.add("det2.shift", DET);
+    c.add_gemm("desc2.w", (int)DS, (int)HC); c.add("desc2.b", DS); c.add("desc2.scale", DS); c.add("desc2.shift", DS);
 }
 
 struct Shapes {
@@ -157,9 +170,23 @@ extern "C" size_t xp_forward_workspace_bytes(void* ctx, int batch, int H, int W)
     return plan_ws(*c, batch, s).total_floats * sizeof(float);
 }
 
+extern "C" size_t xp_split_weights_bytes(void* ctx) { return ctx ? ((Ctx*)ctx)->split_bytes : 0; }
+
 #define RUN(call) do { int rc__ = (call); if (rc__ != XP_OK) return rc__; } while (0)
 
-extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const float* images, int batch, int H, int W,
+extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* wsplit, size_t wsplit_bytes, void* stream) {
+    XP_CHECK_ARG(ctx && weights && wsplit, "xp_prepare_split_weights: null pointer");
+    Ctx* c = (Ctx*)ctx;
+    XP_CHECK_ARG(wsplit_bytes >= c->split_bytes, "xp_prepare_split_weights: buffer too small");
+    XP_CHECK_ARG(((uintptr_t)wsplit & 15) == 0, "xp_prepare_split_weights: buffer must be 16-byte aligned");
+    for (auto& e : c->split) {
+        XP_CHECK_ARG(e.K % 8 == 0, "xp_prepare_split_weights: %s has K = %d, not a multiple of 8", e.name.c_str(), e.K);
+        RUN(xp_split_weights_x3(weights + e.src_offset, (char*)wsplit + e.byte_offset, e.N, e.K, stream));
+    }
+    return XP_OK;
+}
+
+extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
                                  void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
                                  float* logits_nhwc, void* stream) {
     XP_CHECK_ARG(ctx && weights && images && workspace && enc_nhwc, "xp_xpoint_forward: null pointer");
@@ -173,12 +200,23 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const float* i
     float* ws = (float*)workspace;
     float *X = ws + wp.X, *T1 = ws + wp.T1, *T2 = ws + wp.T2, *T3 = ws + wp.T3, *HB = ws + wp.HB, *XD = ws + wp.XD, *SS = ws + wp.SS;
     auto P = [&](const std::string& n) -> const float* { return weights + c->off(n); };
+    // dense layers: the split-bf16 kernels when the caller passed split weights, else the exact-f32 MFMA kernels
+    auto gemm = [&](const float* A, const std::string& w, float* C, const float* bias, const float* scale, const float* shift,
+                    const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act) -> int {
+        if (wsplit) return xp_gemm_nt_x3(A, (const char*)wsplit + c->split_off(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
+        return xp_gemm_nt(A, P(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
+    };
+    auto conv = [&](const float* x, const std::string& w, float* y, const float* bias, const float* scale, const float* shift,
+                    int Hi, int Wi, int Ci, int Co, int stride, int reflect, int act) -> int {
+        if (wsplit) return xp_conv3x3_nhwc_x3(x, (const char*)wsplit + c->split_off(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
+        return xp_conv3x3_nhwc(x, P(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
+    };
     const float eps = 1e-5f;
     const int E = c->cfg.embed_dim;
 
     // patch embed (VMamba.py:1405-1420)
     RUN(xp_stem_conv_ln_gelu(images, P("stem.w"), P("stem.b"), P("stem.ln_w"), P("stem.ln_b"), HB, batch, H, W, E / 2, eps, stream));
-    RUN(xp_conv3x3_nhwc(HB, P("pe2.w"), T1, P("pe2.b"), nullptr, nullptr, batch, sh.Hs, sh.Ws, E / 2, E, 2, 0, 0, stream));
+    RUN(conv(HB, "pe2.w", T1, P("pe2.b"), nullptr, nullptr, sh.Hs, sh.Ws, E / 2, E, 2, 0, 0));
     RUN(xp_layernorm(T1, X, P("pe2.ln_w"), P("pe2.ln_b"), sh.M[0], E, eps, 0, stream));
 
     for (int s = 0; s < c->nstages; ++s) {
@@ -189,20 +227,20 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const float* i
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
             RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
-            RUN(xp_gemm_nt(T1, P(b + "in_w"), T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0, stream));
+            RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
             RUN(xp_dwconv3x3_silu(T2, P(b + "dw_w"), T3, batch, sh.H[s], sh.W[s], C, stream));
-            RUN(xp_gemm_nt(T3, P(b + "xproj_w"), XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0, stream));
+            RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
             RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
                                  T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
-            RUN(xp_gemm_nt(T1, P(b + "out_w"), X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0, stream));
+            RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
             // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
             RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
-            RUN(xp_gemm_nt(T1, P(b + "fc1_w"), HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1, stream));
-            RUN(xp_gemm_nt(HB, P(b + "fc2_w"), X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0, stream));
+            RUN(gemm(T1, b + "fc1_w", HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
+            RUN(gemm(HB, b + "fc2_w", X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));
         }
         if (s < c->nstages - 1) {   // downsample v3 (VMamba.py:1432-1440)
             const std::string d = "s" + std::to_string(s) + ".ds.";
-            RUN(xp_conv3x3_nhwc(X, P(d + "w"), T1, P(d + "b"), nullptr, nullptr, batch, sh.H[s], sh.W[s], C, 2 * C, 2, 0, 0, stream));
+            RUN(conv(X, d + "w", T1, P(d + "b"), nullptr, nullptr, sh.H[s], sh.W[s], C, 2 * C, 2, 0, 0));
             RUN(xp_layernorm(T1, X, P(d + "ln_w"), P(d + "ln_b"), sh.M[s + 1], 2 * C, eps, 0, stream));
         }
     }
@@ -213,15 +251,15 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const float* i
     const int EC = c->dims[L] / 16, HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
     const int Mc = batch * sh.Hc * sh.Wc;
     if (prob || logits_nhwc || desc_nhwc) {
-        RUN(xp_conv3x3_nhwc(enc_nhwc, P("head.w"), HB, P("head.b"), P("head.scale"), P("head.shift"), batch, sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2, stream));
+        RUN(conv(enc_nhwc, "head.w", HB, P("head.b"), P("head.scale"), P("head.shift"), sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2));
     }
     if (prob || logits_nhwc) {
         float* lg = logits_nhwc ? logits_nhwc : T2;
-        RUN(xp_gemm_nt(HB, P("det2.w"), lg, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0, stream));
+        RUN(gemm(HB, "det2.w", lg, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0));
         if (prob) RUN(xp_softmax_shuffle(lg, prob, batch, sh.Hc, sh.Wc, 8, DET, 0, stream));
     }
     if (desc_nhwc) {
-        RUN(xp_gemm_nt(HB + HC, P("desc2.w"), T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0, stream));
+        RUN(gemm(HB + HC, "desc2.w", T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0));
         RUN(xp_l2norm_rows(T1, desc_nhwc, Mc, DS, 1e-12f, stream));
     }
     return XP_OK;

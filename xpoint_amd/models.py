@@ -11,6 +11,7 @@ from __future__ import annotations
 import collections
 import copy
 import ctypes
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -65,6 +66,9 @@ class XPoint(torch.nn.Module):
             assert self.config['takes_pair'], "RegNet can only be used with takes_pair=True"       # XPoint.py:103
         self._ref_state: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
         self._blob: Optional[torch.Tensor] = None        # device-format weights (one float32 tensor)
+        self._wsplit: Optional[torch.Tensor] = None      # split-bf16 copies of the GEMM weights, derived from _blob on the device
+        # "x3": dense layers on the bf16 matrix pipe with split operands (fp32-accurate); "f32": exact-f32 MFMA kernels
+        self.gemm_mode = os.environ.get("XP_GEMM_MODE", "x3")
         self._device = torch.device("cpu")
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._conv_impl = None
@@ -155,6 +159,7 @@ class XPoint(torch.nn.Module):
                 t = torch.from_numpy(np.array(t, copy=True)) if isinstance(t, np.ndarray) else t
                 self._ref_state[k] = t.detach().to("cpu").clone()
         self._blob = None
+        self._wsplit = None
         self._conv_impl = None
         self._regnet_w = None
         return _LoadResult(missing, unexpected)
@@ -235,6 +240,7 @@ class XPoint(torch.nn.Module):
         """Adopt an already packed device blob (e.g. received by RCCL broadcast)."""
         assert blob.is_cuda and blob.dtype == torch.float32 and blob.numel() == self.weights_numel()
         self._blob = blob.contiguous()
+        self._wsplit = None
         self._device = blob.device
 
     def to(self, device=None, *a, **k):
@@ -242,6 +248,7 @@ class XPoint(torch.nn.Module):
             self._device = torch.device(device)
             if self._blob is not None and self._blob.device != self._device:
                 self._blob = self._blob.to(self._device)
+                self._wsplit = None
         return self
 
     def cuda(self, device=None):
@@ -279,8 +286,17 @@ class XPoint(torch.nn.Module):
             return self._conv_impl.forward_raw(images, want_logits=want_logits)
         if self._blob is None or self._blob.device != dev:
             self._blob = self.pack_weights().to(dev)
+            self._wsplit = None
         n, _, H, W = images.shape
         lib = _lib.load()
+        if self.gemm_mode not in ("x3", "f32"):
+            raise RuntimeError(f"XPoint.gemm_mode must be 'x3' or 'f32', got {self.gemm_mode!r}")
+        if self.gemm_mode == "x3" and self._wsplit is None:
+            nb = lib.xp_split_weights_bytes(self._ctx)
+            self._wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.xp_prepare_split_weights(self._ctx, ptr(self._blob), ptr(self._wsplit), ctypes.c_size_t(nb),
+                                                    _lib.current_stream()), "xp_prepare_split_weights")
+        wsplit = ptr(self._wsplit) if self.gemm_mode == "x3" else None
         Hc = c_i(); Wc = c_i(); Ce = c_i()
         _lib.check(lib.xp_forward_shapes(self._ctx, n, H, W, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)), "xp_forward_shapes")
         Hc, Wc, Ce = Hc.value, Wc.value, Ce.value
@@ -289,7 +305,7 @@ class XPoint(torch.nn.Module):
         out["prob"] = torch.empty((n, H, W), device=dev) if want_prob else None
         out["desc_nhwc"] = torch.empty((n, Hc, Wc, self._cfg.desc_size), device=dev) if want_desc else None
         out["logits_nhwc"] = torch.empty((n, Hc, Wc, 65), device=dev) if want_logits else None
-        _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(self._blob), ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
+        _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(self._blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                          ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
                                          _lib.current_stream()), "xp_xpoint_forward")
         return out
