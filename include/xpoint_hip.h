@@ -74,7 +74,7 @@ int xp_conv3x3_nhwc(const float* x, const float* Wt, float* y, const float* bias
  * DESIGN.md §4).  Same semantics, epilogue and reference call sites as the two entry points above, but
  * the weight matrix is passed pre-split: xp_split_weights_x3 converts a row-major (N, K) f32 matrix
  * (for the conv: (Co, 3, 3, Ci) flattened, K = 9 Ci) into xp_split_weights_x3_bytes(N, K) bytes of
- * slab-interleaved bf16 planes, once per weight upload.  K (resp. Ci) must be a multiple of 8. */
+ * slab-major bf16 planes, once per weight upload.  K, lda (resp. Ci) multiples of 4, as above. */
 size_t xp_split_weights_x3_bytes(int N, int K);
 int xp_split_weights_x3(const float* W, void* out, int N, int K, void* stream);
 int xp_gemm_nt_x3(const float* A, const void* Wx3, float* C, const float* bias, const float* scale,

@@ -80,15 +80,15 @@ def _split_x3(L, Wd):
 
 
 def test_split_weights_x3_exact(gpu_lib):
-    """The three bf16 planes sum back to the f32 weight bit-for-bit; K tail is zero-padded; layout [n][slab][plane][16]."""
+    """The three bf16 planes sum back to the f32 weight bit-for-bit; K tail is zero-padded; layout [slab][n][plane][16]."""
     L = _lib()
     N, K = 37, 72
     W = _u("x3w", (N, K), -3.0, 3.0)
     W[0, 0] = 1e-30; W[1, 1] = -123456.789; W[2, 2] = 0.0
     buf = _split_x3(L, W.cuda())
     nslab = (K + 15) // 16
-    planes = buf.cpu().view(torch.bfloat16).view(N, nslab, 3, 16).float()
-    rec = (planes[:, :, 0] + planes[:, :, 1] + planes[:, :, 2]).reshape(N, nslab * 16)
+    planes = buf.cpu().view(torch.bfloat16).view(nslab, N, 3, 16).float()
+    rec = (planes[:, :, 0] + planes[:, :, 1] + planes[:, :, 2]).permute(1, 0, 2).reshape(N, nslab * 16)
     assert torch.equal(rec[:, :K], W)
     assert float(rec[:, K:].abs().max()) == 0.0
 
@@ -96,7 +96,7 @@ def test_split_weights_x3_exact(gpu_lib):
 @pytest.mark.parametrize("M,N,K,act,res", [(300, 96, 96, 0, True), (1000, 32, 96, 0, False), (517, 56, 192, 0, False),
                                            (260, 384, 96, 1, False), (260, 96, 384, 0, True), (130, 768, 768, 0, False),
                                            (4800, 3072, 768, 1, False), (333, 65, 256, 0, False), (200, 200, 768, 0, False),
-                                           (129, 192, 72, 0, False)])
+                                           (129, 192, 72, 0, False), (70, 40, 20, 0, False)])
 def test_gemm_nt_x3(gpu_lib, M, N, K, act, res):
     L = _lib()
     A = _u(f"A{M}{N}{K}", (M, K)); Wt = _u(f"W{M}{N}{K}", (N, K), -0.1, 0.1); bias = _u(f"b{M}{N}{K}", (N,))
@@ -135,7 +135,7 @@ def test_gemm_x3_scale_shift_lda(gpu_lib):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride,reflect", [(2, 12, 20, 48, 96, 2, 0), (1, 15, 20, 96, 192, 2, 0), (2, 8, 12, 48, 512, 1, 1),
-                                                        (1, 9, 7, 16, 32, 2, 0), (1, 6, 5, 8, 40, 1, 0)])
+                                                        (1, 9, 7, 16, 32, 2, 0), (1, 6, 5, 8, 40, 1, 0), (1, 6, 5, 4, 24, 1, 1)])
 def test_conv3x3_x3(gpu_lib, B, H, W, Ci, Co, stride, reflect):
     L = _lib()
     x = _u(f"cx{Ci}{Co}", (B, Ci, H, W)); w = _u(f"cw{Ci}{Co}", (Co, Ci, 3, 3), -0.1, 0.1); b = _u(f"cb{Ci}{Co}", (Co,))

@@ -10,6 +10,7 @@ shapes = [  # (M, N, K, act, res)
     (4800, 768, 768, 0, 0), (4800, 3072, 768, 1, 0), (4800, 768, 3072, 0, 1),
     (76800, 65, 256, 0, 0), (76800, 256, 256, 0, 0),
     (19200, 96, 96, 0, 0), (65536, 96, 96, 0, 0),
+    (10240, 384, 1536, 0, 0),   # 20: 240 workgroups of 128x128 = one per CU: the single-workgroup K-loop timeline
 ]
 import os
 if os.environ.get('GB_ONLY'):

@@ -5,6 +5,9 @@
 
 #include "xp_common.h"
 
+#ifndef XP_EPI_DBG
+#define XP_EPI_DBG 0   /* timing experiment: 1 = compute the epilogue but store (almost) nothing */
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmParams {
@@ -67,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int m0, int n
                     if (ACT == 3) v = fmaxf(v, 0.f);
                     rv[r] = rv[r] + v;
                 }
-                if (cok) {
+                if (cok && !(XP_EPI_DBG && rv[0] != 12345.678f)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rl = T::row_of(i, r);

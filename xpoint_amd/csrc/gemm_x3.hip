@@ -4,8 +4,8 @@
 //
 //   C[m, n] = epilogue( sum_k A'[m, k] * W[n, k] )     A' = A (row-major M x K, f32) or im2col(NHWC f32 image)
 //   W is given pre-split: xp_split_weights_x3 turns the (N, K) f32 matrix into
-//       Wx3[n][slab = k / 16][plane 0..2][16] bf16      (K zero-padded to a multiple of 16)
-//   once per weight upload; each (row, slab) is 96 contiguous bytes.
+//       Wx3[slab = k / 16][n][plane 0..2][16] bf16      (K zero-padded to a multiple of 16)
+//   once per weight upload: slab-major, so the BN rows a workgroup needs for one slab are BN * 96 contiguous bytes.
 #include <stdlib.h>
 
 #include <string>
@@ -27,7 +27,7 @@ __global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restr
     for (int j = 0; j < 8; ++j) v[j] = (k + j < K) ? W[(int64_t)n * K + k + j] : 0.f;
     uint4 p0, p1, p2;
     xp_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
-    uint4* o = out + ns * X3_SLAB_UNITS + oct;
+    uint4* o = out + ((int64_t)slab * N + n) * X3_SLAB_UNITS + oct;
     o[0] = p0; o[2] = p1; o[4] = p2;
 }
 
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
             const int b = mc / hw, rr = mc - b * hw;
             a_oh[s] = (rr / p.Wo) * p.stride - 1; a_ow[s] = (rr % p.Wo) * p.stride - 1;
             a_ptr[s] = p.A + (int64_t)b * p.Hi * p.Wi * p.Ci;
-            const int k = T::a_oct(s) * 8;       // (tap, ci) advance by one slab per call: no division in the K loop
+            const int k = T::a_quad(s) * 4;      // (tap, ci) advance by one slab per call: no division in the K loop
             a_tap[s] = k / p.Ci; a_ci[s] = k - a_tap[s] * p.Ci;
         }
     }
@@ -66,20 +66,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
 #pragma unroll
     for (int s = 0; s < T::B_LD; ++s) {
         const int n = n0 + T::b_row(s);
-        w_unit[s] = reinterpret_cast<const uint4*>(p.Wt) + (int64_t)(n < p.N ? n : 0) * nslab * X3_SLAB_UNITS + T::b_unit(s);
+        w_unit[s] = reinterpret_cast<const uint4*>(p.Wt) + (int64_t)(n < p.N ? n : 0) * X3_SLAB_UNITS + T::b_unit(s);
     }
-    const int kmax = p.K - 8;
-    auto ldA = [&](int s, int k, float4& lo, float4& hi) -> bool {
+    const int kmax = p.K - 4;
+    const int64_t w_slab = (int64_t)p.N * X3_SLAB_UNITS;     // 16-byte units per slab of the whole weight matrix
+    auto ldA = [&](int s, int k, float4& v) -> bool {
         bool ok = k < p.K;
         const float* src;
         if (MODE == 0) {
             src = a_ptr[s] + (ok ? k : kmax);
         } else {
             int tap = a_tap[s], ci = a_ci[s];
-            if (!ok) { tap = 8; ci = p.Ci - 8; }
-            a_ci[s] += X3_BK;                              // Ci >= 8: at most two wraps per 16-wide slab, as selects
+            if (!ok) { tap = 8; ci = p.Ci - 4; }
+            a_ci[s] += X3_BK;                              // Ci >= 4: at most four wraps per 16-wide slab, as selects
 #pragma unroll
-            for (int w = 0; w < 2; ++w) { const bool wrap = a_ci[s] >= p.Ci; a_ci[s] -= wrap ? p.Ci : 0; a_tap[s] += wrap ? 1 : 0; }
+            for (int w = 0; w < 4; ++w) { const bool wrap = a_ci[s] >= p.Ci; a_ci[s] -= wrap ? p.Ci : 0; a_tap[s] += wrap ? 1 : 0; }
             int ih = a_oh[s] + tap / 3, iw = a_ow[s] + tap % 3;
             if (p.reflect) {
                 ih = ih < 0 ? -ih : (ih >= p.Hi ? 2 * p.Hi - 2 - ih : ih);
@@ -91,11 +92,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
             }
             src = a_ptr[s] + ((int64_t)ih * p.Wi + iw) * p.Ci + ci;
         }
-        lo = *reinterpret_cast<const float4*>(src);
-        hi = *reinterpret_cast<const float4*>(src + 4);
+        v = *reinterpret_cast<const float4*>(src);
         return ok;
     };
-    auto ldB = [&](int s, int t) -> uint4 { return w_unit[s][(t < nslab ? t : nslab - 1) * X3_SLAB_UNITS]; };
+    auto ldB = [&](int s, int t) -> uint4 { return w_unit[s][(t < nslab ? t : nslab - 1) * w_slab]; };
 
     f32x16 acc[TM][TN];
     T::run(lds_x3, p.K, ldA, ldB, acc);
@@ -160,7 +160,7 @@ extern "C" int xp_gemm_nt_x3(const float* A, const void* Wx3, float* C, const fl
                              int act, void* stream) {
     XP_CHECK_ARG(A && Wx3 && C, "xp_gemm_nt_x3: null pointer");
     XP_CHECK_ARG(M > 0 && N > 0 && K > 0, "xp_gemm_nt_x3: bad shape %d %d %d", M, N, K);
-    XP_CHECK_ARG(K % 8 == 0 && lda % 4 == 0, "xp_gemm_nt_x3: K must be a multiple of 8 and lda of 4 (got %d, %d)", K, lda);
+    XP_CHECK_ARG(K % 4 == 0 && lda % 4 == 0, "xp_gemm_nt_x3: K and lda must be multiples of 4 (got %d, %d)", K, lda);
     XP_CHECK_ARG((scale == nullptr) == (shift == nullptr), "xp_gemm_nt_x3: scale and shift go together");
     XP_CHECK_ARG(act >= 0 && act <= 3, "xp_gemm_nt_x3: bad act %d", act);
     GemmParams p{};
@@ -173,7 +173,7 @@ extern "C" int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, con
                                   const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride,
                                   int reflect_pad, int act, void* stream) {
     XP_CHECK_ARG(x && Wx3 && y, "xp_conv3x3_nhwc_x3: null pointer");
-    XP_CHECK_ARG(Ci % 8 == 0, "xp_conv3x3_nhwc_x3: Ci must be a multiple of 8 (got %d)", Ci);
+    XP_CHECK_ARG(Ci % 4 == 0, "xp_conv3x3_nhwc_x3: Ci must be a multiple of 4 (got %d)", Ci);
     XP_CHECK_ARG(stride == 1 || stride == 2, "xp_conv3x3_nhwc_x3: stride 1 or 2");
     XP_CHECK_ARG((scale == nullptr) == (shift == nullptr), "xp_conv3x3_nhwc_x3: scale and shift go together");
     XP_CHECK_ARG(!reflect_pad || (Hi >= 2 && Wi >= 2), "xp_conv3x3_nhwc_x3: reflection pad needs H,W >= 2");

@@ -180,7 +180,7 @@ extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* w
     XP_CHECK_ARG(wsplit_bytes >= c->split_bytes, "xp_prepare_split_weights: buffer too small");
     XP_CHECK_ARG(((uintptr_t)wsplit & 15) == 0, "xp_prepare_split_weights: buffer must be 16-byte aligned");
     for (auto& e : c->split) {
-        XP_CHECK_ARG(e.K % 8 == 0, "xp_prepare_split_weights: %s has K = %d, not a multiple of 8", e.name.c_str(), e.K);
+        XP_CHECK_ARG(e.K % 4 == 0, "xp_prepare_split_weights: %s has K = %d, not a multiple of 4", e.name.c_str(), e.K);
         RUN(xp_split_weights_x3(weights + e.src_offset, (char*)wsplit + e.byte_offset, e.N, e.K, stream));
     }
     return XP_OK;
