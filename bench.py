@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (roofline events are then taken in a separate eager pass)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (images uploaded from pinned host memory every step); never the headline value")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the bounded CPU-baseline sample")
+    ap.add_argument("--no-other-backend", action="store_true", help="skip the extra timing pass on the other dense-layer back end (keeps profiler output to one back end)")
     ap.add_argument("--gemm", choices=["x3", "f32"], default=os.environ.get("XP_GEMM_MODE", "x3"),
                     help="dense-layer back end: x3 = f32-accurate split-bf16 on the bf16 matrix pipe (default), f32 = exact-f32 MFMA")
     return ap.parse_args()
@@ -154,7 +155,7 @@ def main():
         # the same step on the other dense-layer back end, for the record (never the headline value)
         other = "f32" if args.gemm == "x3" else "x3"
         other_rate = None
-        if not args.graph:
+        if not args.graph and not args.no_other_backend:
             net.gemm_mode = other
             for _ in range(2):
                 pipe.run(opt, thr, mo, mt)

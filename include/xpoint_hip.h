@@ -166,7 +166,7 @@ int xp_sample_descriptors(const int* kp, const int* counts, const float* desc_nh
  * mode 0 = strict mutual nearest neighbour (primary), 1 = legacy cross-check.  Outputs: idx12/dist12 (pairs,cap1),
  * idx21/dist21 (pairs,cap2), matches (pairs,cap1) as (queryIdx, trainIdx, distance) ascending in queryIdx,
  * match_count (pairs). */
-size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2);
+size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2, int D);
 int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs,
                  int cap1, int cap2, int D, int mode, int* idx12, float* dist12, int* idx21, float* dist21,
                  int* match_q, int* match_t, float* match_d, int* match_count, void* workspace, size_t workspace_bytes,

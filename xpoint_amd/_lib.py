@@ -68,7 +68,7 @@ _SIZE_QUERIES = {
     "xp_split_weights_x3_bytes": (c_sz, [c_i] * 2),
     "xp_split_weights_bytes": (c_sz, [c_p]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
-    "xp_match_workspace_bytes": (c_sz, [c_i] * 3),
+    "xp_match_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_extract_keypoints_workspace_bytes": (c_sz, [c_i] * 3),
 }
 

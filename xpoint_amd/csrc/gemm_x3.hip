@@ -127,6 +127,18 @@ void launch(const GemmParams& p, hipStream_t s) {
 
 int dispatch(const GemmParams& p, hipStream_t s) {
     const int N = p.N;
+    static const int force = getenv("XP_X3_TILE") ? atoi(getenv("XP_X3_TILE")) : -1;   // tuning experiments only
+    if (force >= 0) {
+        switch (force) {
+            case 0: launch<4, 1, 1, 1>(p, s); break;
+            case 1: launch<4, 1, 1, 2>(p, s); break;
+            case 2: launch<4, 1, 1, 3>(p, s); break;
+            case 3: launch<2, 2, 1, 2>(p, s); break;
+            default: launch<2, 2, 2, 2>(p, s); break;
+        }
+        XP_LAUNCH_CHECK();
+        return XP_OK;
+    }
     if (N <= 32) launch<4, 1, 1, 1>(p, s);                                   // 128 x 32
     else if (N <= 64) launch<4, 1, 1, 2>(p, s);                              // 128 x 64
     else if (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) launch<4, 1, 1, 3>(p, s);   // 128 x 96  (N = 65..96, 192)

@@ -231,6 +231,87 @@ struct GemmTileX3 {
         if (t < nslab) { step(t, std::integral_constant<int, 0>{}); step(t + 1, std::integral_constant<int, 1>{}); }
     }
 
+    // Both operands already split (xp_split_weights_x3 layout): staging is a straight copy for A as well — no VALU at all.
+    // ldAu(slot, slab) / ldBu(slot, slab) -> the slot's 16-byte unit.  Used by the descriptor matcher (match.hip), whose
+    // two operands are split once per image by its prepare kernel.
+    static constexpr int AU_TOT = BM * X3_SLAB_UNITS, AU_LD = (AU_TOT + NT - 1) / NT;
+    __device__ static __forceinline__ int au_id(int s) { const int id = (int)threadIdx.x + s * NT; return (s + 1) * NT <= AU_TOT ? id : (id < AU_TOT ? id : AU_TOT - 1); }
+    __device__ static __forceinline__ int au_row(int s) { return au_id(s) / X3_SLAB_UNITS; }
+    __device__ static __forceinline__ int au_unit(int s) { return au_id(s) % X3_SLAB_UNITS; }
+    template <class LA, class LB>
+    __device__ static __forceinline__ void run_presplit(unsigned char* lds, int K, LA ldAu, LB ldBu, f32x16 (&acc)[TM][TN]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int fr = lane & 31, fh = lane >> 5;
+        struct RawAu { uint4 a[AU_LD]; };
+        int a_dst[AU_LD], b_dst[B_LD];
+#pragma unroll
+        for (int s = 0; s < AU_LD; ++s) a_dst[s] = lds_row(au_row(s)) * X3_ROWB + au_unit(s) * 16;
+#pragma unroll
+        for (int s = 0; s < B_LD; ++s) b_dst[s] = BM * X3_ROWB + b_row(s) * X3_ROWB + b_unit(s) * 16;
+        const int a_frag = lds_row(wm * TM * 32 + fr) * X3_ROWB + 16 * fh;
+        const int b_frag = BM * X3_ROWB + (wn * TN * 32 + fr) * X3_ROWB + 16 * fh;
+        bf16x8 af[3][TM], bf[3][TN];
+        auto gload = [&](RawAu& ra, RawB& rb, int t) {
+#pragma unroll
+            for (int s = 0; s < AU_LD; ++s) ra.a[s] = ldAu(s, t);
+#pragma unroll
+            for (int s = 0; s < B_LD; ++s) rb.b[s] = ldBu(s, t);
+        };
+        auto lstore = [&](const RawAu& ra, const RawB& rb, unsigned char* buf) {
+#pragma unroll
+            for (int s = 0; s < AU_LD; ++s) *reinterpret_cast<uint4*>(buf + a_dst[s]) = ra.a[s];
+#pragma unroll
+            for (int s = 0; s < B_LD; ++s) *reinterpret_cast<uint4*>(buf + b_dst[s]) = rb.b[s];
+        };
+        auto frags = [&](const unsigned char* buf) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_frag + pl * 32 + i * 32 * X3_ROWB);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(buf + b_frag + pl * 32 + j * 32 * X3_ROWB);
+            }
+        };
+        auto mfmas = [&](int pp0, int pp1) {
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int pp = pp0; pp < pp1; ++pp)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pp]][i], bf[PB[pp]][j], acc[i][j], 0, 0, 0);
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        unsigned char* bufs[2] = {lds, lds + kBufBytes};
+        const int nslab = ((K + X3_BK - 1) / X3_BK + 1) & ~1;       // callers pad K to a multiple of 32 (zero planes)
+        RawAu ra[2]; RawB rb[2];
+        gload(ra[0], rb[0], 0);
+        gload(ra[1], rb[1], 1);
+        lstore(ra[0], rb[0], bufs[0]);
+        gload(ra[0], rb[0], 2);
+        xp_lds_barrier();
+        auto step = [&](int t, auto u_tag) {
+            constexpr int U = decltype(u_tag)::value;          // t % 2
+            frags(bufs[U]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(ra[U ^ 1], rb[U ^ 1], bufs[U ^ 1]);       // slab t+1, loaded during slab t-2
+            __builtin_amdgcn_sched_barrier(0);
+            gload(ra[U ^ 1], rb[U ^ 1], t + 3);
+            mfmas(2, 6);
+            xp_lds_barrier();
+        };
+        for (int t = 0; t < nslab; t += 2) { step(t, std::integral_constant<int, 0>{}); step(t + 1, std::integral_constant<int, 1>{}); }
+    }
+
     // element (i, j, r) of this lane's accumulators is C[row_of(i, r)][col_of(j)] within the tile
     __device__ static __forceinline__ int row_of(int i, int r) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -3,7 +3,9 @@
 // reference xpoint/utils/matching.py:4-36 (and the in-repo NNMatcher, matching.py:38-75).
 //
 // CDNA4 mapping.  d2[q,t] = |a_q|^2 + |b_t|^2 - 2 a_q.b_t : the N1 x 256 . 256 x N2 contraction runs on
-// the fp32 MFMA tile engine (gemm_core.h, 128x128 tiles), the row/column minima are reduced with wave
+// the split-bf16 tile engine (gemm_x3_core.h: fp32-accurate products on the bf16 matrix pipe, 128x128
+// tiles; the prepare kernel writes both descriptor sets as bf16 planes once per image, so the tile
+// kernel stages both operands with straight 16-byte copies), the row/column minima are reduced with wave
 // shuffles inside the tile and merged across tiles with one 64-bit atomicMin per row/column and tile
 // (key = float bits of d2 << 32 | index, so equal distances resolve to the smallest index = first
 // minimum, independent of scheduling).
@@ -15,7 +17,7 @@
 // minimum, because the running minimum only decreases.  A second kernel re-evaluates the nominated
 // pairs in direct form with fp64 accumulation and picks the exact first minimum.  The result is the
 // exact-arithmetic mutual nearest neighbour; it does not depend on fp32 rounding or tile order.
-#include "gemm_core.h"
+#include "gemm_x3_core.h"
 
 namespace {
 
@@ -27,6 +29,8 @@ struct MatchParams {
     const int* n1p; const int* n2p;               // device counts per pair (may be null -> n1max/n2max)
     int which1, which2;                           // index into counts for this pair layout (see host)
     int cap1, cap2, D;
+    const uint4* p1; const uint4* p2;             // descriptors as bf16 planes: [pair][slab][row][plane][16] (xp_split_weights_x3 layout)
+    int nslab;                                    // 16-wide slabs per descriptor (D padded to a multiple of 32)
     float* na; float* nb;                         // norms^2 (pairs, cap)
     unsigned long long* rowkey; unsigned long long* colkey;   // (pairs, cap)
     int* rcnt; int* ccnt; int* rcand; int* ccand; // candidate lists (pairs, cap[, CAND_CAP])
@@ -36,7 +40,8 @@ __device__ __forceinline__ int count_of(const int* p, int idx, int cap) { int n 
 
 __global__ __launch_bounds__(256) void match_prepare_kernel(const float* __restrict__ d, const int* __restrict__ cnt, int cnt_stride,
                                                             int cnt_off, int cap, int D, float* __restrict__ nrm,
-                                                            unsigned long long* __restrict__ key, int* __restrict__ ccount) {
+                                                            unsigned long long* __restrict__ key, int* __restrict__ ccount,
+                                                            uint2* __restrict__ planes, int nslab) {
     const int pair = blockIdx.y;
     const int n = count_of(cnt, pair * cnt_stride + cnt_off, cap);
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -49,6 +54,15 @@ __global__ __launch_bounds__(256) void match_prepare_kernel(const float* __restr
         for (int c = lane; c < D; c += 64) s = fmaf(r[c], r[c], s);
         s = xp_wave_sum(s);
         if (lane == 0) nrm[o] = s;
+        // the row as three bf16 planes (exact split), slab-major so that a tile's slab is one contiguous run
+        for (int q = lane; q < nslab * 4; q += 64) {
+            const int k = q * 4;
+            const float4 v = k < D ? *reinterpret_cast<const float4*>(r + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 p0, p1, p2;
+            xp_split4(v, p0, p1, p2);
+            uint2* dst = planes + ((((int64_t)pair * nslab + (q >> 2)) * cap + i) * X3_SLAB_UNITS) * 2 + (q & 3);   // 8-byte units
+            dst[0] = p0; dst[4] = p1; dst[8] = p2;
+        }
     }
     if (lane == 0) { key[o] = ~0ull; ccount[o] = 0; }
 }
@@ -59,7 +73,7 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, int idx) {
 
 // One 128x128 tile of the distance matrix of one pair.
 __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_stride) {
-    using T = GemmTile<2, 2, 2, 2>;
+    using T = GemmTileX3<2, 2, 2, 2>;
     extern __shared__ __align__(16) float lds[];
     __shared__ unsigned long long s_col[T::BN];
     const int pair = blockIdx.z;
@@ -67,20 +81,25 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
     const int n2 = count_of(p.n2p, pair * cnt_stride + p.which2, p.cap2);
     const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
     if (m0 >= n1 || n0 >= n2) return;
-    const float* A = p.d1 + (int64_t)pair * p.cap1 * p.D;
-    const float* B = p.d2 + (int64_t)pair * p.cap2 * p.D;
-    const float* arow[T::A_LD]; const float* brow[T::B_LD];
-    bool aok[T::A_LD], bok[T::B_LD];
+    // rows past n1 / n2 are clamped to row 0: they only feed distances that are overwritten with +inf below
+    const uint4* a_unit[T::AU_LD]; const uint4* b_unit[T::B_LD];
 #pragma unroll
-    for (int s = 0; s < T::A_LD; ++s) { const int m = m0 + T::slot_row(s); aok[s] = m < n1; arow[s] = A + (int64_t)(aok[s] ? m : 0) * p.D; }
+    for (int s = 0; s < T::AU_LD; ++s) {
+        const int m = m0 + T::au_row(s);
+        a_unit[s] = p.p1 + ((int64_t)pair * p.nslab * p.cap1 + (m < n1 ? m : 0)) * X3_SLAB_UNITS + T::au_unit(s);
+    }
 #pragma unroll
-    for (int s = 0; s < T::B_LD; ++s) { const int n = n0 + T::slot_row(s); bok[s] = n < n2; brow[s] = B + (int64_t)(bok[s] ? n : 0) * p.D; }
-    const int kmax = p.D - 4;
-    auto ldA = [&](int s, int k, bool& ok) -> float4 { ok = aok[s] && k < p.D; return *reinterpret_cast<const float4*>(arow[s] + (k < p.D ? k : kmax)); };
-    auto ldB = [&](int s, int k, bool& ok) -> float4 { ok = bok[s] && k < p.D; return *reinterpret_cast<const float4*>(brow[s] + (k < p.D ? k : kmax)); };
+    for (int s = 0; s < T::B_LD; ++s) {
+        const int n = n0 + T::b_row(s);
+        b_unit[s] = p.p2 + ((int64_t)pair * p.nslab * p.cap2 + (n < n2 ? n : 0)) * X3_SLAB_UNITS + T::b_unit(s);
+    }
+    const int64_t a_slab = (int64_t)p.cap1 * X3_SLAB_UNITS, b_slab = (int64_t)p.cap2 * X3_SLAB_UNITS;
+    const int last = p.nslab - 1;
+    auto ldA = [&](int s, int t) -> uint4 { return a_unit[s][(t < last ? t : last) * a_slab]; };
+    auto ldB = [&](int s, int t) -> uint4 { return b_unit[s][(t < last ? t : last) * b_slab]; };
     for (int i = threadIdx.x; i < T::BN; i += 256) s_col[i] = ~0ull;
     f32x16 acc[2][2];
-    T::run(lds, p.D, ldA, ldB, acc);   // ends with a barrier, so s_row/s_col init is visible
+    T::run_presplit(reinterpret_cast<unsigned char*>(lds), p.nslab * X3_BK, ldA, ldB, acc);   // ends with a barrier, so the s_col init is visible
 
     const float* na = p.na + (int64_t)pair * p.cap1;
     const float* nb = p.nb + (int64_t)pair * p.cap2;
@@ -268,10 +287,13 @@ __global__ __launch_bounds__(1024) void match_mutual_kernel(const int* __restric
 
 }  // namespace
 
-extern "C" size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2) {
+static int match_nslab(int D) { return ((D + X3_BK - 1) / X3_BK + 1) & ~1; }   // even number of 16-wide slabs
+
+extern "C" size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2, int D) {
     const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
-    // na, nb (f32) | rowkey, colkey, scratch (u64) | rcnt, ccnt | rcand, ccand
-    return 4 * (a + b) + 8 * (a + b + a) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 256;
+    // rowkey, colkey, scratch (u64) | na, nb (f32) | rcnt, ccnt | rcand, ccand | bf16 planes of both descriptor sets
+    return 8 * (a + b + a) + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 512 +
+           (a + b) * (size_t)match_nslab(D) * X3_SLAB_UNITS * 16;
 }
 
 // d1 (pairs, cap1, D), d2 (pairs, cap2, D); counts: device int array, n1 of pair i at counts[i*cnt_stride + which1]
@@ -285,7 +307,8 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
                  "xp_match_mnn: null pointer");
     XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D % 4 == 0, "xp_match_mnn: bad shape (D must be a multiple of 4)");
     XP_CHECK_ARG(mode == 0 || mode == 1, "xp_match_mnn: mode 0 (strict_mnn) or 1 (legacy_crosscheck)");
-    XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2), "xp_match_mnn: workspace too small");
+    XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2, D), "xp_match_mnn: workspace too small");
+    XP_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "xp_match_mnn: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
     char* w = (char*)workspace;
@@ -300,18 +323,24 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     p.rcnt = (int*)w; w += 4 * a;
     p.ccnt = (int*)w; w += 4 * b;
     p.rcand = (int*)w; w += 4 * CAND_CAP * a;
-    p.ccand = (int*)w;
+    p.ccand = (int*)w; w += 4 * CAND_CAP * b;
+    w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    p.nslab = match_nslab(D);
+    uint4* planes1 = (uint4*)w; w += a * (size_t)p.nslab * X3_SLAB_UNITS * 16;
+    uint4* planes2 = (uint4*)w;
+    p.p1 = planes1; p.p2 = planes2;
     XpProfScope prof("match_mnn", s, 0.0, 0.0);   // work depends on device-side counts: bench.py prices it from the fetched counts
-    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, counts, cnt_stride, which1, cap1, D, p.na, p.rowkey, p.rcnt);
-    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, counts, cnt_stride, which2, cap2, D, p.nb, p.colkey, p.ccnt);
-    using T = GemmTile<2, 2, 2, 2>;
+    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, counts, cnt_stride, which1, cap1, D, p.na, p.rowkey, p.rcnt, (uint2*)planes1, p.nslab);
+    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, counts, cnt_stride, which2, cap2, D, p.nb, p.colkey, p.ccnt, (uint2*)planes2, p.nslab);
+    using T = GemmTileX3<2, 2, 2, 2>;
+    constexpr size_t kTileLds = T::kLdsBytes > sizeof(float) * T::BM * 136 ? T::kLdsBytes : sizeof(float) * T::BM * 136;   // K-loop buffers, then the [128][136] distance tile
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
         attr_set = true;
     }
     dim3 grid(xp_cdiv(cap2, T::BN), xp_cdiv(cap1, T::BM), pairs);
-    hipLaunchKernelGGL(match_tile_kernel, grid, dim3(256), T::kLdsBytes, s, p, cnt_stride);
+    hipLaunchKernelGGL(match_tile_kernel, grid, dim3(256), kTileLds, s, p, cnt_stride);
     hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
                        cap1, cap2, D, p.rcnt, p.rcand, idx12, dist12);
     hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, d1, counts, counts, cnt_stride, which2, which1,

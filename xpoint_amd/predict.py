@@ -106,7 +106,7 @@ class PairPipeline:
                       match_q=torch.empty((P, self.cap), dtype=torch.int32, device=dev),
                       match_t=torch.empty((P, self.cap), dtype=torch.int32, device=dev),
                       match_d=torch.empty((P, self.cap), device=dev), match_count=torch.zeros((P,), dtype=torch.int32, device=dev))
-        self.match_ws = torch.empty(lib.xp_match_workspace_bytes(P, self.cap, self.cap), dtype=torch.uint8, device=dev)
+        self.match_ws = torch.empty(lib.xp_match_workspace_bytes(P, self.cap, self.cap, D), dtype=torch.uint8, device=dev)
         self.raw = None
 
     def run(self, optical, thermal, mask_optical=None, mask_thermal=None):

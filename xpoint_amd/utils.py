@@ -147,7 +147,7 @@ def match_descriptors(d1, d2, counts=None, mode="strict_mnn"):
                idx21=torch.empty((P, cap2), dtype=torch.int32, device=dev), dist21=torch.empty((P, cap2), device=dev),
                match_q=torch.empty((P, cap1), dtype=torch.int32, device=dev), match_t=torch.empty((P, cap1), dtype=torch.int32, device=dev),
                match_d=torch.empty((P, cap1), device=dev), match_count=torch.zeros((P,), dtype=torch.int32, device=dev))
-    ws = torch.empty(lib.xp_match_workspace_bytes(P, cap1, cap2), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.xp_match_workspace_bytes(P, cap1, cap2, D), dtype=torch.uint8, device=dev)
     d1, d2 = d1.contiguous(), d2.contiguous()
     _lib.check(lib.xp_match_mnn(ptr(d1), ptr(d2), ptr(counts), 1, 0, P, P, cap1, cap2, D, MATCH_MODES[mode],
                                 ptr(res["idx12"]), ptr(res["dist12"]), ptr(res["idx21"]), ptr(res["dist21"]), ptr(res["match_q"]),
