@@ -97,16 +97,36 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
     const int last = p.nslab - 1;
     auto ldA = [&](int s, int t) -> uint4 { return a_unit[s][(t < last ? t : last) * a_slab]; };
     auto ldB = [&](int s, int t) -> uint4 { return b_unit[s][(t < last ? t : last) * b_slab]; };
+    // squared norms of the tile's rows / columns (0 for rows past the counts) and their maxima, staged once: the
+    // nomination passes below test 2 x 64 values per thread against thresholds that depend on them
+    __shared__ float s_na[T::BM], s_nb[T::BN];
+    __shared__ float s_max[2];
+    const float* na = p.na + (int64_t)pair * p.cap1;
+    const float* nb = p.nb + (int64_t)pair * p.cap2;
+    if (threadIdx.x < 2) s_max[threadIdx.x] = 0.f;
     for (int i = threadIdx.x; i < T::BN; i += 256) s_col[i] = ~0ull;
+    __syncthreads();
+    if (threadIdx.x < T::BM) {
+        const int row = m0 + threadIdx.x;
+        const float v = row < n1 ? na[row] : 0.f;
+        s_na[threadIdx.x] = v;
+        const float mx = xp_wave_max(v);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(&s_max[0]), __float_as_int(mx));   // norms are >= 0: int order = float order
+    } else {
+        const int cl = threadIdx.x - T::BM, col = n0 + cl;
+        const float v = col < n2 ? nb[col] : 0.f;
+        s_nb[cl] = v;
+        const float mx = xp_wave_max(v);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(&s_max[1]), __float_as_int(mx));
+    }
     f32x16 acc[2][2];
     T::run_presplit(reinterpret_cast<unsigned char*>(lds), p.nslab * X3_BK, ldA, ldB, acc);   // ends with a barrier, so the s_col init is visible
 
-    const float* na = p.na + (int64_t)pair * p.cap1;
-    const float* nb = p.nb + (int64_t)pair * p.cap2;
     const int lane = threadIdx.x & 63;
+    const float na_max = s_max[0], nb_max = s_max[1];
     float nbv[2]; int colg[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { colg[j] = n0 + T::col_of(j); nbv[j] = colg[j] < n2 ? nb[colg[j]] : 0.f; }
+    for (int j = 0; j < 2; ++j) { colg[j] = n0 + T::col_of(j); nbv[j] = s_nb[T::col_of(j)]; }
     // distances in place; invalid entries -> +inf.  The K-loop's LDS is free now: the tile is also written there
     // ([128][TS] floats) so that ROW minima become in-lane scans (the MFMA layout keeps a row spread over 32 lanes,
     // a column in one lane's registers).
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = T::row_of(i, r), row = m0 + rl;
-            const float nav = row < n1 ? na[row] : 0.f;
+            const float nav = s_na[rl];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float d = fmaxf(nav + nbv[j] - 2.f * acc[i][j][r], 0.f);
@@ -170,15 +190,17 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
         run = __shfl(run, lane & ~1, 64);
         if (row < n1) {
             const float rmin = __uint_as_float((unsigned int)(run >> 32));
-            const float nav = na[row];
+            const float nav = s_na[rl];
+            const float loose = rmin + MATCH_EPS * (nav + nb_max + 1e-30f);     // >= every per-column threshold of this tile
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const float4 v = *reinterpret_cast<const float4*>(trow + 8 * m);
+                if (!(v.x <= loose || v.y <= loose || v.z <= loose || v.w <= loose)) continue;   // almost always
                 const float dv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c = n0 + 8 * m + 4 * hf + e;
-                    if (c < n2 && dv[e] <= rmin + MATCH_EPS * (nav + nb[c] + 1e-30f)) {
+                    const int cl = 8 * m + 4 * hf + e, c = n0 + cl;
+                    if (c < n2 && dv[e] <= rmin + MATCH_EPS * (nav + s_nb[cl] + 1e-30f)) {
                         const int pos = atomicAdd(&rcnt[row], 1);
                         if (pos < CAND_CAP) rcand[(int64_t)row * CAND_CAP + pos] = c;
                     }
@@ -194,13 +216,15 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
     for (int j = 0; j < 2; ++j) {
         if (colg[j] >= n2) continue;
         const float cmin = __uint_as_float((unsigned int)(s_col[T::col_of(j)] >> 32));
+        const float loose = cmin + MATCH_EPS * (na_max + nbv[j] + 1e-30f);      // >= every per-row threshold of this tile
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + T::row_of(i, r);
+                if (!(acc[i][j][r] <= loose)) continue;                          // almost always (invalid rows hold +inf)
+                const int rl = T::row_of(i, r), row = m0 + rl;
                 if (row >= n1) continue;
-                if (acc[i][j][r] <= cmin + MATCH_EPS * (na[row] + nbv[j] + 1e-30f)) {
+                if (acc[i][j][r] <= cmin + MATCH_EPS * (s_na[rl] + nbv[j] + 1e-30f)) {
                     const int pos = atomicAdd(&ccnt[colg[j]], 1);
                     if (pos < CAND_CAP) ccand[(int64_t)colg[j] * CAND_CAP + pos] = row;
                 }
