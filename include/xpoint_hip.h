@@ -47,7 +47,7 @@ int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, co
 /* Fused SS2D core in pixel layout = cross_scan + dt_proj + selective_scan + cross_merge + out_norm of
  * xpoint/models/vmamba_src/VMamba.py:601-646 (forward_corev2) with csm_triton.py:22-85 (cross scan/merge).
  *   u (batch, H, W, C) = SiLU(dwconv(in_proj(x)));  xdbl (batch*H*W, 4*(R+2)) = u @ x_proj^T with the four
- *   directions stored in the order (0, 2, 1, 3), each [dt_rank values, B, C];  wdt (4, C, R), dt_bias (4, C),
+ *   directions stored in the order (0, 2, 1, 3), each [dt_rank values, B, C];  wdt (4, R, C) (= dt_projs_weight transposed: channel-contiguous), dt_bias (4, C),
  *   A (4, C) = -exp(A_logs), Ds (4, C) in the same direction order;  ln_w/ln_b = out_norm;  out (batch, H, W, C).
  *   d_state must be 1 (the XPoint config; general d_state: xp_selective_scan_fwd). */
 size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C);

@@ -243,7 +243,7 @@ def test_ss2d_core_vs_oracle(gpu_lib, B, C, H, W):
     out = torch.empty((B, H, W, C), device="cuda")
     nbytes = L.load().xp_ss2d_core_workspace_bytes(B, H, W, C)
     ws = torch.empty(nbytes // 4 + 4, device="cuda")
-    dtw = sd[pre + "dt_projs_weight"][order].contiguous().cuda(); dtb = sd[pre + "dt_projs_bias"][order].contiguous().cuda()
+    dtw = sd[pre + "dt_projs_weight"][order].permute(0, 2, 1).contiguous().cuda(); dtb = sd[pre + "dt_projs_bias"][order].contiguous().cuda()
     Dd = sd[pre + "Ds"].view(4, C)[order].contiguous().cuda()
     lnw, lnb = sd[pre + "out_norm.weight"].cuda(), sd[pre + "out_norm.bias"].cuda()
     L.call("xp_ss2d_core_fwd", L.ptr(u), L.ptr(xdbl), L.ptr(dtw), L.ptr(dtb), L.ptr(A), L.ptr(Dd), L.ptr(lnw), L.ptr(lnb), L.ptr(out),

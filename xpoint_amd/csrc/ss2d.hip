@@ -27,7 +27,7 @@ namespace {
 struct SS2DParams {
     const float* u;      // (B, H, W, C)   after dwconv + SiLU
     const float* xdbl;   // (B*H*W, 4*(R+2))  [pair][dir][dtr(R), B, C]
-    const float* wdt;    // (4, C, R)  order (0,2,1,3)
+    const float* wdt;    // (4, R, C)  directions in the order (0,2,1,3); channel-contiguous so that a wave's weight loads coalesce
     const float* dtb;    // (4, C)
     const float* A;      // (4, C)    = -exp(A_logs)
     const float* Dp;     // (4, C)
@@ -110,37 +110,75 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     const int chunk = chunk0 + cl;
     if (chunk >= p.nc) return;
     const int L = p.H * p.W;
-    float w0[R], w1[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * p.C + c) * R + r];
-        w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * p.C + c) * R + r];
-    }
-    const float b0 = p.dtb[(pair * 2 + 0) * p.C + c], b1 = p.dtb[(pair * 2 + 1) * p.C + c];
-    const float A0 = p.A[(pair * 2 + 0) * p.C + c], A1 = p.A[(pair * 2 + 1) * p.C + c];
     const float* ub = p.u + (int64_t)b * L * p.C + c;
     float P0 = 1.f, S0 = 0.f, Q1 = 1.f, S1 = 0.f;
-    for (int i0 = 0; i0 < p.T; i0 += 4) {
-        float uv[4];
-        int px[4];
+    if constexpr (R < 16) {
+        // small dt_rank (the wide, HBM-bound stages): both routes in one sweep over u
+        float w0[R], w1[R];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            px[k] = s_pix[cl * p.T + i0 + k];
-            const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];     // 32-bit offsets (host checks B*L*C < 2^31)
-            uv[k] = (px[k] >= 0) ? t : 0.f;
+        for (int r = 0; r < R; ++r) {
+            w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
+            w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
         }
+        const float b0 = p.dtb[(pair * 2 + 0) * p.C + c], b1 = p.dtb[(pair * 2 + 1) * p.C + c];
+        const float A0 = p.A[(pair * 2 + 0) * p.C + c], A1 = p.A[(pair * 2 + 1) * p.C + c];
+        for (int i0 = 0; i0 < p.T; i0 += 4) {
+            float uv[4];
+            int px[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // Pixels past the end of the last chunk run as u = 0 steps (their xdbl row is zero-filled): b = 0, and their
-            // decay factor only reaches states that nobody reads (forward: after the last pixel; backward: multiplied
-            // into the zero initial state), so no branch is needed.
-            const float* xr = s_x + (cl * p.T + i0 + k) * XW;
-            float a, bb, cv;
-            step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
-            S0 = a * S0 + bb; P0 *= a;
-            step_vals<R>(xr + (R + 2), w1, b1, A1, uv[k], a, bb, cv);
-            S1 = fmaf(Q1, bb, S1); Q1 *= a;     // backward route accumulated in forward order
+            for (int k = 0; k < 4; ++k) {
+                px[k] = s_pix[cl * p.T + i0 + k];
+                const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];     // 32-bit offsets (host checks B*L*C < 2^31)
+                uv[k] = (px[k] >= 0) ? t : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // Pixels past the end of the last chunk run as u = 0 steps (their xdbl row is zero-filled): b = 0, and their
+                // decay factor only reaches states that nobody reads (forward: after the last pixel; backward: multiplied
+                // into the zero initial state), so no branch is needed.
+                const float* xr = s_x + (cl * p.T + i0 + k) * XW;
+                float a, bb, cv;
+                step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
+                S0 = a * S0 + bb; P0 *= a;
+                step_vals<R>(xr + (R + 2), w1, b1, A1, uv[k], a, bb, cv);
+                S1 = fmaf(Q1, bb, S1); Q1 *= a;     // backward route accumulated in forward order
+            }
         }
+    } else {
+    // large dt_rank: the two routes run one after the other so that only one route's R projection weights are live at a time: with
+    // both (2R = 96 registers at C = 768) a 768-thread workgroup fills the CU's register file by itself and every
+    // load latency is exposed.  u is re-read for the second route (L1 / L2 hits; these stages are small).
+#pragma unroll 1
+    for (int route = 0; route < 2; ++route) {
+        float w[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] = p.wdt[((int64_t)(pair * 2 + route) * R + r) * p.C + c];
+        const float bias = p.dtb[(pair * 2 + route) * p.C + c], Av = p.A[(pair * 2 + route) * p.C + c];
+        float Pr = 1.f, Sr = 0.f;
+        for (int i0 = 0; i0 < p.T; i0 += 4) {
+            float uv[4];
+            int px[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                px[k] = s_pix[cl * p.T + i0 + k];
+                const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];     // 32-bit offsets (host checks B*L*C < 2^31)
+                uv[k] = (px[k] >= 0) ? t : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // Pixels past the end of the last chunk run as u = 0 steps (their xdbl row is zero-filled): b = 0, and their
+                // decay factor only reaches states that nobody reads (forward: after the last pixel; backward: multiplied
+                // into the zero initial state), so no branch is needed.
+                const float* xr = s_x + (cl * p.T + i0 + k) * XW + route * (R + 2);
+                float a, bb, cv;
+                step_vals<R>(xr, w, bias, Av, uv[k], a, bb, cv);
+                if (route == 0) Sr = a * Sr + bb;
+                else Sr = fmaf(Pr, bb, Sr);                 // backward route accumulated in forward order
+                Pr *= a;
+            }
+        }
+        if (route == 0) { P0 = Pr; S0 = Sr; } else { Q1 = Pr; S1 = Sr; }
+    }
     }
     const int64_t o = ((((int64_t)b * 2 + pair) * p.nc + chunk) * 2) * p.C + c;
     p.wsP[o] = P0; p.wsS[o] = S0;
@@ -207,15 +245,13 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     const int chunk = chunk0 + cl;
     const int L = p.H * p.W;
     if (chunk < p.nc) {
-        float w0[R], w1[R];
+        // one route's projection weights live at a time (see pass 1)
+        float w0[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * p.C + c) * R + r];
-            w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * p.C + c) * R + r];
-        }
-        const float b0 = p.dtb[(pair * 2 + 0) * p.C + c], b1 = p.dtb[(pair * 2 + 1) * p.C + c];
-        const float A0 = p.A[(pair * 2 + 0) * p.C + c], A1 = p.A[(pair * 2 + 1) * p.C + c];
-        const float D0 = p.Dp[(pair * 2 + 0) * p.C + c], D1 = p.Dp[(pair * 2 + 1) * p.C + c];
+        for (int r = 0; r < R; ++r) w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
+        const float b0 = p.dtb[(pair * 2 + 0) * p.C + c];
+        const float A0 = p.A[(pair * 2 + 0) * p.C + c];
+        const float D0 = p.Dp[(pair * 2 + 0) * p.C + c];
         const float* ub = p.u + (int64_t)b * L * p.C + c;
         const int64_t o = ((((int64_t)b * 2 + pair) * p.nc + chunk) * 2) * p.C + c;
         float h = p.wsS[o];
@@ -240,6 +276,13 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
             }
         }
         // backward route over the same pixels
+        asm volatile("" ::: "memory");      // keep the second route's weight loads below the forward loop
+        float w1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
+        const float b1 = p.dtb[(pair * 2 + 1) * p.C + c];
+        const float A1 = p.A[(pair * 2 + 1) * p.C + c];
+        const float D1 = p.Dp[(pair * 2 + 1) * p.C + c];
         h = p.wsS[o + p.C];
         const float* prev = COLPAIR ? (p.ya + (int64_t)b * L * p.C + c) : nullptr;
         float* dst = COLPAIR ? nullptr : (p.ya + (int64_t)b * L * p.C + c);

@@ -196,7 +196,7 @@ class XPoint(torch.nn.Module):
                 out[d + "in_w"] = s[r + "op.in_proj.weight"]
                 out[d + "dw_w"] = s[r + "op.conv2d.weight"].reshape(C, 9).t()
                 out[d + "xproj_w"] = s[r + "op.x_proj_weight"][_DIR_ORDER]
-                out[d + "dt_w"] = s[r + "op.dt_projs_weight"][_DIR_ORDER]
+                out[d + "dt_w"] = s[r + "op.dt_projs_weight"][_DIR_ORDER].permute(0, 2, 1)          # (4, R, C): channel-contiguous for the scan kernels
                 out[d + "dt_b"] = s[r + "op.dt_projs_bias"][_DIR_ORDER]
                 out[d + "A"] = (-torch.exp(s[r + "op.A_logs"].float())).view(4, C, -1)[_DIR_ORDER]      # VMamba.py:619
                 out[d + "D"] = s[r + "op.Ds"].view(4, C)[_DIR_ORDER]
