@@ -223,6 +223,36 @@ def test_hipgraph_replay_equals_eager(gpu_lib):
         assert a["match_q"].tolist() == b["match_q"].tolist() and a["match_t"].tolist() == b["match_t"].tolist()
 
 
+@pytest.mark.parametrize("split", [0, 2, 4])
+def test_overlapped_pipeline_equals_single_stream(gpu_lib, split):
+    """overlap=True (two streams, encoder of call i+1 behind the detection / matching of call i, double-buffered encoder
+    outputs) returns exactly the single-stream results: a sequence of calls with different inputs, the caller reusing
+    its input tensors right after run() returns, masks included; also with the encoder split into image groups on
+    several streams."""
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 96, 128, 2
+    net = _net(synth.xpoint_exp1_config(H, W))
+    seq = [_data(s, B, H, W) for s in (0, 5, 9, 3)]
+    with torch.no_grad():
+        single = PairPipeline(net, B, H, W, cap=2048)
+        refs = []
+        for d in seq:
+            refs.append(single.run(d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"]).fetch())
+        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=True, split_encoder=split)
+        io, it = torch.empty_like(seq[0]["optical"]["image"]), torch.empty_like(seq[0]["thermal"]["image"])
+        mo, mt = torch.empty_like(seq[0]["optical"]["valid_mask"]), torch.empty_like(seq[0]["thermal"]["valid_mask"])
+        for n_calls in (1, 2, 3, 4):
+            for d in seq[:n_calls]:          # back-to-back calls, inputs refilled in place without synchronising
+                io.copy_(d["optical"]["image"]); it.copy_(d["thermal"]["image"])
+                mo.copy_(d["optical"]["valid_mask"]); mt.copy_(d["thermal"]["valid_mask"])
+                pipe.run(io, it, mo, mt)
+            got = pipe.fetch()               # results of the LAST call
+            for a, b in zip(got, refs[n_calls - 1]):
+                assert torch.equal(a["kp_optical"], b["kp_optical"]) and torch.equal(a["kp_thermal"], b["kp_thermal"])
+                assert torch.equal(a["desc_optical"], b["desc_optical"]) and torch.equal(a["desc_thermal"], b["desc_thermal"])
+                assert a["match_q"].tolist() == b["match_q"].tolist() and a["match_t"].tolist() == b["match_t"].tolist()
+
+
 def test_pipeline_edge_cases(gpu_lib):
     """Empty inputs (everything masked), capacity overflow and an under-iterated async NMS are detected, not silent."""
     from xpoint_amd.predict import PairPipeline

@@ -265,9 +265,16 @@ class XPoint(torch.nn.Module):
             self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws[key]
 
-    def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False):
+    def workspace_bytes(self, n_img, H, W) -> int:
+        return int(_lib.load().xp_forward_workspace_bytes(self._ctx, n_img, H, W))
+
+    def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None):
         """images (N,1,H,W) float32 on the GPU -> dict of NHWC device tensors (no layout exports):
-        prob (N,H,W), desc_nhwc (N,Hc,Wc,D), enc_nhwc (N,Hc,Wc,E/2), logits_nhwc (N,Hc,Wc,65)."""
+        prob (N,H,W), desc_nhwc (N,Hc,Wc,D), enc_nhwc (N,Hc,Wc,E/2), logits_nhwc (N,Hc,Wc,65).
+        out: a dict returned by an earlier call with the same shapes -> its tensors are overwritten instead of
+        allocating new ones (VMamba branch; lets a caller double-buffer the outputs across streams).
+        workspace: a uint8 device tensor of workspace_bytes(N, H, W) bytes owned by the caller (concurrent calls on
+        different streams need one each); default: the model's own cached workspace."""
         if not images.is_cuda:
             raise RuntimeError("xpoint_amd.XPoint runs on the GPU only (no CPU fallback): move the data to 'cuda'")
         if self.training:
@@ -300,11 +307,15 @@ class XPoint(torch.nn.Module):
         Hc = c_i(); Wc = c_i(); Ce = c_i()
         _lib.check(lib.xp_forward_shapes(self._ctx, n, H, W, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)), "xp_forward_shapes")
         Hc, Wc, Ce = Hc.value, Wc.value, Ce.value
-        ws = self._workspace(n, H, W, dev)
-        out = {"enc_nhwc": torch.empty((n, Hc, Wc, Ce), device=dev)}
-        out["prob"] = torch.empty((n, H, W), device=dev) if want_prob else None
-        out["desc_nhwc"] = torch.empty((n, Hc, Wc, self._cfg.desc_size), device=dev) if want_desc else None
-        out["logits_nhwc"] = torch.empty((n, Hc, Wc, 65), device=dev) if want_logits else None
+        ws = self._workspace(n, H, W, dev) if workspace is None else workspace
+        if out is None:
+            out = {"enc_nhwc": torch.empty((n, Hc, Wc, Ce), device=dev)}
+            out["prob"] = torch.empty((n, H, W), device=dev) if want_prob else None
+            out["desc_nhwc"] = torch.empty((n, Hc, Wc, self._cfg.desc_size), device=dev) if want_desc else None
+            out["logits_nhwc"] = torch.empty((n, Hc, Wc, 65), device=dev) if want_logits else None
+        elif tuple(out["enc_nhwc"].shape) != (n, Hc, Wc, Ce) or (want_prob and out.get("prob") is None) or \
+                (want_desc and out.get("desc_nhwc") is None) or (want_logits and out.get("logits_nhwc") is None):
+            raise RuntimeError("forward_raw(out=...): buffers do not match this call")
         _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(self._blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                          ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
                                          _lib.current_stream()), "xp_xpoint_forward")

@@ -82,17 +82,41 @@ class PairPipeline:
     keypoint extraction, descriptor sampling, mutual-NN matching.  Results stay on the GPU; `fetch()`
     synchronises, checks NMS convergence / capacity and returns host lists."""
 
-    def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=6):
+    def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=6, overlap=False,
+                 split_encoder=False):
+        """overlap=True: two HIP streams — the encoder of call i+1 runs while the detection / matching kernels of call i
+        (many small, latency-bound launches) are still in flight; encoder outputs are double-buffered.  Results of a
+        call are complete after fetch() / torch.cuda.synchronize(), exactly as without overlap."""
         self.net, self.B, self.H, self.W, self.cap = net, int(batch), int(H), int(W), int(cap)
+        self.overlap = bool(overlap)
+        # split_encoder = S > 1: the 2B images go through the encoder as S groups on S streams (images are independent),
+        # so the kernels of different groups fill each other's tails and latency-bound phases
+        self.split_encoder = (int(split_encoder) if self.overlap else 0)
+        if self.split_encoder in (0, 1) or (2 * self.B) % max(self.split_encoder, 1):
+            self.split_encoder = 0
+        self._call = 0
         self.pred = _cfg(cfg_prediction)
         self.mode = match_mode
         self.sweeps = int(nms_sweeps)
         dev = torch.device("cuda")
         n = 2 * self.B
         lib = _lib.load()
-        self.images = torch.empty((n, 1, H, W), device=dev)
+        nbuf = 2 if self.overlap else 1
+        self.images_b = [torch.empty((n, 1, H, W), device=dev) for _ in range(nbuf)]
+        self.images = self.images_b[0]
+        self.raw_b = [None] * nbuf
+        self.mask_b = [None] * nbuf
         self.prob_nms = torch.empty((n, H, W), device=dev)
         self.prob_masked = torch.empty((n, H, W), device=dev)
+        if self.overlap:
+            self.enc_stream, self.post_stream = torch.cuda.Stream(), torch.cuda.Stream()
+            if self.split_encoder:
+                S = self.split_encoder
+                self.enc_streams = [self.enc_stream] + [torch.cuda.Stream() for _ in range(S - 1)]
+                self.encs_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+                self.group_ws = [torch.empty(net.workspace_bytes(n // S, H, W), dtype=torch.uint8, device=dev) for _ in range(S)]
+            self.enc_done = [torch.cuda.Event() for _ in range(2)]
+            self.post_done = [torch.cuda.Event() for _ in range(2)]
         self.nms_ws = torch.empty(lib.xp_box_nms_workspace_bytes(n, H, W, self.cap), dtype=torch.uint8, device=dev)
         self.kp = torch.zeros((n, self.cap, 2), dtype=torch.int32, device=dev)
         self.counts = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -110,17 +134,69 @@ class PairPipeline:
         self.raw = None
 
     def run(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        if not self.overlap:
+            self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
+            self._encode(0, None, None)
+            return self._post(0, mask_optical is not None, None)
+        k = self._call & 1
+        self._call += 1
+        cur = torch.cuda.current_stream()
+        # inputs are taken over on the CALLER's stream (so the caller may reuse its tensors right after run() returns),
+        # once the call before last has finished with buffer k
+        cur.wait_event(self.post_done[k])
+        self._stage_inputs(k, optical, thermal, mask_optical, mask_thermal)
+        self.enc_stream.wait_stream(cur)
+        if self.split_encoder:
+            S = self.split_encoder
+            if self.raw_b[k] is None:          # allocate the full-batch outputs once; the groups write into views of them
+                with torch.cuda.stream(self.enc_stream):
+                    self._encode(k, None, None)
+                cur.wait_stream(self.enc_stream)
+            g = 2 * self.B // S
+            for h, stream in enumerate(self.enc_streams):
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    sl = slice(h * g, (h + 1) * g)
+                    view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
+                    self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h])
+                    self.encs_done[k][h].record()
+                self.post_stream.wait_event(self.encs_done[k][h])
+        else:
+            with torch.cuda.stream(self.enc_stream):
+                self._encode(k, None, None)
+                self.enc_done[k].record()
+            self.post_stream.wait_event(self.enc_done[k])
+        with torch.cuda.stream(self.post_stream):
+            self._post(k, mask_optical is not None, None)
+            self.post_done[k].record()
+        return self
+
+    def _stage_inputs(self, k, optical, thermal, mask_optical, mask_thermal):
+        B, H, W = self.B, self.H, self.W
+        img = self.images_b[k]
+        img[:B].copy_(optical, non_blocking=True)
+        img[B:].copy_(thermal, non_blocking=True)
+        if mask_optical is not None:
+            if self.mask_b[k] is None:
+                self.mask_b[k] = torch.empty((2 * B, H, W), dtype=torch.uint8, device=img.device)
+            self.mask_b[k][:B].copy_(mask_optical.reshape(B, H, W))
+            self.mask_b[k][B:].copy_(mask_thermal.reshape(B, H, W))
+
+    def _encode(self, k, optical, thermal):
+        if optical is not None:
+            self._stage_inputs(k, optical, thermal, None, None)
+        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k])
+
+    def _post(self, k, masked=False, _unused=None):
         B, H, W, n = self.B, self.H, self.W, 2 * self.B
         lib = _lib.load()
         st = _lib.current_stream()
-        self.images[:B].copy_(optical, non_blocking=True)
-        self.images[B:].copy_(thermal, non_blocking=True)
-        raw = self.net.forward_raw(self.images, want_prob=True, want_desc=True)
+        raw = self.raw_b[k]
         self.raw = raw
+        self.images = self.images_b[k]
         prob = raw["prob"]
-        if mask_optical is not None:
-            mask = torch.cat([mask_optical.reshape(B, H, W), mask_thermal.reshape(B, H, W)], 0).to(torch.uint8).contiguous()
-            _lib.check(lib.xp_mul_mask(ptr(prob), ptr(mask), ptr(self.prob_masked), n * H * W, st), "xp_mul_mask")
+        if masked:
+            _lib.check(lib.xp_mul_mask(ptr(prob), ptr(self.mask_b[k]), ptr(self.prob_masked), n * H * W, st), "xp_mul_mask")
             prob = self.prob_masked
         thr = float(self.pred['detection_threshold'])
         if self.pred['nms'] > 0:
@@ -141,10 +217,19 @@ class PairPipeline:
                                     ptr(self.match_ws), self.match_ws.numel(), st), "xp_match_mnn")
         return self
 
+    def wait(self):
+        """Make the caller's current stream wait for everything run() has enqueued so far (overlapped mode: the
+        detection / matching stream); after it, stream-ordered reads of the result tensors are safe."""
+        if self.overlap and self._call:
+            torch.cuda.current_stream().wait_event(self.post_done[(self._call - 1) & 1])
+        return self
+
     def capture(self, optical, thermal, mask_optical=None, mask_thermal=None):
         """Capture run() into a hipGraph (fixed shapes, preallocated buffers) and return a replay callable.  The inputs
         are copied into the pipeline's own image buffer by the graph itself, so refill `optical` / `thermal` in place
         (same storage) between replays."""
+        if self.overlap:
+            raise RuntimeError("PairPipeline.capture: build the pipeline with overlap=False (a captured graph is one stream)")
         self.run(optical, thermal, mask_optical, mask_thermal)          # warm-up outside capture (one-time attribute calls)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -168,7 +253,7 @@ class PairPipeline:
             raise RuntimeError(f"PairPipeline: {mx} keypoints exceed capacity {self.cap}")
 
     def fetch(self):
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()        # device-wide: covers both streams of the overlapped mode
         self.verify()
         B = self.B
         counts = self.counts.cpu().numpy()
