@@ -173,6 +173,13 @@ int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_st
                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Evaluation-harness helper: out[i] = min_j |a_i - b_j| (Euclidean, 2-D points (y, x)); +inf when
+ * nb == 0.  a is f64 (warped keypoints), b f32 (pixel keypoints): the difference is formed in f64 and cast to f32, the
+ * norm is taken in f32 — the arithmetic of benchmark_evaluation.py:441-450 (repeatability) and :652-659 (correct-match
+ * matrix, reduced over one axis) without materialising the N x M matrix. */
+int xp_points_min_dist(const double* a, int na, const float* b, int nb, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; replaces the
  * reference's wall-clock brackets, benchmark_evaluation.py:12-37).  Off by default.  xp_prof_filter(tag)
  * restricts recording to one kernel tag (NULL/"" = all).  xp_prof_count / xp_prof_get synchronise on the

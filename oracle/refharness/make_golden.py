@@ -61,6 +61,42 @@ def gen_g12():
     np.savez_compressed(os.path.join(OUT, "g12_conv_xpoint.npz"), **out)
 
 
+def gen_g13():
+    """G13: evaluation-harness metrics: the reference's compute_repeatability_for_sample,
+    compute_descriptor_for_sample and compute_desc_dict (benchmark_evaluation.py:396-558,588-751) on synthetic heat maps /
+    descriptor maps / homographies.  cv2.perspectiveTransform and cv2.BFMatcher are the harness stand-ins (stubs.py)."""
+    torch.set_num_threads(1)
+    stubs.install()
+    import xpoint.utils.benchmark_evaluation as be
+    out = {}
+    config = {"prediction": {"matching": {"method": "bfmatcher", "knn_matches": False, "method_kwargs": {"crossCheck": True}}}}
+    for seed in (0, 1):
+        c = synth.make_eval_case(seed)
+        t = {k: torch.from_numpy(v) for k, v in c.items()}
+        data = {"optical": {"image": torch.zeros(t["prob_optical"].shape), "valid_mask": t["mask_optical"], "homography": t["H_optical"]},
+                "thermal": {"image": torch.zeros(t["prob_thermal"].shape), "valid_mask": t["mask_thermal"], "homography": t["H_thermal"]}}
+        oo, ot = {"prob": t["prob_optical"]}, {"prob": t["prob_thermal"]}
+        rep, nko, nkt = be.compute_repeatability_for_sample(oo, ot, data, t["H_optical"], t["H_thermal"], 0.015, [1, 3, 5])
+        for th, v in rep.items():
+            out[f"s{seed}/rep/{th}"] = np.array(v, np.float64)
+        out[f"s{seed}/rep/n_kp_optical"] = np.array(nko); out[f"s{seed}/rep/n_kp_thermal"] = np.array(nkt)
+        # reference call site compute_metrics:878-879 masks the heat maps first
+        po, pt = t["prob_optical"] * t["mask_optical"], t["prob_thermal"] * t["mask_thermal"]
+        dd = be.compute_descriptor_for_sample(po, pt, t["desc_optical"], t["desc_thermal"], data, config, 0.015, [2, 4])
+        for th, v in dd.items():
+            for k2, v2 in v.items():
+                out[f"s{seed}/desc/{th}/{k2}"] = np.array(v2, np.float64)
+        res = be.compute_desc_dict({th: {k2: (v2 if not k2.startswith("n_gt") else v2) for k2, v2 in v.items()} for th, v in dd.items()})
+        for th, v in res.items():
+            for k2 in ("nn_map_optical", "nn_map_thermal", "nn_map", "m_score"):
+                out[f"s{seed}/res/{th}/{k2}"] = np.array(float(v[k2]))
+            for k2 in ("precision_optical", "recall_optical", "precision_thermal", "recall_thermal"):
+                out[f"s{seed}/res/{th}/{k2}"] = np.asarray(v[k2], np.float64)
+        print("G13 seed", seed, "rep", {k: float(np.mean(v)) for k, v in rep.items()}, "n_kp", nko, nkt,
+              {th: (float(res[th]["nn_map"]), float(res[th]["m_score"])) for th in res})
+    np.savez_compressed(os.path.join(OUT, "g13_eval_metrics.npz"), **out)
+
+
 def main():
     torch.set_num_threads(1)
     stubs.install()

@@ -9,7 +9,11 @@ What is shimmed:
   * timm.models.layers   -> DropPath (identity in eval), trunc_normal_, to_2tuple
   * fvcore.nn            -> 4 unused names
   * yacs.config.CfgNode  -> attribute dict with clone/defrost/freeze/merge_from_file
-  * cv2                  -> DMatch + __version__ (BFMatcher is NOT available: parity unpinned there)
+  * cv2                  -> DMatch + __version__; perspectiveTransform (the textbook projective map, fp64) and a
+                            BFMatcher(NORM_L2, crossCheck=...) whose match() is the exact (fp64, first-minimum)
+                            nearest neighbour / mutual nearest neighbour.  Both are stand-ins written from the
+                            documented behaviour, NOT OpenCV: they exist so that the reference's evaluation
+                            harness (benchmark_evaluation.py) runs here; parity with OpenCV itself stays unpinned
   * h5py, kornia, matplotlib, GPUtil -> empty modules
   * torchvision.ops.nms / ops.boxes.batched_nms -> plain greedy restatement (documented
     algorithm: stable descending sort; suppress when inter/(a_i+a_j-inter) > iou)
@@ -139,6 +143,46 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
     return greedy_nms(boxes + offsets[:, None], scores, iou_threshold)
 
 
+def perspective_transform(src, m):
+    """cv2.perspectiveTransform for an array of shape (1, N, 2): (x, y) -> (x', y') = (X/W, Y/W), [X Y W]^T = M [x y 1]^T."""
+    src = np.asarray(src)
+    m = np.asarray(m, dtype=np.float64)
+    pts = src.reshape(-1, 2).astype(np.float64)
+    hom = np.concatenate([pts, np.ones((pts.shape[0], 1))], 1) @ m.T
+    out = hom[:, :2] / hom[:, 2:3]
+    return out.reshape(src.shape).astype(src.dtype if src.dtype in (np.float32, np.float64) else np.float64)
+
+
+class BFMatcher:
+    """Stand-in for cv2.BFMatcher(NORM_L2, crossCheck): brute force in fp64, first minimum wins, results ordered by
+    queryIdx; crossCheck=True keeps (q, t) iff t is q's nearest train descriptor and q is t's nearest query descriptor."""
+
+    def __init__(self, norm=4, crossCheck=False):
+        self.cross = bool(crossCheck)
+
+    def match(self, d1, d2):
+        d1 = np.asarray(d1, dtype=np.float64); d2 = np.asarray(d2, dtype=np.float64)
+        if d1.shape[0] == 0 or d2.shape[0] == 0:
+            return []
+        d = np.sqrt(np.maximum(((d1[:, None, :] - d2[None, :, :]) ** 2).sum(-1), 0.0)) if d1.shape[0] * d2.shape[0] <= 1 << 22 else None
+        if d is None:       # large case: row blocks
+            nn12 = np.empty(d1.shape[0], np.int64); dm = np.empty(d1.shape[0]); best21 = np.full(d2.shape[0], np.inf); nn21 = np.zeros(d2.shape[0], np.int64)
+            for i0 in range(0, d1.shape[0], 256):
+                blk = np.sqrt(np.maximum(((d1[i0:i0 + 256, None, :] - d2[None, :, :]) ** 2).sum(-1), 0.0))
+                nn12[i0:i0 + 256] = blk.argmin(1); dm[i0:i0 + 256] = blk.min(1)
+                cm = blk.min(0); ca = blk.argmin(0) + i0
+                upd = cm < best21
+                best21[upd] = cm[upd]; nn21[upd] = ca[upd]
+        else:
+            nn12 = d.argmin(1); dm = d.min(1); nn21 = d.argmin(0)
+        out = []
+        for q in range(d1.shape[0]):
+            t = int(nn12[q])
+            if not self.cross or int(nn21[t]) == q:
+                out.append(DMatch(q, t, float(np.float32(dm[q]))))
+        return out
+
+
 _installed = False
 
 
@@ -156,7 +200,8 @@ def install():
     _mod("fvcore")
     _mod("fvcore.nn", FlopCountAnalysis=None, flop_count_str=None, flop_count=None, parameter_count=None)
     _mod("yacs"); _mod("yacs.config", CfgNode=CfgNode)
-    _mod("cv2", DMatch=DMatch, __version__="0.0.0-harness-stub")
+    _mod("cv2", DMatch=DMatch, __version__="0.0.0-harness-stub", perspectiveTransform=perspective_transform, BFMatcher=BFMatcher,
+         NORM_L2=4)
     _mod("h5py")
     _mod("GPUtil")
     for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.image"):

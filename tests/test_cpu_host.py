@@ -90,3 +90,29 @@ def test_get_matches_host_errors():
         get_matches(np.zeros((2, 4), np.float32), np.zeros((2, 4), np.float32), "nope")
     with pytest.raises(NotImplementedError):
         get_matches(np.zeros((2, 4), np.float32), np.zeros((2, 4), np.float32), "flann")
+
+
+def test_evaluation_host_logic_vs_reference_golden(golden):
+    """§8(f): the host-side halves of xpoint_amd.evaluation (precision / recall / NN-mAP / M-score assembly, keypoint
+    warping and filtering) against numbers produced by the reference's own benchmark_evaluation.py (g13)."""
+    import numpy as np
+    from xpoint_amd import evaluation as ev
+    g = golden("g13_eval_metrics.npz")
+    for seed in (0, 1):
+        dd = {}
+        for th in (2, 4):
+            dd[th] = {k: g[f"s{seed}/desc/{th}/{k}"].tolist() for k in ("tp_optical", "tp_thermal", "distance_optical", "distance_thermal",
+                                                                        "m_score_optical", "m_score_thermal")}
+            dd[th]["n_gt_optical"] = int(g[f"s{seed}/desc/{th}/n_gt_optical"]); dd[th]["n_gt_thermal"] = int(g[f"s{seed}/desc/{th}/n_gt_thermal"])
+        res = ev.compute_desc_dict(dd)
+        for th in (2, 4):
+            for k in ("nn_map_optical", "nn_map_thermal", "nn_map", "m_score"):
+                assert abs(float(res[th][k]) - float(g[f"s{seed}/res/{th}/{k}"])) < 1e-12, (seed, th, k)
+            assert np.allclose(res[th]["precision_thermal"], g[f"s{seed}/res/{th}/precision_thermal"], atol=1e-12)
+    # warp_keypoints: (y, x) points through a homography acting on (x, y, 1); int return truncates toward zero
+    h = np.array([[1.0, 0.0, 2.5], [0.0, 1.0, -3.5], [0.0, 0.0, 1.0]])
+    kp = np.array([[10, 20], [0, 0], [5, 1]])
+    assert ev.warp_keypoints(kp, h).tolist() == [[6, 22], [-3, 2], [1, 3]]
+    assert np.allclose(ev.warp_keypoints(kp, h, float), [[6.5, 22.5], [-3.5, 2.5], [1.5, 3.5]])
+    assert ev.filter_points(np.array([[-1, 2], [3, 4], [5, 200], [9, 9]]), (10, 100)).tolist() == [[3, 4], [9, 9]]
+    assert ev.warp_keypoints(np.zeros((0, 2)), h).shape == (0, 2)

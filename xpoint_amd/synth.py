@@ -343,3 +343,48 @@ def to_torch(data, device="cpu"):
     if isinstance(data, dict):
         return {k: to_torch(v, device) for k, v in data.items()}
     return torch.from_numpy(np.ascontiguousarray(data)).to(device)
+
+
+def make_eval_case(seed: int, B: int = 2, H: int = 96, W: int = 128, n_base: int = 260, n_extra: int = 90, D: int = 256):
+    """Synthetic input of the evaluation harness (reference benchmark_evaluation.py): heat maps with peaks at the images of
+    common scene points under two homographies (plus unrelated peaks), coarse descriptor maps sampled from one smooth
+    field in the scene frame (plus noise), valid masks with a border.  Returns numpy arrays:
+    prob_optical/prob_thermal (B,1,H,W), desc_optical/desc_thermal (B,D,H/8,W/8), mask_* (B,1,H,W), H_optical/H_thermal (B,3,3)."""
+    out = {k: [] for k in ("prob_optical", "prob_thermal", "desc_optical", "desc_thermal", "mask_optical", "mask_thermal",
+                           "H_optical", "H_thermal")}
+    Hc, Wc = H // 8, W // 8
+    freq = uniform(f"eval{seed}/freq", (D, 2), -0.09, 0.09).astype(np.float64)
+    phase = uniform(f"eval{seed}/phase", (D,), 0.0, 6.283).astype(np.float64)
+    for b in range(B):
+        hs = []
+        for spec in ("optical", "thermal"):
+            r = uniform(f"eval{seed}/{b}/{spec}/h", (8,), -1.0, 1.0).astype(np.float64)
+            # (x, y) convention of cv2.perspectiveTransform; mild rotation / scale / shift / perspective
+            hm = np.array([[1.0 + 0.06 * r[0], 0.05 * r[1], 4.0 * r[2]],
+                           [0.05 * r[3], 1.0 + 0.06 * r[4], 4.0 * r[5]],
+                           [2e-4 * r[6], 2e-4 * r[7], 1.0]])
+            hs.append(hm)
+        base = np.stack([uniform(f"eval{seed}/{b}/bx", (n_base,), 6.0, W - 7.0), uniform(f"eval{seed}/{b}/by", (n_base,), 6.0, H - 7.0)], 1).astype(np.float64)
+        for si, spec in enumerate(("optical", "thermal")):
+            hm = hs[si]
+            pts = np.concatenate([base, np.ones((n_base, 1))], 1) @ hm.T
+            pts = pts[:, :2] / pts[:, 2:3]
+            prob = np.zeros((H, W), np.float32)
+            score = uniform(f"eval{seed}/{b}/{spec}/score", (n_base,), 0.05, 0.95)
+            for (x, y), sc in zip(np.rint(pts).astype(int), score):
+                if 0 <= y < H and 0 <= x < W:
+                    prob[y, x] = max(prob[y, x], sc)
+            ex = np.stack([uniform(f"eval{seed}/{b}/{spec}/ex", (n_extra,), 0, W - 1), uniform(f"eval{seed}/{b}/{spec}/ey", (n_extra,), 0, H - 1)], 1)
+            for (x, y), sc in zip(np.rint(ex).astype(int), uniform(f"eval{seed}/{b}/{spec}/es", (n_extra,), 0.02, 0.6)):
+                prob[y, x] = max(prob[y, x], sc)
+            mask = np.zeros((H, W), np.float32); mask[3:H - 3, 2:W - 4] = 1.0
+            # coarse descriptor map: cell centre -> scene frame -> smooth field (+ noise), L2-normalised over channels
+            cy, cx = np.meshgrid((np.arange(Hc) + 0.5) * 8 - 0.5, (np.arange(Wc) + 0.5) * 8 - 0.5, indexing="ij")
+            cells = np.stack([cx.ravel(), cy.ravel(), np.ones(Hc * Wc)], 1) @ np.linalg.inv(hm).T
+            cells = cells[:, :2] / cells[:, 2:3]
+            f = np.sin(cells @ freq.T + phase[None, :]) + 0.15 * uniform(f"eval{seed}/{b}/{spec}/dn", (Hc * Wc, D), -1.0, 1.0)
+            f = f / np.linalg.norm(f, axis=1, keepdims=True)
+            out[f"prob_{spec}"].append(prob[None]); out[f"mask_{spec}"].append(mask[None])
+            out[f"desc_{spec}"].append(f.T.reshape(D, Hc, Wc).astype(np.float32))
+            out[f"H_{spec}"].append(hm.astype(np.float32))
+    return {k: np.stack(v) for k, v in out.items()}
