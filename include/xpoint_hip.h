@@ -180,6 +180,19 @@ int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_st
 int xp_points_min_dist(const double* a, int na, const float* b, int nb, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Robust homography from point correspondences, batched over pairs: the device-side stand-in
+ * for cv2.findHomography(src, dst, cv2.USAC_MAGSAC, ransacReprojThreshold, confidence, maxIters) as called from
+ * predict_align_image_pair.py:291-303 and benchmark_evaluation.py:796-812.  Same contract (H maps src -> dst, h33 = 1;
+ * inlier mask at the reprojection threshold; no model below 4 correspondences -> n_inliers = 0, H = identity), a
+ * different — deterministic — estimator (hash-seeded 4-point DLT hypotheses, MSAC score, least-squares refinement):
+ * not bit-comparable with OpenCV.
+ *   src, dst (pairs, cap, 2) f32 (x, y); counts (pairs) int32 or NULL; H (pairs, 9) f64; mask (pairs, cap) u8. */
+size_t xp_find_homography_workspace_bytes(int pairs);
+int xp_find_homography(const float* src, const float* dst, const int* counts, int pairs, int cap, float reproj_thr,
+                       int max_iters, unsigned seed, double* H, uint8_t* mask, int* n_inliers, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; replaces the
  * reference's wall-clock brackets, benchmark_evaluation.py:12-37).  Off by default.  xp_prof_filter(tag)
  * restricts recording to one kernel tag (NULL/"" = all).  xp_prof_count / xp_prof_get synchronise on the

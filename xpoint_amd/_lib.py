@@ -53,6 +53,7 @@ _SIGNATURES = {
     "xp_sample_descriptors": [c_p] * 4 + [c_i] * 7 + [c_p],
     "xp_match_mnn": [c_p, c_p, c_p] + [c_i] * 8 + [c_p] * 9 + [c_sz, c_p],
     "xp_points_min_dist": [c_p, c_i, c_p, c_i, c_p, c_p],
+    "xp_find_homography": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, ctypes.c_uint, c_p, c_p, c_p, c_p, c_sz, c_p],
     "xp_prof_enable": [c_i],
     "xp_prof_filter": [ctypes.c_char_p],
     "xp_prof_reset": [],
@@ -68,6 +69,7 @@ _SIZE_QUERIES = {
     "xp_ss2d_core_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_split_weights_x3_bytes": (c_sz, [c_i] * 2),
     "xp_split_weights_bytes": (c_sz, [c_p]),
+    "xp_find_homography_workspace_bytes": (c_sz, [c_i]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_match_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_extract_keypoints_workspace_bytes": (c_sz, [c_i] * 3),

@@ -7,8 +7,11 @@ structures, including its per-sample overwrite quirks, see below) and `xpoint/ut
   compute_repeatability_for_sample   benchmark_evaluation.py:396-467
   compute_descriptor_for_sample      benchmark_evaluation.py:588-751   (NN-mAP inputs, M-score)
   compute_mAP / compute_desc_dict    benchmark_evaluation.py:469-558
-  compute_metrics                    benchmark_evaluation.py:832-963   (repeatability + descriptor parts; the
-                                     homography-estimation part needs cv2.findHomography: §8(f) rank 2, not here)
+  compute_pts_dist_for_sample        benchmark_evaluation.py:755-830   (corner error of the estimated homography;
+  compute_homography_dict            benchmark_evaluation.py:560-586    the estimator is utils.find_homography, the
+                                                                        device stand-in for cv2.findHomography MAGSAC:
+                                                                        same contract, not bit-comparable — §8(f) rank 2)
+  compute_metrics                    benchmark_evaluation.py:832-963
 
 Device work goes through the C ABI: keypoints and descriptors stay on the GPU, descriptor sampling is
 `xp_sample_descriptors`, both match directions come from ONE `xp_match_mnn` call (mutual nearest neighbours are
@@ -219,12 +222,68 @@ def compute_desc_dict(descriptor_metrics_dict):
     return results
 
 
-def compute_metrics(net, dataloader, device, config, keypoint_detection_threshold=0.015, thresh_repeatability=3, thresh_keypoints=2):
-    """benchmark_evaluation.py:832-963 without its homography-estimation leg (cv2.findHomography; §8(f) rank 2).
-    `dataloader` is any iterable of reference-style `data` dicts; returns {'repeatability': ..., 'descriptor': ...}."""
+def compute_pts_dist_for_sample(prob_optical, prob_thermal, desc_optical, desc_thermal, data, config, keypoint_detection_threshold,
+                                ransac_reporjection_thresholds):
+    """benchmark_evaluation.py:755-830: mean distance of the four image "corners" (the reference's own point list,
+    [[0,0],[H,0],[0,W],[H,H]]) warped by the ground-truth and by the estimated optical->thermal homography; 999.0 when
+    no model could be estimated.  Returns {threshold: [distance per sample]}."""
+    ths = ransac_reporjection_thresholds if type(ransac_reporjection_thresholds) is list else [ransac_reporjection_thresholds]
+    H_o, W_o = data['optical']['image'].shape[2:]
+    H_t, W_t = data['thermal']['image'].shape[2:]
+    samples = []
+    for (prob_o, prob_t, h_o, h_t, desc_o, desc_t) in zip(prob_optical, prob_thermal, data['optical']['homography'],
+                                                          data['thermal']['homography'], desc_optical, desc_thermal):
+        h_o, h_t = h_o.float().cpu(), h_t.float().cpu()
+        gt_homography = torch.mm(h_t, h_o.inverse())
+        pred_optical = torch.nonzero((prob_o.squeeze() > keypoint_detection_threshold).float())
+        pred_thermal = torch.nonzero((prob_t.squeeze() > keypoint_detection_threshold).float())
+        d_o = utils.interpolate_descriptors(pred_optical, desc_o, H_o, W_o)
+        d_t = utils.interpolate_descriptors(pred_thermal, desc_t, H_t, W_t)
+        m_o, _ = _mutual_matches(d_o, d_t)
+        if m_o:
+            qi = torch.tensor([m[0] for m in m_o], device=pred_optical.device); ti = torch.tensor([m[1] for m in m_o], device=pred_optical.device)
+            optical_pts = pred_optical[qi].flip(-1).float()       # cv2.KeyPoint(x = col, y = row)
+            thermal_pts = pred_thermal[ti].flip(-1).float()
+        else:
+            optical_pts = thermal_pts = torch.zeros((0, 2), device=pred_optical.device)
+        samples.append((gt_homography, optical_pts, thermal_pts))
+    out = {}
+    for th in ths:
+        member = []
+        for gt_homography, optical_pts, thermal_pts in samples:
+            H_est, _ = utils.find_homography(optical_pts, thermal_pts, th) if optical_pts.shape[0] >= 4 else (None, None)
+            if H_est is not None:
+                pts = np.array([[0, 0], [H_o, 0], [0, W_o], [H_o, H_o]])
+                gt = warp_keypoints(pts, gt_homography.numpy(), float)
+                est = warp_keypoints(pts, H_est, float)
+                member.append(np.linalg.norm(est - gt, axis=1).sum() / 4)
+            else:
+                member.append(999.0)
+        out[th] = member
+    return out
+
+
+def compute_homography_dict(overall_pts_dist_dict, threshold_warp):
+    """benchmark_evaluation.py:560-586."""
+    results = {}
+    for th_ransac, dists in overall_pts_dist_dict.items():
+        pts_dist = np.array(dists)
+        out = {'average_h_error': pts_dist.mean(), 'h_correctness': {}}
+        for th_warp in threshold_warp:
+            out['h_correctness']['epsilon_warp_th' + str(th_warp)] = (pts_dist < th_warp).sum() / len(pts_dist)
+        results[th_ransac] = out
+    return results
+
+
+def compute_metrics(net, dataloader, device, config, keypoint_detection_threshold=0.015, thresh_repeatability=3, thresh_keypoints=2,
+                    thresh_warp=2, ransac_reproj_thresholds=3):
+    """benchmark_evaluation.py:832-963.  `dataloader` is any iterable of reference-style `data` dicts; returns
+    {'repeatability': ..., 'descriptor': ..., 'homography': ...} (the last one from this build's estimator)."""
     repeatability = {th: [] for th in thresh_repeatability} if type(thresh_repeatability) is list else {thresh_repeatability: []}
     n_kp_optical, n_kp_thermal = [], []
     descriptor_metrics_dict = {th: {} for th in thresh_keypoints} if type(thresh_keypoints) is list else {thresh_keypoints: {}}
+    rts = ransac_reproj_thresholds if type(ransac_reproj_thresholds) is list else [ransac_reproj_thresholds]
+    overall_pts_dist_dict = {th: [] for th in rts}
     pred = config['prediction']
     for data in dataloader:
         B = data['optical']['image'].shape[0]
@@ -258,7 +317,13 @@ def compute_metrics(net, dataloader, device, config, keypoint_detection_threshol
                     descriptor_metrics_dict[key][key2] = descriptor_metrics_dict[key].get(key2, 0) + value2
                 else:
                     descriptor_metrics_dict[key][key2] = descriptor_metrics_dict[key].get(key2, []) + value2
+        pd = compute_pts_dist_for_sample(prob_optical, prob_thermal, out_optical['desc'], out_thermal['desc'], data, config,
+                                         keypoint_detection_threshold, rts)
+        for key, value in pd.items():
+            overall_pts_dist_dict[key] += value
     out_rep = {'repeatability_mean': {k: np.mean(v) for k, v in repeatability.items()},
                'n_kp_optical': np.mean(n_kp_optical), 'n_kp_thermal': np.mean(n_kp_thermal)}
     out_rep['n_kp_avg'] = (out_rep['n_kp_optical'] + out_rep['n_kp_thermal']) / 2.0
-    return {"repeatability": out_rep, "descriptor": compute_desc_dict(descriptor_metrics_dict)}
+    tw = thresh_warp if type(thresh_warp) is list else [thresh_warp]
+    return {"repeatability": out_rep, "descriptor": compute_desc_dict(descriptor_metrics_dict),
+            "homography": compute_homography_dict(overall_pts_dist_dict, tw)}

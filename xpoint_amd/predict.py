@@ -29,10 +29,12 @@ def _cfg(pred):
     return c
 
 
-def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_mnn"):
+def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_mnn", estimate_homography=False):
     """data: the reference pair dict ({'optical': {'image','valid_mask',...}, 'thermal': {...}}) on the GPU.
     Returns (out_optical, out_thermal, results) where results[i] = dict(kp_optical, kp_thermal (N,2) int64 (y,x),
-    desc_optical, desc_thermal (N,D), matches [DMatch])."""
+    desc_optical, desc_thermal (N,D), matches [DMatch]).  estimate_homography=True adds the registration step of
+    predict_align_image_pair.py:287-303: H_est (3,3) float64 mapping optical (x, y) to thermal (identity when fewer than
+    4 matches, as the reference) and matchesMask, from `utils.find_homography` at `reprojection_threshold` (default 3)."""
     pred = _cfg(cfg_prediction)
     if net.takes_pair():
         out_o, out_t, _ = net(data)
@@ -53,7 +55,17 @@ def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_
         dt = utils.interpolate_descriptors_nhwc(kt, out_t['desc_nhwc'][i], H, W)
         ms = utils.get_matches(do, dt, pred['matching']['method'], pred['matching']['knn_matches'], mode=match_mode,
                                **pred['matching']['method_kwargs'])
-        results.append(dict(kp_optical=ko, kp_thermal=kt, desc_optical=do, desc_thermal=dt, matches=ms))
+        r = dict(kp_optical=ko, kp_thermal=kt, desc_optical=do, desc_thermal=dt, matches=ms)
+        if estimate_homography:
+            import numpy as np
+            H_est, mask = None, None
+            if len(ms) >= 4:
+                qi = torch.tensor([m.queryIdx for m in ms], device=ko.device); ti = torch.tensor([m.trainIdx for m in ms], device=ko.device)
+                H_est, mask = utils.find_homography(ko[qi].flip(-1).float(), kt[ti].flip(-1).float(),
+                                                    float(pred.get('reprojection_threshold', 3.0)))
+            r["H_est"] = H_est if H_est is not None else np.eye(3)
+            r["matchesMask"] = mask.ravel().tolist() if mask is not None else []
+        results.append(r)
     return out_o, out_t, results
 
 

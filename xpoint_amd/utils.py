@@ -184,3 +184,38 @@ def get_matches(desc_1, desc_2, method='bfmatcher', knn_matches=False, mode="str
         keep = d < float(kwargs.get('threshold', 0.7))
         q, t, d = q[keep], t[keep], d[keep]
     return [DMatch(a, b, c) for a, b, c in zip(q, t, d)]
+
+
+# ---------------------------------------------------------------- homography estimation
+def find_homography_batched(src, dst, counts=None, reproj_threshold=3.0, max_iters=10000, seed=0):
+    """src, dst: (P, cap, 2) float32 device tensors of (x, y) correspondences (row i of src matches row i of dst);
+    counts: optional (P,) int32 device tensor.  Returns device tensors H (P,3,3) float64, mask (P,cap) uint8,
+    n_inliers (P,) int32 (0 = no model).  Device stand-in for cv2.findHomography(..., USAC_MAGSAC, thr): same contract,
+    deterministic estimator (include/xpoint_hip.h: xp_find_homography)."""
+    P, cap, _ = src.shape
+    dev = src.device
+    lib = _lib.load()
+    src, dst = src.contiguous().float(), dst.contiguous().float()
+    H = torch.empty((P, 3, 3), dtype=torch.float64, device=dev)
+    mask = torch.empty((P, cap), dtype=torch.uint8, device=dev)
+    n_inl = torch.empty((P,), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.xp_find_homography_workspace_bytes(P) // 8 + 1, dtype=torch.float64, device=dev)
+    cnt = counts.to(torch.int32).contiguous() if counts is not None else None
+    _lib.check(lib.xp_find_homography(ptr(src), ptr(dst), ptr(cnt), P, cap, float(reproj_threshold), int(max_iters), int(seed) & 0xffffffff,
+                                      ptr(H), ptr(mask), ptr(n_inl), ptr(ws), ws.numel() * 8, _lib.current_stream()), "xp_find_homography")
+    return H, mask, n_inl
+
+
+def find_homography(src_pts, dst_pts, reproj_threshold=3.0, max_iters=10000, seed=0):
+    """cv2.findHomography-shaped call: src_pts / dst_pts (N,1,2) or (N,2) float (x, y) numpy arrays or tensors.
+    Returns (H (3,3) float64 numpy or None, mask (N,1) uint8 numpy) like cv2 does."""
+    import numpy as np
+    s = torch.as_tensor(np.asarray(src_pts, dtype=np.float32) if not torch.is_tensor(src_pts) else src_pts).reshape(-1, 2).float()
+    d = torch.as_tensor(np.asarray(dst_pts, dtype=np.float32) if not torch.is_tensor(dst_pts) else dst_pts).reshape(-1, 2).float()
+    n = s.shape[0]
+    if n < 4:
+        return None, np.zeros((n, 1), np.uint8)
+    H, mask, n_inl = find_homography_batched(s.cuda()[None], d.cuda()[None], None, reproj_threshold, max_iters, seed)
+    if int(n_inl[0].item()) == 0:
+        return None, np.zeros((n, 1), np.uint8)
+    return H[0].cpu().numpy(), mask[0].cpu().numpy().reshape(n, 1)
