@@ -237,7 +237,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     int* s_pix = reinterpret_cast<int*>(smem);
     float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * npx);
     constexpr int XW = 2 * (R + 2);
-    float* s_y = s_x + npx * XW;   // [npx][C]
+    float* s_y = s_x + npx * XW;   // [npx][C + 8]: the pad keeps the 16-lanes-per-pixel LayerNorm reads of 4 rows off the same banks
+    const int SY = p.C + 8;
     const int pair = COLPAIR ? 1 : 0;
     const int b = blockIdx.y, chunk0 = blockIdx.x * p.cpb;
     stage_chunk<R>(p, b, pair, chunk0, s_pix, s_x);
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 float a, bb, cv;
                 step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
                 h = a * h + bb;
-                s_y[pi * p.C + c] = cv * h + D0 * uv[k];   // y = C*h + D*u (csms6s.py:61,67); rows past the end are never read
+                s_y[pi * SY + c] = cv * h + D0 * uv[k];   // y = C*h + D*u (csms6s.py:61,67); rows past the end are never read
             }
         }
         // backward route over the same pixels
@@ -305,20 +306,44 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 step_vals<R>(xr, w1, b1, A1, uv[k], a, bb, cv);
                 h = a * h + bb;                                      // u = 0 steps before the image's last pixel keep h = 0
                 const float y2 = cv * h + D1 * uv[k];
-                const float tot = s_y[pi * p.C + c] + y2;           // y_fwd + flip(y_bwd)
-                if (COLPAIR) s_y[pi * p.C + c] = pv[k] + tot;      // (y0+y2) + (y1+y3)
+                const float tot = s_y[pi * SY + c] + y2;           // y_fwd + flip(y_bwd)
+                if (COLPAIR) s_y[pi * SY + c] = pv[k] + tot;      // (y0+y2) + (y1+y3)
                 else if (px[k] >= 0) dst[px[k] * p.C] = tot;
             }
         }
     }
     if (!COLPAIR) return;
     __syncthreads();
-    // out_norm: LayerNorm over C per pixel, one wave per pixel (two-pass mean / variance).
+    // out_norm: LayerNorm over C per pixel (two-pass mean / variance).  Narrow stages (C <= 192): 16 lanes per pixel, four
+    // pixels per wave — with a whole wave per pixel two thirds of the lanes idle at C = 96 and the two 6-step shuffle
+    // reductions dominate (this part was a third of the column pass at stage 0).  Wide stages: one wave per pixel.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (p.C <= 192) {
+        const int sub = lane & 15, grp = lane >> 4;
+        const float invC = 1.f / (float)p.C;
+        for (int pi = wave * 4 + grp; pi < npx; pi += nw * 4) {      // a 16-lane group skips as a whole: shuffles stay inside the group
+            const int px = s_pix[pi];
+            if (px < 0) continue;
+            const float* row = s_y + pi * SY;
+            float s = 0.f;
+            for (int cc = sub; cc < p.C; cc += 16) s += row[cc];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * invC;
+            float v = 0.f;
+            for (int cc = sub; cc < p.C; cc += 16) { const float d = row[cc] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const float rstd = 1.f / sqrtf(v * invC + p.eps);
+            float* orow = p.out + ((int64_t)b * L + px) * p.C;
+            for (int cc = sub; cc < p.C; cc += 16) orow[cc] = (row[cc] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+        }
+        return;
+    }
     for (int pi = wave; pi < npx; pi += nw) {
         const int px = s_pix[pi];
         if (px < 0) continue;
-        const float* row = s_y + pi * p.C;
+        const float* row = s_y + pi * SY;
         float s = 0.f;
         for (int cc = lane; cc < p.C; cc += 64) s += row[cc];
         const float mean = xp_wave_sum(s) / (float)p.C;
@@ -336,7 +361,7 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const int npx = p.cpb * p.T;
     const int threads = p.cpb * p.C;
     const size_t sm1 = sizeof(int) * npx + sizeof(float) * npx * XW;
-    const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * p.C;
+    const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * (p.C + 8);
     dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
     const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * XW;
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
