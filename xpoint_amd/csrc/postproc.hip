@@ -2,6 +2,8 @@
 //   box_nms            reference xpoint/utils/utils.py:148-192  (torchvision.ops.nms / batched_nms)
 //   extract_keypoints  reference predict_align_image_pair.py:242-243, predict_keypoints.py:213-215
 //   sample_descriptors reference xpoint/utils/utils.py:229-238  (F.grid_sample bilinear, align_corners)
+#include <stdlib.h>
+
 #include "xp_common.h"
 
 extern "C" size_t xp_extract_keypoints_workspace_bytes(int batch, int H, int W);
@@ -351,9 +353,24 @@ static int box_nms_enqueue(const float* prob, float* out, void* workspace, int b
     XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
     XP_HIP(hipMemsetAsync(w.counters, 0, sizeof(int) * NMS_MAX_SWEEPS, s));
     dim3 grid(xp_cdiv(W, NMS_TILE), xp_cdiv(H, NMS_TILE), batch);
+    // Local fixed-point iterations per sweep.  Early sweeps are dominated by decisions that wait on a neighbouring tile, so
+    // iterating long inside a tile is wasted there (measured: 8 iterations in sweep 0 cost 256 us, 2 cost 128 us, and the
+    // number of sweeps to convergence is the same); late sweeps touch few tiles and finish them locally.
+    // XP_NMS_SCHED="a,b,c,..." overrides (tuning).
+    static int sched[NMS_MAX_SWEEPS];
+    static bool sched_init = false;
+    if (!sched_init) {
+        for (int i = 0; i < NMS_MAX_SWEEPS; ++i) sched[i] = i < 3 ? 2 : 8;
+        if (const char* e = getenv("XP_NMS_SCHED")) {
+            int i = 0, last = 8;
+            for (const char* q = e; *q && i < NMS_MAX_SWEEPS;) { last = atoi(q); sched[i++] = last; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            for (; i < NMS_MAX_SWEEPS; ++i) sched[i] = last;
+        }
+        sched_init = true;
+    }
     for (int i = 0; i < sweeps; ++i)
         hipLaunchKernelGGL(nms_sweep_kernel, grid, dim3(256), 0, s, prob, w.state, out, w.tile_active, H, W, tab, min_prob, w.counters,
-                           i, (first_round && i == 0) ? 1 : 0, 8);
+                           i, (first_round && i == 0) ? 1 : 0, sched[i]);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
