@@ -97,6 +97,31 @@ def gen_g13():
     np.savez_compressed(os.path.join(OUT, "g13_eval_metrics.npz"), **out)
 
 
+def gen_g14():
+    """G14: multispectral two-encoder routing (XPoint.py:98-100, 284-305) on the reduced VMamba
+    model: pair forward (optical -> encoder_optical, thermal -> encoder_thermal) and a mixed-flag single batch."""
+    torch.set_num_threads(1)
+    H, W, B = 64, 96, 2
+    cfg = synth.xpoint_exp1_config(H, W, vssm={"EMBED_DIM": 32})
+    cfg["multispectral"] = True
+    cfg["mixed_precision"] = False      # the reference allocates a half tensor otherwise (XPoint.py:289-291), unusable on the CPU
+    sdn = synth.make_state_dict(cfg)
+    net = build_ref.build_reference_xpoint(cfg, sdn)
+    data = synth.to_torch(synth.make_pair_batch(0, B, H, W))
+    out = {}
+    with torch.no_grad():
+        o, t, _ = net(data)
+        for spec, r in (("optical", o), ("thermal", t)):
+            for k in ("prob", "desc", "encoder_output"):
+                out[f"pair/{spec}/{k}"] = r[k].numpy()
+        mixed = {"image": torch.cat([data["optical"]["image"][:1], data["thermal"]["image"][:1], data["optical"]["image"][1:]], 0),
+                 "is_optical": torch.tensor([[True], [False], [True]])}
+        r = net.forward_impl(mixed)
+        out["mixed/prob"] = r["prob"].numpy(); out["mixed/desc"] = r["desc"].numpy()
+    print("G14: optical vs thermal encoder differ by", float(np.abs(out["pair/optical/prob"] - out["pair/thermal/prob"]).max()))
+    np.savez_compressed(os.path.join(OUT, "g14_multispectral.npz"), **out)
+
+
 def main():
     torch.set_num_threads(1)
     stubs.install()

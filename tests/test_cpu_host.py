@@ -74,9 +74,13 @@ def test_model_config_and_state_dict_errors():
     assert models.XPoint(cfg).load_state_dict(extra, strict=False).unexpected_keys == ["bogus.weight"]
     with pytest.raises(RuntimeError):                                 # forward before weights / on CPU
         models.XPoint(cfg).eval()({"optical": {"image": torch.zeros(1, 1, 64, 96)}, "thermal": {"image": torch.zeros(1, 1, 64, 96)}})
+    # multispectral: two encoders' keys (thermal first, XPoint.py:98-100); conv-encoder multispectral stays unimplemented
+    c2 = synth.xpoint_exp1_config(64, 96); c2["multispectral"] = True
+    keys = list(models.XPoint(c2).expected_keys())
+    assert keys[0].startswith("encoder_thermal.") and any(k.startswith("encoder_optical.") for k in keys) and "encoder.patch_embed.0.weight" not in keys
     with pytest.raises(NotImplementedError):
-        c2 = synth.xpoint_exp1_config(64, 96); c2["multispectral"] = True
-        models.XPoint(c2)
+        c3 = synth.multipoint_config(); c3["multispectral"] = True
+        models.XPoint(c3)
     from xpoint_amd.utils import fix_model_weigth_keys, dict_update
     assert list(fix_model_weigth_keys({"module__encoder.x": 1, "y": 2})) == ["encoder.x", "y"]
     assert dict_update({"a": {"b": 1, "c": 2}}, {"a": {"b": 3}}) == {"a": {"b": 3, "c": 2}}

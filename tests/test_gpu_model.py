@@ -287,3 +287,38 @@ def test_async_nms_reports_non_convergence(gpu_lib):
     assert left.value > 0                                        # one sweep cannot finish a 640-long chain
     L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 0, ctypes.byref(left), L.current_stream()), "nms")
     assert torch.equal(out.cpu(), xo.box_nms(p.unsqueeze(1), 8, 0.015)[:, 0])      # the synchronous form iterates to the fixed point
+
+
+def test_multispectral_two_encoder_routing(gpu_lib, golden):
+    """`multispectral: true` (XPoint.py:98-100, 284-305) — optical images through encoder_optical,
+    thermal through encoder_thermal, shared heads — against the real reference on the reduced VMamba model: the pair
+    forward, a mixed-flag batch, and the batched PairPipeline (single stream and overlapped)."""
+    from xpoint_amd.predict import PairPipeline, predict_align_image_pair
+    g = golden("g14_multispectral.npz")
+    H, W, B = 64, 96, 2
+    cfg = synth.xpoint_exp1_config(H, W, vssm={"EMBED_DIM": 32})
+    cfg["multispectral"] = True
+    net = _net(cfg)
+    data = _data(0, B, H, W)
+    with torch.no_grad():
+        o, t, _ = net(data)
+        for spec, r in (("optical", o), ("thermal", t)):
+            for k in ("prob", "desc", "encoder_output"):
+                err = float(np.abs(r[k].cpu().numpy() - g[f"pair/{spec}/{k}"]).max())
+                assert err < TOL, (spec, k, err)
+        mixed = {"image": torch.cat([data["optical"]["image"][:1], data["thermal"]["image"][:1], data["optical"]["image"][1:]], 0),
+                 "is_optical": torch.tensor([[True], [False], [True]]).cuda()}
+        r = net.forward_impl(mixed)
+        assert float(np.abs(r["prob"].cpu().numpy() - g["mixed/prob"]).max()) < TOL
+        assert float(np.abs(r["desc"].cpu().numpy() - g["mixed/desc"]).max()) < TOL
+        # the encoders really differ, and the batched pipelines route the two halves like the per-pair flow does
+        assert float((o["prob"] - t["prob"]).abs().max()) > 0.1
+        _, _, ref = predict_align_image_pair(net, _data(0, B, H, W))
+        for ov in (False, True):
+            got = PairPipeline(net, B, H, W, cap=1024, overlap=ov, split_encoder=2 if ov else 0).run(
+                data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"]).fetch()
+            for a, b in zip(got, ref):
+                assert torch.equal(a["kp_optical"], b["kp_optical"].cpu()) and torch.equal(a["kp_thermal"], b["kp_thermal"].cpu())
+                assert a["match_q"].tolist() == [m.queryIdx for m in b["matches"]]
+    with pytest.raises(RuntimeError):
+        net.forward_raw(data["optical"]["image"])          # flags are mandatory for a two-encoder model

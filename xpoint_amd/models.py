@@ -56,8 +56,8 @@ class XPoint(torch.nn.Module):
         if self._kind is None:
             raise NotImplementedError("xpoint_amd.models.XPoint implements the VMamba encoder (model_weights/XPoint-EXP1/params.yaml) "
                                       "and the conv encoder (model_weights/multipoint/params.yaml); SwinV2 is out of scope")
-        if self.config['multispectral']:
-            raise NotImplementedError("multispectral two-encoder routing (XPoint.py:284-305) is out of scope; XPoint-EXP1 uses one shared encoder")
+        if self.config['multispectral'] and self._kind != "vmamba":
+            raise NotImplementedError("multispectral two-encoder routing (XPoint.py:284-305) is implemented for the VMamba encoder only")
         for k, v in (('reflection_pad', True), ('bn_first', False), ('final_batchnorm', True), ('descriptor_head', True),
                      ('normalize_descriptors', True)):
             if self.config[k] != v:
@@ -65,8 +65,10 @@ class XPoint(torch.nn.Module):
         if self.config['homography_regression_head']['check']:
             assert self.config['takes_pair'], "RegNet can only be used with takes_pair=True"       # XPoint.py:103
         self._ref_state: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
-        self._blob: Optional[torch.Tensor] = None        # device-format weights (one float32 tensor)
+        self._blob: Optional[torch.Tensor] = None        # device-format weights (one float32 tensor); multispectral: the OPTICAL encoder + heads
         self._wsplit: Optional[torch.Tensor] = None      # split-bf16 copies of the GEMM weights, derived from _blob on the device
+        self._blob_t: Optional[torch.Tensor] = None      # multispectral only: the THERMAL encoder + the same heads
+        self._wsplit_t: Optional[torch.Tensor] = None
         # "x3": dense layers on the bf16 matrix pipe with split operands (fp32-accurate); "f32": exact-f32 MFMA kernels
         self.gemm_mode = os.environ.get("XP_GEMM_MODE", "x3")
         self._device = torch.device("cpu")
@@ -160,6 +162,8 @@ class XPoint(torch.nn.Module):
                 self._ref_state[k] = t.detach().to("cpu").clone()
         self._blob = None
         self._wsplit = None
+        self._blob_t = None
+        self._wsplit_t = None
         self._conv_impl = None
         self._regnet_w = None
         return _LoadResult(missing, unexpected)
@@ -170,8 +174,9 @@ class XPoint(torch.nn.Module):
         shift = s[pre + "bias"].double() - s[pre + "running_mean"].double() * scale
         return scale.float(), shift.float()
 
-    def _device_params(self):
-        """reference state dict -> device-format tensors (names of csrc/model.cpp build_layout)."""
+    def _device_params(self, e="encoder."):
+        """reference state dict -> device-format tensors (names of csrc/model.cpp build_layout) for the encoder whose
+        state_dict prefix is `e` ("encoder.", or "encoder_optical." / "encoder_thermal." when multispectral)."""
         s = self._ref_state
         missing = [k for k, (_, kind) in self.expected_keys().items() if k not in s and kind != "bn_count"
                    and not k.startswith("hm_regressor.")]
@@ -179,7 +184,6 @@ class XPoint(torch.nn.Module):
             raise RuntimeError(f"XPoint: weights not loaded ({len(missing)} tensors missing, e.g. {missing[:3]}); "
                                "call load_state_dict first")
         out = {}
-        e = "encoder."
         w0 = s[e + "patch_embed.0.weight"].double().sum(dim=1)                 # gray replicated to 3 channels (VMamba.py:1509)
         out["stem.w"] = w0.permute(1, 2, 0).reshape(9, -1).float()
         out["stem.b"] = s[e + "patch_embed.0.bias"]
@@ -221,11 +225,17 @@ class XPoint(torch.nn.Module):
         out["desc2.scale"], out["desc2.shift"] = self._bn_affine(dsc + "5.")
         return out
 
-    def pack_weights(self) -> torch.Tensor:
-        """The device-format blob on the CPU (one float32 vector); what rank 0 broadcasts over RCCL."""
+    def pack_weights(self, spectrum: Optional[str] = None) -> torch.Tensor:
+        """The device-format blob on the CPU (one float32 vector); what rank 0 broadcasts over RCCL.
+        multispectral models have two (spectrum = "optical" / "thermal": that encoder + the shared heads)."""
         total = _lib.load().xp_weights_numel(self._ctx)
         blob = torch.zeros(total, dtype=torch.float32)
-        dp = self._device_params()
+        if self.config['multispectral']:
+            if spectrum not in ("optical", "thermal"):
+                raise RuntimeError("multispectral XPoint: pack_weights(spectrum='optical' | 'thermal')")
+            dp = self._device_params(f"encoder_{spectrum}.")
+        else:
+            dp = self._device_params()
         for name, (off, num) in self._layout.items():
             t = dp[name].contiguous().float().reshape(-1)
             if t.numel() != num:
@@ -237,7 +247,9 @@ class XPoint(torch.nn.Module):
         return int(_lib.load().xp_weights_numel(self._ctx))
 
     def set_weight_blob(self, blob: torch.Tensor):
-        """Adopt an already packed device blob (e.g. received by RCCL broadcast)."""
+        """Adopt an already packed device blob (e.g. received by RCCL broadcast).  Single-encoder models only."""
+        if self.config['multispectral']:
+            raise NotImplementedError("set_weight_blob: multispectral models hold two blobs; load the state_dict on every rank instead")
         assert blob.is_cuda and blob.dtype == torch.float32 and blob.numel() == self.weights_numel()
         self._blob = blob.contiguous()
         self._wsplit = None
@@ -249,6 +261,9 @@ class XPoint(torch.nn.Module):
             if self._blob is not None and self._blob.device != self._device:
                 self._blob = self._blob.to(self._device)
                 self._wsplit = None
+            if self._blob_t is not None and self._blob_t.device != self._device:
+                self._blob_t = self._blob_t.to(self._device)
+                self._wsplit_t = None
         return self
 
     def cuda(self, device=None):
@@ -268,13 +283,16 @@ class XPoint(torch.nn.Module):
     def workspace_bytes(self, n_img, H, W) -> int:
         return int(_lib.load().xp_forward_workspace_bytes(self._ctx, n_img, H, W))
 
-    def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None):
+    def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
+                    is_optical=None):
         """images (N,1,H,W) float32 on the GPU -> dict of NHWC device tensors (no layout exports):
         prob (N,H,W), desc_nhwc (N,Hc,Wc,D), enc_nhwc (N,Hc,Wc,E/2), logits_nhwc (N,Hc,Wc,65).
         out: a dict returned by an earlier call with the same shapes -> its tensors are overwritten instead of
         allocating new ones (VMamba branch; lets a caller double-buffer the outputs across streams).
         workspace: a uint8 device tensor of workspace_bytes(N, H, W) bytes owned by the caller (concurrent calls on
-        different streams need one each); default: the model's own cached workspace."""
+        different streams need one each); default: the model's own cached workspace.
+        is_optical: multispectral models only (XPoint.py:284-305) — bool per image, True -> optical encoder, False ->
+        thermal encoder (heads are shared); a uniform batch is one call, a mixed batch is gathered per spectrum."""
         if not images.is_cuda:
             raise RuntimeError("xpoint_amd.XPoint runs on the GPU only (no CPU fallback): move the data to 'cuda'")
         if self.training:
@@ -291,19 +309,53 @@ class XPoint(torch.nn.Module):
                     raise RuntimeError(f"XPoint: weights not loaded ({len(missing)} tensors missing, e.g. {missing[:3]})")
                 self._conv_impl = ConvEncoderXPointImpl(self._ref_state, dev)
             return self._conv_impl.forward_raw(images, want_logits=want_logits)
-        if self._blob is None or self._blob.device != dev:
-            self._blob = self.pack_weights().to(dev)
+        thermal = False
+        if self.config['multispectral']:
+            if is_optical is None:
+                raise RuntimeError("multispectral XPoint: forward_raw needs is_optical (one bool per image)")
+            flags = torch.as_tensor(is_optical).reshape(-1).to(torch.bool).cpu()
+            if flags.numel() != images.shape[0]:
+                raise RuntimeError("is_optical must hold one flag per image")
+            if bool(flags.all()):
+                thermal = False
+            elif not bool(flags.any()):
+                thermal = True
+            else:       # mixed batch: run each spectrum's images through its encoder and scatter the results back
+                idx_o = torch.nonzero(flags).reshape(-1).to(dev); idx_t = torch.nonzero(~flags).reshape(-1).to(dev)
+                ro = self.forward_raw(images[idx_o], want_prob, want_desc, want_logits, None, workspace, [True] * int(idx_o.numel()))
+                rt = self.forward_raw(images[idx_t], want_prob, want_desc, want_logits, None, workspace, [False] * int(idx_t.numel()))
+                res = {}
+                for k, v in ro.items():
+                    if v is None:
+                        res[k] = None
+                        continue
+                    full = out[k] if (out is not None and out.get(k) is not None) else torch.empty((images.shape[0],) + tuple(v.shape[1:]), device=dev)
+                    full[idx_o] = v; full[idx_t] = rt[k]
+                    res[k] = full
+                return res
+        if thermal:
+            if self._blob_t is None or self._blob_t.device != dev:
+                self._blob_t = self.pack_weights("thermal").to(dev)
+                self._wsplit_t = None
+        elif self._blob is None or self._blob.device != dev:
+            self._blob = self.pack_weights("optical" if self.config['multispectral'] else None).to(dev)
             self._wsplit = None
         n, _, H, W = images.shape
         lib = _lib.load()
         if self.gemm_mode not in ("x3", "f32"):
             raise RuntimeError(f"XPoint.gemm_mode must be 'x3' or 'f32', got {self.gemm_mode!r}")
-        if self.gemm_mode == "x3" and self._wsplit is None:
+        blob = self._blob_t if thermal else self._blob
+        ws_split = self._wsplit_t if thermal else self._wsplit
+        if self.gemm_mode == "x3" and ws_split is None:
             nb = lib.xp_split_weights_bytes(self._ctx)
-            self._wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
-            _lib.check(lib.xp_prepare_split_weights(self._ctx, ptr(self._blob), ptr(self._wsplit), ctypes.c_size_t(nb),
+            ws_split = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.xp_prepare_split_weights(self._ctx, ptr(blob), ptr(ws_split), ctypes.c_size_t(nb),
                                                     _lib.current_stream()), "xp_prepare_split_weights")
-        wsplit = ptr(self._wsplit) if self.gemm_mode == "x3" else None
+            if thermal:
+                self._wsplit_t = ws_split
+            else:
+                self._wsplit = ws_split
+        wsplit = ptr(ws_split) if self.gemm_mode == "x3" else None
         Hc = c_i(); Wc = c_i(); Ce = c_i()
         _lib.check(lib.xp_forward_shapes(self._ctx, n, H, W, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)), "xp_forward_shapes")
         Hc, Wc, Ce = Hc.value, Wc.value, Ce.value
@@ -316,7 +368,7 @@ class XPoint(torch.nn.Module):
         elif tuple(out["enc_nhwc"].shape) != (n, Hc, Wc, Ce) or (want_prob and out.get("prob") is None) or \
                 (want_desc and out.get("desc_nhwc") is None) or (want_logits and out.get("logits_nhwc") is None):
             raise RuntimeError("forward_raw(out=...): buffers do not match this call")
-        _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(self._blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
+        _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                          ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
                                          _lib.current_stream()), "xp_xpoint_forward")
         return out
@@ -339,19 +391,31 @@ class XPoint(torch.nn.Module):
                'desc_nhwc': raw["desc_nhwc"][sl]}
         return out
 
+    def _flags(self, data):
+        """is_optical column of a reference data dict (XPoint.py:293-296), or None for single-encoder models."""
+        if not self.config['multispectral']:
+            return None
+        f = data['is_optical']
+        if f.dim() == 1:
+            f = f.unsqueeze(0)
+        return f[:, 0]
+
     def forward_impl(self, data):
         lm = self.config['force_return_logits']
-        raw = self.forward_raw(data['image'], want_prob=not lm, want_logits=lm)
+        raw = self.forward_raw(data['image'], want_prob=not lm, want_logits=lm, is_optical=self._flags(data))
         return self._export(raw, slice(0, data['image'].shape[0]))
 
     def forward(self, data):
-        """reference XPoint.py:181-214.  Both spectra share one encoder (multispectral False), so the optical
-        and thermal batches run as ONE 2B-image batch."""
+        """reference XPoint.py:181-214.  With one shared encoder (multispectral False) the optical and thermal batches
+        run as ONE 2B-image batch; with two encoders each spectrum's images go through its own (forward_raw)."""
         if not self.takes_pair():
             return self.forward_impl(data)
         io, it = data["optical"]["image"], data["thermal"]["image"]
         lm = self.config['force_return_logits']
-        raw = self.forward_raw(torch.cat([io, it], 0), want_prob=not lm, want_logits=lm)
+        flags = None
+        if self.config['multispectral']:
+            flags = torch.cat([self._flags(data["optical"]).cpu(), self._flags(data["thermal"]).cpu()], 0)
+        raw = self.forward_raw(torch.cat([io, it], 0), want_prob=not lm, want_logits=lm, is_optical=flags)
         B = io.shape[0]
         pred_optical = self._export(raw, slice(0, B))
         pred_thermal = self._export(raw, slice(B, B + it.shape[0]))

@@ -170,7 +170,9 @@ class PairPipeline:
                 with torch.cuda.stream(stream):
                     sl = slice(h * g, (h + 1) * g)
                     view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
-                    self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h])
+                    fl = self._flags()
+                    self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
+                                         is_optical=None if fl is None else fl[sl])
                     self.encs_done[k][h].record()
                 self.post_stream.wait_event(self.encs_done[k][h])
         else:
@@ -182,6 +184,12 @@ class PairPipeline:
             self._post(k, mask_optical is not None, None)
             self.post_done[k].record()
         return self
+
+    def _flags(self):
+        """multispectral models: the first B images of the batch are optical, the last B thermal."""
+        if not self.net.config.get('multispectral', False):
+            return None
+        return [True] * self.B + [False] * self.B
 
     def _stage_inputs(self, k, optical, thermal, mask_optical, mask_thermal):
         B, H, W = self.B, self.H, self.W
@@ -197,7 +205,7 @@ class PairPipeline:
     def _encode(self, k, optical, thermal):
         if optical is not None:
             self._stage_inputs(k, optical, thermal, None, None)
-        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k])
+        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], is_optical=self._flags())
 
     def _post(self, k, masked=False, _unused=None):
         B, H, W, n = self.B, self.H, self.W, 2 * self.B

@@ -113,39 +113,40 @@ def xpoint_state_spec(cfg: dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str
         spec[prefix + ".running_var"] = ((c,), "bn_var")
         spec[prefix + ".num_batches_tracked"] = ((), "bn_count")
 
-    p = "encoder." if not cfg.get("multispectral", False) else None
-    assert p is not None, "multispectral two-encoder routing is out of scope (SURVEY.md 8f rank 4)"
-    spec[p + "patch_embed.0.weight"] = ((E // 2, 3, 3, 3), "conv_w")
-    spec[p + "patch_embed.0.bias"] = ((E // 2,), "conv_b:27")
-    ln(p + "patch_embed.2", E // 2)
-    spec[p + "patch_embed.5.weight"] = ((E, E // 2, 3, 3), "conv_w")
-    spec[p + "patch_embed.5.bias"] = ((E,), "conv_b:%d" % (9 * (E // 2)))
-    ln(p + "patch_embed.7", E)
-    for s, (C, depth) in enumerate(zip(dims, depths)):
-        R = ranks[s]
-        H4 = int(C * mlp)
-        for j in range(depth):
-            b = f"{p}layers.{s}.blocks.{j}."
-            ln(b + "norm", C)
-            spec[b + "op.x_proj_weight"] = ((4, R + 2 * N, C), "xproj")
-            spec[b + "op.A_logs"] = ((4 * C, N), "A_logs")
-            spec[b + "op.Ds"] = ((4 * C,), "Ds")
-            spec[b + "op.dt_projs_weight"] = ((4, C, R), "dt_w")
-            spec[b + "op.dt_projs_bias"] = ((4, C), "dt_b")
-            ln(b + "op.out_norm", C)
-            spec[b + "op.in_proj.weight"] = ((C, C), "lin_w")
-            spec[b + "op.conv2d.weight"] = ((C, 1, 3, 3), "conv_w")
-            spec[b + "op.out_proj.weight"] = ((C, C), "lin_w")
-            ln(b + "norm2", C)
-            spec[b + "mlp.fc1.weight"] = ((H4, C), "lin_w")
-            spec[b + "mlp.fc1.bias"] = ((H4,), "lin_b")
-            spec[b + "mlp.fc2.weight"] = ((C, H4), "lin_w")
-            spec[b + "mlp.fc2.bias"] = ((C,), "lin_b")
-        if s < len(dims) - 1:
-            d = f"{p}layers.{s}.downsample."
-            spec[d + "1.weight"] = ((2 * C, C, 3, 3), "conv_w")
-            spec[d + "1.bias"] = ((2 * C,), "conv_b:%d" % (9 * C))
-            ln(d + "3", 2 * C)
+    # multispectral (XPoint.py:98-100): two encoders, created thermal first; else one shared encoder
+    prefixes = ["encoder_thermal.", "encoder_optical."] if cfg.get("multispectral", False) else ["encoder."]
+    for p in prefixes:
+        spec[p + "patch_embed.0.weight"] = ((E // 2, 3, 3, 3), "conv_w")
+        spec[p + "patch_embed.0.bias"] = ((E // 2,), "conv_b:27")
+        ln(p + "patch_embed.2", E // 2)
+        spec[p + "patch_embed.5.weight"] = ((E, E // 2, 3, 3), "conv_w")
+        spec[p + "patch_embed.5.bias"] = ((E,), "conv_b:%d" % (9 * (E // 2)))
+        ln(p + "patch_embed.7", E)
+        for s, (C, depth) in enumerate(zip(dims, depths)):
+            R = ranks[s]
+            H4 = int(C * mlp)
+            for j in range(depth):
+                b = f"{p}layers.{s}.blocks.{j}."
+                ln(b + "norm", C)
+                spec[b + "op.x_proj_weight"] = ((4, R + 2 * N, C), "xproj")
+                spec[b + "op.A_logs"] = ((4 * C, N), "A_logs")
+                spec[b + "op.Ds"] = ((4 * C,), "Ds")
+                spec[b + "op.dt_projs_weight"] = ((4, C, R), "dt_w")
+                spec[b + "op.dt_projs_bias"] = ((4, C), "dt_b")
+                ln(b + "op.out_norm", C)
+                spec[b + "op.in_proj.weight"] = ((C, C), "lin_w")
+                spec[b + "op.conv2d.weight"] = ((C, 1, 3, 3), "conv_w")
+                spec[b + "op.out_proj.weight"] = ((C, C), "lin_w")
+                ln(b + "norm2", C)
+                spec[b + "mlp.fc1.weight"] = ((H4, C), "lin_w")
+                spec[b + "mlp.fc1.bias"] = ((H4,), "lin_b")
+                spec[b + "mlp.fc2.weight"] = ((C, H4), "lin_w")
+                spec[b + "mlp.fc2.bias"] = ((C,), "lin_b")
+            if s < len(dims) - 1:
+                d = f"{p}layers.{s}.downsample."
+                spec[d + "1.weight"] = ((2 * C, C, 3, 3), "conv_w")
+                spec[d + "1.bias"] = ((2 * C,), "conv_b:%d" % (9 * C))
+                ln(d + "3", 2 * C)
     enc_c = E // 2
     if cfg.get("homography_regression_head", {}).get("check", False):
         spec["hm_regressor.layer1.0.weight"] = ((96, enc_c, 3, 3), "conv_w")
