@@ -287,6 +287,10 @@ def main():
         print("480x640", spec, "candidates", int((r["prob"] > 0.015).sum()), "kpts", len(kp), "pmax", float(p.max()))
     np.savez_compressed(os.path.join(OUT, "g10_full480x640.npz"), **g10)
 
+    gen_g12(); gen_g13(); gen_g14()
+    manifest["generators"] = {"g1..g11": "main()", "g12_conv_xpoint.npz": "gen_g12()",
+                              "g13_eval_metrics.npz": "gen_g13() (reference benchmark_evaluation.py functions; cv2 stand-ins in stubs.py)",
+                              "g14_multispectral.npz": "gen_g14()"}
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             manifest["files"][f] = os.path.getsize(os.path.join(OUT, f))
