@@ -168,6 +168,18 @@ def main():
         lib.xp_prof_enable(0)
         dom = [r for r in prof_table() if r["tag"] == dominant][0]
         pipe.verify()
+        # the same K steps on ONE stream (no cross-step overlap), for the record
+        single_rate = None
+        if overlap:
+            for _ in range(2):
+                pipe1.run(opt, thr, mo, mt)
+            sync_all()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe1.run(opt, thr, mo, mt)
+            sync_all()
+            single_rate = world * B * args.steps / (time.perf_counter() - t3)
+            pipe1.verify()
         # the same step on the other dense-layer back end, for the record (never the headline value)
         other = "f32" if args.gemm == "x3" else "x3"
         other_rate = None
@@ -268,6 +280,8 @@ def main():
                        "matches_per_pair_mean": round(sum(len(r["match_q"]) for r in res) / len(res), 1)},
             "roofline": roof,
         }
+        if single_rate is not None:
+            out["single_stream"] = {"pairs_per_s": round(single_rate, 2), "note": "same steps enqueued on one HIP stream (bench.py --no-overlap)"}
         if other_rate is not None:
             out["other_gemm_backend"] = {"gemm": other, "pairs_per_s": round(other_rate, 2),
                                          "note": "same step with the dense layers on the " + ("exact-f32 MFMA kernels" if other == "f32" else "split-bf16 kernels")}
