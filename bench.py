@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (images uploaded from pinned host memory every step); never the headline value")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--split-encoder", type=int, default=2, help="encoder as S image groups on S streams (0/1 = whole batch on one stream); needs overlap")
+    ap.add_argument("--register", action="store_true", help="also run the registration step (robust homography per pair) inside every step; not part of the headline metric's definition")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: no overlap of step i's detection / matching kernels with step i+1's encoder")
     ap.add_argument("--no-other-backend", action="store_true", help="skip the extra timing passes (other dense-layer back end, single-stream rate): keeps profiler output to the headline configuration")
     ap.add_argument("--gemm", choices=["x3", "f32"], default=os.environ.get("XP_GEMM_MODE", "x3"),
@@ -104,7 +105,7 @@ def main():
     opt, thr = data["optical"]["image"], data["thermal"]["image"]
     mo, mt = data["optical"]["valid_mask"], data["thermal"]["valid_mask"]
     overlap = not args.no_overlap and not args.graph
-    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=overlap, split_encoder=args.split_encoder)
+    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=overlap, split_encoder=args.split_encoder, estimate_homography=args.register)
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
     pipe1 = PairPipeline(net, B, H, W, cap=8192) if overlap else pipe

@@ -187,6 +187,11 @@ int xp_points_min_dist(const double* a, int na, const float* b, int nb, float* o
  * different — deterministic — estimator (hash-seeded 4-point DLT hypotheses, MSAC score, least-squares refinement):
  * not bit-comparable with OpenCV.
  *   src, dst (pairs, cap, 2) f32 (x, y); counts (pairs) int32 or NULL; H (pairs, 9) f64; mask (pairs, cap) u8. */
+/* Correspondences of the mutual matches for xp_find_homography (counts = match_count): kp (2*pairs, cap, 2) int32 (y, x),
+ * optical images first; src / dst (pairs, cap, 2) f32 (x, y) — the optical_pts / thermal_pts lists of
+ * predict_align_image_pair.py:283-284 built on the device. */
+int xp_gather_match_points(const int* kp, const int* match_q, const int* match_t, const int* match_count, int pairs, int cap,
+                           float* src, float* dst, void* stream);
 size_t xp_find_homography_workspace_bytes(int pairs);
 int xp_find_homography(const float* src, const float* dst, const int* counts, int pairs, int cap, float reproj_thr,
                        int max_iters, unsigned seed, double* H, uint8_t* mask, int* n_inliers, void* workspace,

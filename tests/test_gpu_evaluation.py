@@ -160,3 +160,25 @@ def test_predict_align_image_pair_with_registration(gpu_lib):
         _, _, res = predict_align_image_pair(net, d, estimate_homography=True)
     r = res[0]
     assert len(r["matches"]) >= 4 and np.abs(r["H_est"] - np.eye(3)).max() < 1e-6 and sum(r["matchesMask"]) == len(r["matches"])
+
+
+def test_pairpipeline_device_registration(gpu_lib):
+    """PairPipeline(estimate_homography=True): the registration step runs on the device from the match lists (no host
+    round trip) and agrees with the per-pair host-facing call on the same matches."""
+    from xpoint_amd import models, utils
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 96, 128, 2
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = models.XPoint(cfg)
+    net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
+    net = net.to("cuda").eval()
+    d = synth.to_torch(synth.make_pair_batch(0, B, H, W), "cuda")
+    d["thermal"]["image"] = torch.roll(d["optical"]["image"], shifts=(0, 0), dims=(2, 3)).clone()       # identical spectra
+    with torch.no_grad():
+        out = PairPipeline(net, B, H, W, cap=2048, estimate_homography=True).run(d["optical"]["image"], d["thermal"]["image"]).fetch()
+    for r in out:
+        assert r["n_inliers"] == len(r["match_q"]) == int(r["matchesMask"].sum()) and r["n_inliers"] >= 4
+        assert np.abs(r["H_est"] - np.eye(3)).max() < 1e-6
+        src = r["kp_optical"][r["match_q"]].flip(-1).float(); dst = r["kp_thermal"][r["match_t"]].flip(-1).float()
+        H2, m2 = utils.find_homography(src, dst, 3.0)
+        assert np.array_equal(H2, r["H_est"]) and np.array_equal(m2.ravel(), r["matchesMask"])

@@ -251,7 +251,39 @@ __global__ __launch_bounds__(256) void hg_refine_kernel(const float* __restrict_
     if (threadIdx.x < 9) Ho[threadIdx.x] = H[threadIdx.x] * sc;
 }
 
+// correspondences of the mutual matches: src = optical keypoint (x, y) of match_q, dst = thermal keypoint (x, y) of match_t
+__global__ __launch_bounds__(256) void gather_match_points_kernel(const int* __restrict__ kp, const int* __restrict__ mq, const int* __restrict__ mt,
+                                                                  const int* __restrict__ mcount, int pairs, int cap, float* __restrict__ src,
+                                                                  float* __restrict__ dst) {
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const int n = min(mcount[pair], cap);
+    float2 a = make_float2(0.f, 0.f), b = a;
+    if (i < n) {
+        const int q = mq[(size_t)pair * cap + i], t = mt[(size_t)pair * cap + i];
+        const int* ko = kp + ((size_t)pair * cap + q) * 2;                  // optical image `pair`
+        const int* kt = kp + ((size_t)(pairs + pair) * cap + t) * 2;        // thermal image `pairs + pair`
+        a = make_float2((float)ko[1], (float)ko[0]);                        // (y, x) -> (x, y), as cv2.KeyPoint(c[1], c[0], 1)
+        b = make_float2((float)kt[1], (float)kt[0]);
+    }
+    reinterpret_cast<float2*>(src)[(size_t)pair * cap + i] = a;
+    reinterpret_cast<float2*>(dst)[(size_t)pair * cap + i] = b;
+}
+
 }  // namespace
+
+// kp (2*pairs, cap, 2) int32 (y, x): optical images first, then thermal (PairPipeline layout); match_q / match_t (pairs, cap),
+// match_count (pairs) from xp_match_mnn -> src / dst (pairs, cap, 2) f32 (x, y) for xp_find_homography (counts = match_count).
+extern "C" int xp_gather_match_points(const int* kp, const int* match_q, const int* match_t, const int* match_count, int pairs, int cap,
+                                      float* src, float* dst, void* stream) {
+    XP_CHECK_ARG(kp && match_q && match_t && match_count && src && dst, "xp_gather_match_points: null pointer");
+    XP_CHECK_ARG(pairs > 0 && cap > 0, "xp_gather_match_points: bad shape");
+    XpProfScope prof("gather_match_points", (hipStream_t)stream, 0.0, 0.0);
+    hipLaunchKernelGGL(gather_match_points_kernel, dim3(xp_cdiv(cap, 256), pairs), dim3(256), 0, (hipStream_t)stream, kp, match_q, match_t,
+                       match_count, pairs, cap, src, dst);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
 
 extern "C" size_t xp_find_homography_workspace_bytes(int pairs) { return pairs > 0 ? (size_t)pairs * (sizeof(Norm) + 8) + 64 : 0; }
 

@@ -95,7 +95,7 @@ class PairPipeline:
     synchronises, checks NMS convergence / capacity and returns host lists."""
 
     def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=6, overlap=False,
-                 split_encoder=False):
+                 split_encoder=False, estimate_homography=False, ransac_iters=10000):
         """overlap=True: two HIP streams — the encoder of call i+1 runs while the detection / matching kernels of call i
         (many small, latency-bound launches) are still in flight; encoder outputs are double-buffered.  Results of a
         call are complete after fetch() / torch.cuda.synchronize(), exactly as without overlap."""
@@ -143,6 +143,14 @@ class PairPipeline:
                       match_t=torch.empty((P, self.cap), dtype=torch.int32, device=dev),
                       match_d=torch.empty((P, self.cap), device=dev), match_count=torch.zeros((P,), dtype=torch.int32, device=dev))
         self.match_ws = torch.empty(lib.xp_match_workspace_bytes(P, self.cap, self.cap, D), dtype=torch.uint8, device=dev)
+        # optional registration step (predict_align_image_pair.py:283-303) on the device: one batched robust fit per pair
+        self.estimate_homography = bool(estimate_homography)
+        self.ransac_iters = int(ransac_iters)
+        if self.estimate_homography:
+            self.hg = dict(src=torch.empty((P, self.cap, 2), device=dev), dst=torch.empty((P, self.cap, 2), device=dev),
+                           H=torch.empty((P, 3, 3), dtype=torch.float64, device=dev), mask=torch.empty((P, self.cap), dtype=torch.uint8, device=dev),
+                           n_inliers=torch.zeros((P,), dtype=torch.int32, device=dev),
+                           ws=torch.empty(lib.xp_find_homography_workspace_bytes(P) // 8 + 1, dtype=torch.float64, device=dev))
         self.raw = None
 
     def run(self, optical, thermal, mask_optical=None, mask_thermal=None):
@@ -235,6 +243,13 @@ class PairPipeline:
                                     utils.MATCH_MODES[self.mode], ptr(m["idx12"]), ptr(m["dist12"]), ptr(m["idx21"]), ptr(m["dist21"]),
                                     ptr(m["match_q"]), ptr(m["match_t"]), ptr(m["match_d"]), ptr(m["match_count"]),
                                     ptr(self.match_ws), self.match_ws.numel(), st), "xp_match_mnn")
+        if self.estimate_homography:
+            h = self.hg
+            _lib.check(lib.xp_gather_match_points(ptr(self.kp), ptr(m["match_q"]), ptr(m["match_t"]), ptr(m["match_count"]), B, self.cap,
+                                                  ptr(h["src"]), ptr(h["dst"]), st), "xp_gather_match_points")
+            _lib.check(lib.xp_find_homography(ptr(h["src"]), ptr(h["dst"]), ptr(m["match_count"]), B, self.cap,
+                                              float(self.pred.get('reprojection_threshold', 3.0)), self.ransac_iters, 0, ptr(h["H"]), ptr(h["mask"]),
+                                              ptr(h["n_inliers"]), ptr(h["ws"]), h["ws"].numel() * 8, st), "xp_find_homography")
         return self
 
     def wait(self):
@@ -281,7 +296,11 @@ class PairPipeline:
         out = []
         for i in range(B):
             no, nt, nm = int(counts[i]), int(counts[B + i]), int(mc[i])
-            out.append(dict(kp_optical=self.kp[i, :no].cpu().long(), kp_thermal=self.kp[B + i, :nt].cpu().long(),
+            extra = {}
+            if self.estimate_homography:
+                extra = dict(H_est=self.hg["H"][i].cpu().numpy(), matchesMask=self.hg["mask"][i, :nm].cpu().numpy(),
+                             n_inliers=int(self.hg["n_inliers"][i].item()))
+            out.append(dict(extra, kp_optical=self.kp[i, :no].cpu().long(), kp_thermal=self.kp[B + i, :nt].cpu().long(),
                             desc_optical=self.desc[i, :no].cpu(), desc_thermal=self.desc[B + i, :nt].cpu(),
                             match_q=self.m["match_q"][i, :nm].cpu().numpy(), match_t=self.m["match_t"][i, :nm].cpu().numpy(),
                             match_d=self.m["match_d"][i, :nm].cpu().numpy(),
