@@ -108,7 +108,7 @@ def main():
     pipe = PairPipeline(net, B, H, W, cap=8192, overlap=overlap, split_encoder=args.split_encoder, estimate_homography=args.register)
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
-    pipe1 = PairPipeline(net, B, H, W, cap=8192) if overlap else pipe
+    pipe1 = PairPipeline(net, B, H, W, cap=8192, estimate_homography=args.register) if overlap else pipe
 
     def sync_all():
         torch.cuda.synchronize()
