@@ -182,3 +182,31 @@ def test_pairpipeline_device_registration(gpu_lib):
         src = r["kp_optical"][r["match_q"]].flip(-1).float(); dst = r["kp_thermal"][r["match_t"]].flip(-1).float()
         H2, m2 = utils.find_homography(src, dst, 3.0)
         assert np.array_equal(H2, r["H_est"]) and np.array_equal(m2.ravel(), r["matchesMask"])
+
+
+def test_evaluation_and_homography_edge_cases(gpu_lib):
+    """Empty keypoint sets, collinear correspondences and duplicate points: no crash, no NaN, the documented 'no model' result."""
+    from xpoint_amd import evaluation as ev, utils
+    B, H, W = 1, 64, 96
+    zero = torch.zeros((B, 1, H, W)).cuda()
+    one = zero.clone(); one[0, 0, 10, 20] = 0.9; one[0, 0, 30, 40] = 0.5
+    eye = torch.eye(3).repeat(B, 1, 1)
+    data = {"optical": {"image": torch.zeros((B, 1, H, W)), "valid_mask": torch.ones((B, 1, H, W)).cuda(), "homography": eye},
+            "thermal": {"image": torch.zeros((B, 1, H, W)), "valid_mask": torch.ones((B, 1, H, W)).cuda(), "homography": eye}}
+    rep, nko, nkt = ev.compute_repeatability_for_sample({"prob": zero}, {"prob": zero}, data, eye, eye, 0.015, [3])
+    assert rep[3] == [] and nko == [0] and nkt == [0]                      # reference: nothing appended when both sets are empty
+    rep, nko, nkt = ev.compute_repeatability_for_sample({"prob": one}, {"prob": zero}, data, eye, eye, 0.015, [3])
+    assert rep[3] == [0.0] and nko == [2] and nkt == [0]
+    desc = torch.nn.functional.normalize(torch.randn((B, 256, H // 8, W // 8)), dim=1).cuda()
+    dd = ev.compute_descriptor_for_sample(one, zero, desc, desc, data, {"prediction": {"matching": {"method": "bfmatcher", "knn_matches": False,
+                                          "method_kwargs": {"crossCheck": True}}}}, 0.015, [2])
+    assert dd[2]["tp_optical"] == [] and dd[2]["m_score_optical"] == [0.0] and dd[2]["n_gt_optical"] == 0
+    # collinear correspondences: every 4-point sample is degenerate -> no model
+    x = np.linspace(0, 100, 50, dtype=np.float32)
+    src = np.stack([x, 2 * x + 1], 1); dst = np.stack([x + 3, 2 * x + 5], 1)
+    Hc, mc = utils.find_homography(src, dst, 3.0, max_iters=512)
+    assert Hc is None and int(mc.sum()) == 0
+    # all correspondences identical points
+    src = np.full((20, 2), 5.0, np.float32)
+    Hd, md = utils.find_homography(src, src, 3.0, max_iters=256)
+    assert Hd is None or np.isfinite(Hd).all()
