@@ -121,6 +121,29 @@ def test_gemm_nt_x3(gpu_lib, M, N, K, act, res):
     assert err <= 2.0 * err32 + 1e-7, (err, err32)
 
 
+def test_gemm_x3_error_bound_wide_dynamic_range(gpu_lib):
+    """The split-bf16 GEMM is an f32-grade GEMM: |C - exact| <= c * eps_f32 * sum_k |a||w| element-wise, on operands spanning
+    12 orders of magnitude with heavy cancellation — the same bound, with the same constant, as the exact-f32 MFMA kernel
+    (the dropped partial products are 2^-24 each, the f32 accumulation rounding dominates both)."""
+    L = _lib()
+    M, N, K = 384, 256, 768
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (M, K), generator=g).float())
+    Wt = torch.randn(N, K, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (N, K), generator=g).float())
+    ref = A.double() @ Wt.double().t()
+    bound = (A.double().abs() @ Wt.double().abs().t())          # sum_k |a||w|
+    Ad, Wd = A.cuda(), Wt.cuda()
+    Wx = _split_x3(L, Wd)
+    C3 = torch.empty((M, N), device="cuda"); C32 = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt_x3", L.ptr(Ad), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C3), None, None, None, None, M, N, K, K, N, 0, 0, L.current_stream())
+    L.call("xp_gemm_nt", L.ptr(Ad), L.ptr(Wd), L.ptr(C32), None, None, None, None, M, N, K, K, N, 0, 0, L.current_stream())
+    eps = 2.0 ** -24
+    r3 = float(((C3.cpu().double() - ref).abs() / bound).max()) / eps
+    r32 = float(((C32.cpu().double() - ref).abs() / bound).max()) / eps
+    assert r3 < 64.0 and r32 < 64.0, (r3, r32)        # measured 19 and 16: a few ulps of the magnitude sum, far below the K * eps = 768 worst case
+    assert r3 <= 2.0 * r32 + 1.0, (r3, r32)
+
+
 def test_gemm_x3_scale_shift_lda(gpu_lib):
     L = _lib()
     M, N, K, lda = 257, 65, 256, 512
