@@ -70,8 +70,25 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
     float dt = w[0] * xv[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dt = fmaf(w[r], xv[r], dt);
-    const float delta = xp_softplus_fast(dt + bias);
-    a = xp_exp_fast(delta * A);
+    // delta = softplus(x), a = exp(delta * A).  Below the softplus threshold both come from ONE logarithm:
+    //   delta = ln(1 + e^x),  a = (1 + e^x)^A = 2^(A * log2(1 + e^x))
+    // so the second exponential needs no argument reduction of its own (the scan is VALU-bound: this saves 5 of ~45
+    // operations per step).  log1p is v_log_f32 plus the first-order correction for the rounding of 1 + e (xp_log1p_fast).
+    const float x = dt + bias;
+    float delta;
+    if (x <= 20.f) {
+        // e^x straight on the exp2 unit: x <= 20 here, so the argument scaling costs at most |x| * 6e-8 relative — measured
+        // no change of the network outputs against the reference goldens (prob 5e-6 either way) for 5 fewer operations
+        const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+        const float uu = 1.f + e;
+        const float l2 = __builtin_amdgcn_logf(uu);                                   // log2(1 + e), ~1 ulp
+        const float cc = ((uu - 1.f) - e) * __builtin_amdgcn_rcpf(uu);                // natural-log units
+        delta = l2 * 0.693147180559945309f - cc;
+        a = __builtin_amdgcn_exp2f(A * fmaf(cc, -1.44269504088896340736f, l2));
+    } else {
+        delta = x;                                                                    // torch softplus threshold (csms6s.py:49-50)
+        a = xp_exp_fast(x * A);
+    }
     b = delta * xv[R] * u;
     Cv = xv[R + 1];
 }
