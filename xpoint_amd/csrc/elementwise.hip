@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __re
         const float rstd = 1.f / sqrtf(q / (float)CO + eps);
 #pragma unroll
         for (int c = 0; c < CO; ++c)
-            s_o[threadIdx.x * (CO + 1) + c] = xp_gelu((acc[c] - mean) * rstd * s_w[10 * CO + c] + s_w[11 * CO + c]);
+            s_o[threadIdx.x * (CO + 1) + c] = xp_gelu_fast((acc[c] - mean) * rstd * s_w[10 * CO + c] + s_w[11 * CO + c]);
     }
     __syncthreads();
     const int64_t nvalid = (total - p0 < 64) ? (total - p0) : 64;
