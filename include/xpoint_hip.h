@@ -84,6 +84,17 @@ int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* b
                        const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
                        int act, void* stream);
 
+/* Fused VSS-block MLP branch, in place:  X <- X + fc2(GELU(fc1(LayerNorm(X)) + b1)) + b2   (reference
+ * VMamba.py:1230-1234 VSSBlock.forward second residual, :110-128 Mlp; LayerNorm over C, biased variance, eps;
+ * exact-erf GELU).  One launch replaces xp_layernorm + two xp_gemm_nt_x3 calls; the (M, hidden) activation is never
+ * written to memory (it goes from the fc1 accumulators to the fc2 operand registers).  Same split-bf16 arithmetic
+ * as xp_gemm_nt_x3: W1x3 / W2x3 are fc1.weight (hidden, C) and fc2.weight (C, hidden) in xp_split_weights_x3
+ * layout.  Supported shapes: xp_mlp_fused_x3_supported(C, hidden) != 0 (C in {32, 64, 96}, hidden % 32 == 0);
+ * other shapes return an argument error — callers use the three separate entry points there. */
+int xp_mlp_fused_x3_supported(int C, int hidden);
+int xp_mlp_fused_x3(float* X, const float* ln_w, const float* ln_b, const void* W1x3, const float* b1,
+                    const void* W2x3, const float* b2, int M, int C, int hidden, float eps, void* stream);
+
 /* Glue kernels (HBM-bound). */
 int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps, int gelu,
                  void* stream);

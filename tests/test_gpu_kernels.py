@@ -121,6 +121,42 @@ def test_gemm_nt_x3(gpu_lib, M, N, K, act, res):
     assert err <= 2.0 * err32 + 1e-7, (err, err32)
 
 
+@pytest.mark.parametrize("M,C,H4", [(128, 96, 384), (300, 96, 384), (1000, 32, 128), (517, 64, 256), (4480, 96, 384), (77, 96, 96)])
+def test_mlp_fused_x3(gpu_lib, M, C, H4):
+    """x + fc2(GELU(fc1(LN(x)))) in one launch (VMamba.py:1230-1234, :110-128) vs fp64 torch, and vs the three-launch form
+    (xp_layernorm + 2 x xp_gemm_nt_x3) it replaces: same arithmetic, so agreement to f32 rounding.  Ragged M included."""
+    L = _lib()
+    X = _u(f"mx{M}{C}", (M, C), -2.0, 2.0); lw = _u(f"mlw{C}", (C,), 0.5, 1.5); lb = _u(f"mlb{C}", (C,), -0.5, 0.5)
+    W1 = _u(f"mw1{C}{H4}", (H4, C), -0.2, 0.2); b1 = _u(f"mb1{H4}", (H4,), -0.5, 0.5)
+    W2 = _u(f"mw2{C}{H4}", (C, H4), -0.1, 0.1); b2 = _u(f"mb2{C}", (C,), -0.5, 0.5)
+    Xd = X.double()
+    ref = Xd + F.linear(F.gelu(F.linear(F.layer_norm(Xd, (C,), lw.double(), lb.double(), 1e-5), W1.double(), b1.double())), W2.double(), b2.double())
+    assert L.load().xp_mlp_fused_x3_supported(C, H4) == 1
+    Xg = X.cuda(); lwd, lbd, b1d, b2d = lw.cuda(), lb.cuda(), b1.cuda(), b2.cuda()
+    W1x, W2x = _split_x3(L, W1.cuda()), _split_x3(L, W2.cuda())
+    st = L.current_stream()
+    L.call("xp_mlp_fused_x3", L.ptr(Xg), L.ptr(lwd), L.ptr(lbd), ctypes.c_void_p(W1x.data_ptr()), L.ptr(b1d),
+           ctypes.c_void_p(W2x.data_ptr()), L.ptr(b2d), M, C, H4, 1e-5, st)
+    err = float((Xg.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    # the three-launch form
+    X3 = X.cuda(); T = torch.empty((M, C), device="cuda"); Hb = torch.empty((M, H4), device="cuda")
+    L.call("xp_layernorm", L.ptr(X3), L.ptr(T), L.ptr(lwd), L.ptr(lbd), M, C, 1e-5, 0, st)
+    L.call("xp_gemm_nt_x3", L.ptr(T), ctypes.c_void_p(W1x.data_ptr()), L.ptr(Hb), L.ptr(b1d), None, None, None, M, H4, C, C, H4, 0, 1, st)
+    L.call("xp_gemm_nt_x3", L.ptr(Hb), ctypes.c_void_p(W2x.data_ptr()), L.ptr(X3), L.ptr(b2d), None, None, L.ptr(X3), M, C, H4, H4, C, C, 0, st)
+    err3 = float((X3.cpu().double() - ref).abs().max())
+    assert err <= 2.0 * err3 + 1e-6, (err, err3)
+    assert float((Xg - X3).abs().max()) < 1e-5
+
+
+def test_mlp_fused_x3_rejects_unsupported(gpu_lib):
+    L = _lib()
+    assert L.load().xp_mlp_fused_x3_supported(192, 768) == 0
+    X = torch.zeros((8, 192), device="cuda")
+    with pytest.raises(Exception):
+        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), 8, 192, 768, 1e-5, L.current_stream())
+
+
 def test_gemm_x3_error_bound_wide_dynamic_range(gpu_lib):
     """The split-bf16 GEMM is an f32-grade GEMM: |C - exact| <= c * eps_f32 * sum_k |a||w| element-wise, on operands spanning
     12 orders of magnitude with heavy cancellation — the same bound, with the same constant, as the exact-f32 MFMA kernel

@@ -1,0 +1,36 @@
+"""Micro-benchmark: fused VSS-block MLP (xp_mlp_fused_x3) vs the three launches it replaces, at the model's shapes."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from xpoint_amd import _lib as L
+shapes = [(307200, 96, 384), (76800, 64, 256), (19200, 96, 384)]
+torch.manual_seed(0)
+st = L.current_stream()
+def split(W):
+    N, K = W.shape
+    o = torch.empty(L.load().xp_split_weights_x3_bytes(N, K), dtype=torch.uint8, device="cuda")
+    L.call("xp_split_weights_x3", L.ptr(W), ctypes.c_void_p(o.data_ptr()), N, K, st)
+    return o
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for (M, C, H4) in shapes:
+    X = torch.randn(M, C, device="cuda"); lw = torch.ones(C, device="cuda"); lb = torch.zeros(C, device="cuda")
+    W1 = torch.randn(H4, C, device="cuda") * 0.05; b1 = torch.randn(H4, device="cuda") * 0.1
+    W2 = torch.randn(C, H4, device="cuda") * 0.05; b2 = torch.randn(C, device="cuda") * 0.1
+    W1x, W2x = split(W1), split(W2)
+    T = torch.empty(M, C, device="cuda"); Hb = torch.empty(M, H4, device="cuda")
+    p1, p2 = ctypes.c_void_p(W1x.data_ptr()), ctypes.c_void_p(W2x.data_ptr())
+    def fused():
+        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(lw), L.ptr(lb), p1, L.ptr(b1), p2, L.ptr(b2), M, C, H4, 1e-5, st)
+    def three():
+        L.call("xp_layernorm", L.ptr(X), L.ptr(T), L.ptr(lw), L.ptr(lb), M, C, 1e-5, 0, st)
+        L.call("xp_gemm_nt_x3", L.ptr(T), p1, L.ptr(Hb), L.ptr(b1), None, None, None, M, H4, C, C, H4, 0, 1, st)
+        L.call("xp_gemm_nt_x3", L.ptr(Hb), p2, L.ptr(X), L.ptr(b2), None, None, L.ptr(X), M, C, H4, H4, C, C, 0, st)
+    tf, t3 = timeit(fused), timeit(three)
+    fl = 4.0 * M * C * H4
+    print(f"M {M:7d} C {C:4d} H {H4:5d}: fused {tf*1e3:8.1f} us {fl/tf/1e9:7.1f} TF/s | 3 launches {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF/s | x{t3/tf:.2f}", flush=True)

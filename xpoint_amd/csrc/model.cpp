@@ -2,6 +2,7 @@
 // VMamba encoder, VMamba.py:1507-1525): a fixed sequence of kernel launches on one HIP stream.
 // The context is host-only metadata (model dims + the device-format parameter table); weights and
 // workspace are caller-owned device buffers, so the library never allocates device memory.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -213,6 +214,9 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     };
     const float eps = 1e-5f;
     const int E = c->cfg.embed_dim;
+    // split-bf16 back end only; XP_NO_FUSED_MLP=1 keeps the three-launch form (A/B timing, tests)
+    static const bool no_fused_mlp = getenv("XP_NO_FUSED_MLP") != nullptr && atoi(getenv("XP_NO_FUSED_MLP")) != 0;
+    const bool fuse_mlp = wsplit != nullptr && !no_fused_mlp;
 
     // patch embed (VMamba.py:1405-1420)
     RUN(xp_stem_conv_ln_gelu(images, P("stem.w"), P("stem.b"), P("stem.ln_w"), P("stem.ln_b"), HB, batch, H, W, E / 2, eps, stream));
@@ -234,6 +238,12 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
                                  T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
             RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
             // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
+            if (fuse_mlp && xp_mlp_fused_x3_supported(C, H4)) {
+                // one launch, the (M, 4C) hidden activation stays in registers (csrc/mlp_fused.hip)
+                RUN(xp_mlp_fused_x3(X, P(b + "ln2_w"), P(b + "ln2_b"), (const char*)wsplit + c->split_off(b + "fc1_w"), P(b + "fc1_b"),
+                                    (const char*)wsplit + c->split_off(b + "fc2_w"), P(b + "fc2_b"), M, C, H4, eps, stream));
+                continue;
+            }
             RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
             RUN(gemm(T1, b + "fc1_w", HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
             RUN(gemm(HB, b + "fc2_w", X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));
