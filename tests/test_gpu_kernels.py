@@ -121,7 +121,7 @@ def test_gemm_nt_x3(gpu_lib, M, N, K, act, res):
     assert err <= 2.0 * err32 + 1e-7, (err, err32)
 
 
-@pytest.mark.parametrize("M,C,H4", [(128, 96, 384), (300, 96, 384), (1000, 32, 128), (517, 64, 256), (4480, 96, 384), (77, 96, 96)])
+@pytest.mark.parametrize("M,C,H4", [(128, 96, 384), (300, 96, 384), (1000, 32, 128), (517, 64, 256), (4480, 96, 384), (77, 96, 96), (200, 64, 64), (130, 32, 512)])
 def test_mlp_fused_x3(gpu_lib, M, C, H4):
     """x + fc2(GELU(fc1(LN(x)))) in one launch (VMamba.py:1230-1234, :110-128) vs fp64 torch, and vs the three-launch form
     (xp_layernorm + 2 x xp_gemm_nt_x3) it replaces: same arithmetic, so agreement to f32 rounding.  Ragged M included."""
@@ -135,8 +135,9 @@ def test_mlp_fused_x3(gpu_lib, M, C, H4):
     Xg = X.cuda(); lwd, lbd, b1d, b2d = lw.cuda(), lb.cuda(), b1.cuda(), b2.cuda()
     W1x, W2x = _split_x3(L, W1.cuda()), _split_x3(L, W2.cuda())
     st = L.current_stream()
-    L.call("xp_mlp_fused_x3", L.ptr(Xg), L.ptr(lwd), L.ptr(lbd), ctypes.c_void_p(W1x.data_ptr()), L.ptr(b1d),
-           ctypes.c_void_p(W2x.data_ptr()), L.ptr(b2d), M, C, H4, 1e-5, st)
+    pack = torch.empty(L.load().xp_mlp_fused_x3_pack_bytes(C, H4), dtype=torch.uint8, device="cuda")
+    L.call("xp_mlp_fused_x3_pack", ctypes.c_void_p(W1x.data_ptr()), ctypes.c_void_p(W2x.data_ptr()), ctypes.c_void_p(pack.data_ptr()), C, H4, st)
+    L.call("xp_mlp_fused_x3", L.ptr(Xg), L.ptr(lwd), L.ptr(lbd), ctypes.c_void_p(pack.data_ptr()), L.ptr(b1d), L.ptr(b2d), M, C, H4, 1e-5, st)
     err = float((Xg.cpu().double() - ref).abs().max())
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
     # the three-launch form
@@ -154,7 +155,7 @@ def test_mlp_fused_x3_rejects_unsupported(gpu_lib):
     assert L.load().xp_mlp_fused_x3_supported(192, 768) == 0
     X = torch.zeros((8, 192), device="cuda")
     with pytest.raises(Exception):
-        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), 8, 192, 768, 1e-5, L.current_stream())
+        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), 8, 192, 768, 1e-5, L.current_stream())
 
 
 def test_gemm_x3_error_bound_wide_dynamic_range(gpu_lib):

@@ -3,6 +3,9 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from xpoint_amd import _lib as L
 shapes = [(307200, 96, 384), (76800, 64, 256), (19200, 96, 384)]
+if os.environ.get("MLP_ONLY"):
+    shapes = [shapes[int(i)] for i in os.environ["MLP_ONLY"].split(",")]
+FUSED_ONLY = os.environ.get("MLP_FUSED_ONLY") == "1"
 torch.manual_seed(0)
 st = L.current_stream()
 def split(W):
@@ -25,12 +28,15 @@ for (M, C, H4) in shapes:
     W1x, W2x = split(W1), split(W2)
     T = torch.empty(M, C, device="cuda"); Hb = torch.empty(M, H4, device="cuda")
     p1, p2 = ctypes.c_void_p(W1x.data_ptr()), ctypes.c_void_p(W2x.data_ptr())
+    pack = torch.empty(L.load().xp_mlp_fused_x3_pack_bytes(C, H4), dtype=torch.uint8, device="cuda")
+    pk = ctypes.c_void_p(pack.data_ptr())
+    L.call("xp_mlp_fused_x3_pack", p1, p2, pk, C, H4, st)
     def fused():
-        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(lw), L.ptr(lb), p1, L.ptr(b1), p2, L.ptr(b2), M, C, H4, 1e-5, st)
+        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(lw), L.ptr(lb), pk, L.ptr(b1), L.ptr(b2), M, C, H4, 1e-5, st)
     def three():
         L.call("xp_layernorm", L.ptr(X), L.ptr(T), L.ptr(lw), L.ptr(lb), M, C, 1e-5, 0, st)
         L.call("xp_gemm_nt_x3", L.ptr(T), p1, L.ptr(Hb), L.ptr(b1), None, None, None, M, H4, C, C, H4, 0, 1, st)
         L.call("xp_gemm_nt_x3", L.ptr(Hb), p2, L.ptr(X), L.ptr(b2), None, None, L.ptr(X), M, C, H4, H4, C, C, 0, st)
-    tf, t3 = timeit(fused), timeit(three)
+    tf = timeit(fused); t3 = tf if FUSED_ONLY else timeit(three)
     fl = 4.0 * M * C * H4
     print(f"M {M:7d} C {C:4d} H {H4:5d}: fused {tf*1e3:8.1f} us {fl/tf/1e9:7.1f} TF/s | 3 launches {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF/s | x{t3/tf:.2f}", flush=True)

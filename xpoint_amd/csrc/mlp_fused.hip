@@ -6,34 +6,42 @@
 // Arithmetic = the split-bf16 engine of gemm_x3_core.h (every f32 operand is the exact sum of three bf16 values, six
 // bf16 MFMA partial products per multiply, f32 accumulate), so results agree with the unfused path to f32 rounding.
 //
-// A wave owns 32 rows of x.  Per 32-wide chunk of hidden units:
-//   fc1   hT[h][m] = sum_k W1[h][k] LN(x)[m][k]     A = W1 fragments from LDS, B = the wave's LN(x) rows, split into planes
-//                                                    ONCE and held in registers for the whole kernel (C/16 slabs x 3 planes)
-//   GELU  on the accumulator registers (+ b1), then the 16 values of a lane are split into bf16 planes in place
-//   fc2   out[m][n] += sum_h hid[m][h] W2[n][h]     A = those registers, B = W2 fragments from LDS
+// A wave owns 32 rows of x.  Per 32-wide chunk c of hidden units:
+//   fc1   hT[h][m] = b1[h] + sum_k W1[h][k] LN(x)[m][k]   A = W1 fragments from LDS, B = the wave's LN(x) rows, split into
+//                                                          planes ONCE and held in registers for the whole kernel
+//   GELU  on the accumulator registers, then the 16 values of a lane are split into bf16 planes
+//   fc2   out[m][n] += sum_h hid[m][h] W2[n][h]           A = those registers, B = W2 fragments from LDS
 // The accumulator of a 32x32x16 MFMA holds a column (here: the row m of x) on the lane and 16 rows in the registers, which
 // is exactly an A operand over k = hidden unit: lane-half g, register r <-> row (r&3) + 8(r>>2) + 4g.  Storing the W1 rows
 // of a chunk in LDS with bits 2 and 3 of the row index swapped makes that "row" the hidden unit 8g + (r&7) + 16(r>>3), i.e.
 // registers 0..7 / 8..15 are two natural 16-wide k slabs and W2 needs no permutation.
 //
-// Only the weights go through LDS, shared by the 4 waves of a workgroup (128 rows): chunk images of W1 (C/16 slabs x 32
-// rows) and W2 (2 slabs x C rows), both 2C rows x 112 B in the padded row format of gemm_x3_core.h (conflict-free
-// ds_read_b128 fragments), filled by LDS-DMA (global_load_lds_dwordx4: no staging registers; the pad unit of a row is a
-// duplicate load) one phase ahead into a 2-slot ring, one counted wait + barrier per phase.
+// Software pipeline (one wave): the fc1 MFMAs of chunk c+1 are issued with the GELU of chunk c between them (the VALU work
+// runs while the matrix pipe executes), then the fc2 MFMAs of chunk c with the bf16 split of its second half between
+// them.  Two accumulator sets for the hidden chunk alternate.
+//
+// Only the weights go through LDS, shared by the 4 waves of a workgroup (128 rows).  xp_mlp_fused_x3_pack lays them out once
+// per weight upload as the exact sequence of LDS images the kernel consumes — W1(0), W1(1), W2(0), W1(2), W2(1), ... — each
+// 2C rows x 112 B in the padded row format of gemm_x3_core.h (conflict-free ds_read_b128 fragments) with the W1 rows already
+// permuted, so an image is one contiguous block and a wave's LDS-DMA (global_load_lds_dwordx4, no staging registers)
+// needs a scalar base and lane * 16.  Images land two phases ahead in a 3-slot ring; one counted wait + barrier per phase.
 #include <stdlib.h>
 
 #include <string>
 
 #include "gemm_x3_core.h"
 
+#ifndef XP_MLP_DBG
+#define XP_MLP_DBG 0   /* timing experiments only (wrong results): 1 no GELU, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no bf16 split of the hidden values, 16 no MFMA */
+#endif
+
 namespace {
 
 struct MlpParams {
     float* X;                 // (M, C) in / out
     const float* ln_w; const float* ln_b;
-    const uint4* W1;          // xp_split_weights_x3 layout of fc1.weight (H4, C)
+    const unsigned char* Wpack;   // xp_mlp_fused_x3_pack output
     const float* b1;
-    const uint4* W2;          // xp_split_weights_x3 layout of fc2.weight (C, H4)
     const float* b2;
     int M, H4;
     float eps;
@@ -47,47 +55,84 @@ struct MlpTile {
     static constexpr int NT = C / 32;            // 32-wide output tiles of fc2
     static constexpr int ROWS = 2 * C;           // rows of a chunk image (W1: KS x 32, W2: 2 x C)
     static constexpr int UNITS = ROWS * 7;       // 16-byte units per image incl. the pad unit of every row
-    static constexpr int IMG = UNITS * 16;       // bytes
-    static constexpr int NWI = UNITS / 64;       // wave-level DMA instructions per image (1 KiB each)
-    static constexpr int NI = (NWI + 3) / 4;     // per wave
-    static_assert(C % 32 == 0 && UNITS % 64 == 0, "C must be a multiple of 32");
+    static constexpr int NI = (UNITS * 16 + 4095) / 4096;     // DMA instructions per wave and image (4 waves x 1 KiB each)
+    static constexpr int IMGP = NI * 4096;       // image stride in the packed stream and in the LDS ring (>= UNITS * 16)
+    static_assert(C % 32 == 0, "C must be a multiple of 32");
 };
+
+__device__ __forceinline__ int mlp_swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// One thread per 16-byte unit of the packed stream (see the header comment for the image order).
+template <int C>
+__global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2, uint4* __restrict__ out, int H4) {
+    using T = MlpTile<C>;
+    const int NC = H4 / 32;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int upi = T::IMGP / 16;
+    if (id >= (int64_t)2 * NC * upi) return;
+    const int n = (int)(id / upi), u = (int)(id - (int64_t)n * upi);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    const int row = u / 7, k = u - row * 7;
+    if (u < T::UNITS && k < 6) {
+        // image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1); n = 2NC-1 -> W2(NC-1)
+        const bool is_w1 = (n == 0) || ((n & 1) && n < 2 * NC - 1);
+        if (is_w1) {
+            const int c = (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
+            v = W1[((int64_t)s * H4 + h) * X3_SLAB_UNITS + k];
+        } else {
+            const int c = (n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1, j = row / C, nn = row - j * C;
+            v = W2[((int64_t)(2 * c + j) * C + nn) * X3_SLAB_UNITS + k];
+        }
+    }
+    out[id] = v;
+}
+
+// GELU(erf) as max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2): the same erfc approximation as xp_gelu_fast (Abramowitz-Stegun 7.1.26 on
+// the hardware rcp / exp2 units) without the sign select; the factor 0.5 sqrt 2 is folded into the polynomial.
+__device__ __forceinline__ float mlp_gelu(float x) {
+    if (XP_MLP_DBG & 1) return x;
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    constexpr float k = 0.70710678118654752440f;
+    float q = fmaf(1.061405429f * k, t, -1.453152027f * k);
+    q = fmaf(q, t, 1.421413741f * k);
+    q = fmaf(q, t, -0.284496736f * k);
+    q = fmaf(q, t, 0.254829592f * k);
+    const float e = q * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);     // 0.5 sqrt2 erfc(z)
+    return fmaf(-z, e, fmaxf(x, 0.f));
+}
 
 template <int C>
 __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
     using T = MlpTile<C>;
     constexpr int KS = T::KS, NT = T::NT;
-    extern __shared__ __align__(16) unsigned char lds[];       // [2 image slots][b1 (H4 floats)] — ONE array (LDS-DMA waits)
-    unsigned char* const bias_lds = lds + 2 * T::IMG;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, g = lane >> 5;
+    extern __shared__ __align__(16) unsigned char lds[];       // [3 image slots][b1 (H4 floats)] — ONE array (LDS-DMA waits)
+    unsigned char* const bias_lds = lds + 3 * T::IMGP;
+    const int lane = threadIdx.x & 63, fr = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * 128 + wave * 32;
     const int mrow = (m0 + fr < p.M) ? m0 + fr : p.M - 1;      // rows past M are computed on a copy of the last row, never stored
-    const int NC = p.H4 / 32;
+    const int NC = p.H4 / 32, NIMG = 2 * NC;
 
-    // chunk image `ph` (even: W1 of chunk ph/2, odd: W2 of chunk ph/2) -> ring slot ph & 1
-    auto issue_image = [&](int ph) {
-        const int c = ph >> 1;
-        unsigned char* slot = lds + (ph & 1) * T::IMG;
+    // image n of the packed stream -> ring slot; every wave moves NI KiB-sized pieces (source: scalar base + lane * 16)
+    auto issue_image = [&](int n, int slot) {
+        n = n < NIMG ? n : NIMG - 1;               // past the end: the last image again, into a slot nobody reads (uniform wait counts)
+        const unsigned char* src = p.Wpack + (size_t)n * T::IMGP + wave * 1024 + lane * 16;
+        unsigned char* dst = lds + slot * T::IMGP + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < T::NI; ++i) {
-            int q = wave + 4 * i;                               // wave-level instruction index inside the image
-            q = q < T::NWI ? q : T::NWI - 1;                    // surplus instructions repeat the last one (same bytes, same place)
-            const int u = q * 64 + lane;
-            const int row = u / 7, k = u - row * 7;
-            const int unit = k < 6 ? k : 5;                     // pad unit: any valid address
-            int64_t src;
-            if (ph & 1) {                                       // W2: rows = (slab j, n)
-                const int j = row / C, n = row - j * C;
-                src = ((int64_t)(2 * c + j) * C + n) * X3_SLAB_UNITS + unit;
-            } else {                                            // W1: rows = (slab s, permuted hidden row)
-                const int s = row >> 5, hp = row & 31;
-                const int h = 32 * c + ((hp & 0x13) | ((hp & 4) << 1) | ((hp & 8) >> 1));
-                src = ((int64_t)s * p.H4 + h) * X3_SLAB_UNITS + unit;
-            }
-            const uint4* gp = ((ph & 1) ? p.W2 : p.W1) + src;
-            __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(slot + q * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < T::NI; ++i) __builtin_amdgcn_global_load_lds(src + i * 4096, (lds_ptr_t)(dst + i * 4096), 16, 0, 0);
     };
+    // all but the most recently issued image have landed
+    auto wait_images = [&]() {
+        if constexpr (T::NI == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else if constexpr (T::NI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if constexpr (T::NI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if constexpr (T::NI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if constexpr (T::NI == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        static_assert(T::NI <= 6, "wait_images");
+    };
+    auto barrier = [&]() { if (!(XP_MLP_DBG & 4)) __builtin_amdgcn_s_barrier(); };
 
     // ---- prologue: this lane's half (k = 16 s + 8 g .. + 7) of row mrow, LayerNorm, split into planes ----
     float4 xv[KS][2];
@@ -132,9 +177,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
         xp[s][0] = c[0].v; xp[s][1] = c[1].v; xp[s][2] = c[2].v;
     }
     // every ordinary global load above has been consumed: from here to the epilogue the only VMEM traffic is LDS-DMA
-    issue_image(0);
+    issue_image(0, 0);
+    issue_image(1, 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    barrier();
 
     f32x16 oacc[NT];
 #pragma unroll
@@ -144,87 +190,144 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};     // smallest partial products first
     const int frag = fr * X3_ROWB + 16 * g;
 
-    for (int c = 0; c < NC; ++c) {
-        // ---- phase A: fc1 of chunk c (image 2c in slot 0), while W2 of chunk c lands in slot 1 ----
-        issue_image(2 * c + 1);
-        f32x16 hacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-        {
-            const unsigned char* img = lds + frag;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(img + s * 32 * X3_ROWB + pl * 32);
-#pragma unroll
-                for (int pp = 0; pp < 6; ++pp) hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pp]], xp[s][PB[pp]], hacc, 0, 0, 0);
-            }
-        }
-        // bias + GELU + split: registers 8j .. 8j+7 = hidden units 32c + 16j + 8g + 0..7
-        bf16x8 hp[2][3];
+    // accumulator start = b1 of the chunk: registers 8j .. 8j+7 = hidden units 32c + 16j + 8g + 0..7
+    auto load_bias = [&](int c, f32x16& h) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + (32 * c + 16 * j + 8 * g) * 4);
-            const float4 b1v = *reinterpret_cast<const float4*>(bias_lds + (32 * c + 16 * j + 8 * g + 4) * 4);
-            float4 lo, hi;
-            lo.x = xp_gelu_fast(hacc[8 * j + 0] + b0.x); lo.y = xp_gelu_fast(hacc[8 * j + 1] + b0.y);
-            lo.z = xp_gelu_fast(hacc[8 * j + 2] + b0.z); lo.w = xp_gelu_fast(hacc[8 * j + 3] + b0.w);
-            hi.x = xp_gelu_fast(hacc[8 * j + 4] + b1v.x); hi.y = xp_gelu_fast(hacc[8 * j + 5] + b1v.y);
-            hi.z = xp_gelu_fast(hacc[8 * j + 6] + b1v.z); hi.w = xp_gelu_fast(hacc[8 * j + 7] + b1v.w);
-            union { uint4 u; bf16x8 v; } cc[3];
-            xp_split8(lo, hi, cc[0].u, cc[1].u, cc[2].u);
-            hp[j][0] = cc[0].v; hp[j][1] = cc[1].v; hp[j][2] = cc[2].v;
+            const float4 lo = *reinterpret_cast<const float4*>(bias_lds + (32 * c + 16 * j + 8 * g) * 4);
+            const float4 hi = *reinterpret_cast<const float4*>(bias_lds + (32 * c + 16 * j + 8 * g + 4) * 4);
+            h[8 * j + 0] = lo.x; h[8 * j + 1] = lo.y; h[8 * j + 2] = lo.z; h[8 * j + 3] = lo.w;
+            h[8 * j + 4] = hi.x; h[8 * j + 5] = hi.y; h[8 * j + 6] = hi.z; h[8 * j + 7] = hi.w;
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- phase B: fc2 of chunk c (image 2c+1 in slot 1), while W1 of chunk c+1 lands in slot 0 ----
-        if (c + 1 < NC) issue_image(2 * c + 2);
-        {
-            const unsigned char* img = lds + T::IMG + frag;
+    };
+    unsigned hp[2][3][4];                  // GELU(hidden chunk) as planes (slab j, plane, 4 x 2 bf16): the A operand of fc2
+    auto hfrag = [&](int j, int pl) {
+        union { uint4 u; bf16x8 v; } c;
+        c.u = make_uint4(hp[j][pl][0], hp[j][pl][1], hp[j][pl][2], hp[j][pl][3]);
+        return c.v;
+    };
+    // VALU slices placed between MFMAs.  Slices 0..15: GELU of element r in place; 16..19 / 20..23: bf16 split of pair q of half 0 / 1.
+    auto slice = [&](int k, f32x16& h) {
+        if (k < 16) { h[k] = mlp_gelu(h[k]); return; }
+        const int j = (k - 16) >> 2, q = (k - 16) & 3;
+        if (XP_MLP_DBG & 8) { hp[j][0][q] = __float_as_uint(h[8 * j + 2 * q]); hp[j][1][q] = __float_as_uint(h[8 * j + 2 * q + 1]); hp[j][2][q] = hp[j][0][q]; }
+        else xp_split2(h[8 * j + 2 * q], h[8 * j + 2 * q + 1], hp[j][0][q], hp[j][1][q], hp[j][2][q]);
+    };
+    // fc1 of one chunk from the W1 image in `slot` into nxt (preloaded with the bias); between the MFMAs, slices [0, NSL) of the
+    // previous chunk's accumulators `cur` (NSL = 0: none)
+    auto fc1 = [&](int slot, f32x16& nxt, f32x16& cur, auto nsl_tag) {
+        constexpr int NSL = decltype(nsl_tag)::value;
+        const unsigned char* img = lds + slot * T::IMGP + frag;
+        bf16x8 a[2][3];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+        for (int pl = 0; pl < 3; ++pl) a[0][pl] = *reinterpret_cast<const bf16x8*>(img + pl * 32);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bf16x8 b[3];
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {      // fragments of slab s+1 are requested before the MFMAs of slab s
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(img + (j * C + t * 32) * X3_ROWB + pl * 32);
+                for (int pl = 0; pl < 3; ++pl) a[(s + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(img + (s + 1) * 32 * X3_ROWB + pl * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int pp = 0; pp < 6; ++pp) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hp[j][PA[pp]], b[PB[pp]], oacc[t], 0, 0, 0);
-                }
+            for (int pp = 0; pp < 6; ++pp) {
+                const int m = s * 6 + pp;
+                if (XP_MLP_DBG & 16) { if (pp == 0) nxt[0] += (float)a[s & 1][0][0] * (float)xp[s][0][0] + (float)a[s & 1][1][1] * (float)xp[s][1][1] + (float)a[s & 1][2][2] * (float)xp[s][2][2]; }
+                else nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][PA[pp]], xp[s][PB[pp]], nxt, 0, 0, 0);
+#pragma unroll
+                for (int k = (m * NSL + 6 * KS - 1) / (6 * KS); k < ((m + 1) * NSL + 6 * KS - 1) / (6 * KS); ++k) slice(k, cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+    };
+    // fc2 of one chunk from the W2 image in `slot`: hidden slab 0 for every output tile first, with the split of half 1
+    // (slices 20..23 of `cur`) between those MFMAs, then hidden slab 1
+    auto fc2 = [&](int slot, f32x16& cur) {
+        const unsigned char* img = lds + slot * T::IMGP + frag;
+        bf16x8 b[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const bf16x8*>(img + pl * 32);
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {          // step i = (hidden slab j = i / NT, output tile t = i % NT)
+            const int j = i / NT, t = i % NT;
+            if (i + 1 < 2 * NT) {
+                const int j1 = (i + 1) / NT, t1 = (i + 1) % NT;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(img + (j1 * C + t1 * 32) * X3_ROWB + pl * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) {
+                if (XP_MLP_DBG & 16) { if (pp == 0) oacc[t][0] += __uint_as_float(hp[j][0][0]) * (float)b[i & 1][0][0] + __uint_as_float(hp[j][1][1]) * (float)b[i & 1][1][1] + __uint_as_float(hp[j][2][2]) * (float)b[i & 1][2][2]; }
+                else oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hfrag(j, PA[pp]), b[i & 1][PB[pp]], oacc[t], 0, 0, 0);
+                if (i == 0 && pp < 4) slice(20 + pp, cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto next_slot = [](int s) { return s == 2 ? 0 : s + 1; };
+
+    // phase 0: fc1 of chunk 0 (image 0 in slot 0); image 2 -> slot 2
+    f32x16 h0, h1;
+    int n = 0, slot = 0;                   // image used by the current phase and its ring slot; image n + 2 goes to slot - 1 (mod 3)
+    auto begin_phase = [&]() { if (!(XP_MLP_DBG & 2)) issue_image(n + 2, slot == 0 ? 2 : slot - 1); };
+    auto end_phase = [&]() { wait_images(); barrier(); ++n; slot = next_slot(slot); };
+    begin_phase();
+    load_bias(0, h0);
+    fc1(slot, h0, h1, std::integral_constant<int, 0>{});
+    end_phase();
+    // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
+    //          phase B = fc2(c) (image 2 + 2c)
+    auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
+        begin_phase();
+        load_bias(c + 1, nxt);
+        fc1(slot, nxt, cur, std::integral_constant<int, 20>{});
+        end_phase();
+        begin_phase();
+        fc2(slot, cur);
+        end_phase();
+    };
+    int c = 0;
+    for (; c + 2 < NC; c += 2) { iter(c, h0, h1); iter(c + 1, h1, h0); }
+    auto tail = [&](f32x16& cur) {         // last chunk: nothing left to overlap the GELU with; image 2 NC - 1
+#pragma unroll
+        for (int k = 0; k < 20; ++k) slice(k, cur);
+        fc2(slot, cur);
+    };
+    if (c + 1 < NC) { iter(c, h0, h1); tail(h1); } else tail(h0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy DMAs of the last phases
 
     // ---- epilogue: x[m][n] = x[m][n] + (acc + b2[n]); lane = column n, registers = rows (r&3) + 8(r>>2) + 4g ----
     float* xb = p.X + (int64_t)m0 * C;
+    auto epilogue = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = t * 32 + fr;
-        const float bi = p.b2[col];
-        float rv[16];
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 32 + fr;
+            const float bi = p.b2[col];
+            float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-            rv[r] = xb[((m0 + rl < p.M) ? rl : 0) * C + col];
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                rv[r] = xb[((INTERIOR || m0 + rl < p.M) ? rl : 0) * C + col];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float v = oacc[t][r] + bi;
+                if (INTERIOR || m0 + rl < p.M) xb[rl * C + col] = rv[r] + v;
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-            const float v = oacc[t][r] + bi;
-            if (m0 + rl < p.M) xb[rl * C + col] = rv[r] + v;
-        }
-    }
+    };
+    if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 template <int C>
 int launch_mlp(const MlpParams& p, hipStream_t s) {
     using T = MlpTile<C>;
-    const size_t lds_bytes = 2 * (size_t)T::IMG + (size_t)p.H4 * 4;
+    const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4;
     static bool attr_set = false;
-    if (!attr_set && lds_bytes > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
@@ -237,20 +340,42 @@ int launch_mlp(const MlpParams& p, hipStream_t s) {
     return XP_OK;
 }
 
+template <int C>
+size_t pack_bytes(int H4) { return (size_t)2 * (H4 / 32) * MlpTile<C>::IMGP; }
+
 }  // namespace
 
 extern "C" int xp_mlp_fused_x3_supported(int C, int H4) {
-    return (C == 32 || C == 64 || C == 96) && H4 > 0 && H4 % 32 == 0 && H4 <= 4096;
+    return (C == 32 || C == 64 || C == 96) && H4 >= 64 && H4 % 32 == 0 && H4 <= 4096;
 }
 
-extern "C" int xp_mlp_fused_x3(float* X, const float* ln_w, const float* ln_b, const void* W1x3, const float* b1,
-                               const void* W2x3, const float* b2, int M, int C, int H4, float eps, void* stream) {
-    XP_CHECK_ARG(X && ln_w && ln_b && W1x3 && b1 && W2x3 && b2, "xp_mlp_fused_x3: null pointer");
+extern "C" size_t xp_mlp_fused_x3_pack_bytes(int C, int H4) {
+    if (!xp_mlp_fused_x3_supported(C, H4)) return 0;
+    return C == 32 ? pack_bytes<32>(H4) : C == 64 ? pack_bytes<64>(H4) : pack_bytes<96>(H4);
+}
+
+extern "C" int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, void* out, int C, int H4, void* stream) {
+    XP_CHECK_ARG(W1x3 && W2x3 && out, "xp_mlp_fused_x3_pack: null pointer");
+    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3_pack: unsupported shape C = %d, hidden = %d", C, H4);
+    XP_CHECK_ARG((((uintptr_t)W1x3 | (uintptr_t)W2x3 | (uintptr_t)out) & 15) == 0, "xp_mlp_fused_x3_pack: pointers must be 16-byte aligned");
+    const int64_t units = (int64_t)(xp_mlp_fused_x3_pack_bytes(C, H4) / 16);
+    const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (uint4*)out, H4);
+    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (uint4*)out, H4);
+    else hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (uint4*)out, H4);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_mlp_fused_x3(float* X, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
+                               const float* b2, int M, int C, int H4, float eps, void* stream) {
+    XP_CHECK_ARG(X && ln_w && ln_b && Wpack && b1 && b2, "xp_mlp_fused_x3: null pointer");
     XP_CHECK_ARG(M > 0, "xp_mlp_fused_x3: bad M %d", M);
-    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3: unsupported shape C = %d, hidden = %d (C in {32, 64, 96}, hidden %% 32 == 0)", C, H4);
-    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)W1x3 | (uintptr_t)W2x3 | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
+    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3: unsupported shape C = %d, hidden = %d (C in {32, 64, 96}, hidden %% 32 == 0, 64 <= hidden <= 4096)", C, H4);
+    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)Wpack | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
                  "xp_mlp_fused_x3: pointers must be 16-byte aligned");
-    MlpParams p{X, ln_w, ln_b, (const uint4*)W1x3, b1, (const uint4*)W2x3, b2, M, H4, eps};
+    MlpParams p{X, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
     hipStream_t s = (hipStream_t)stream;
     switch (C) {
         case 32: return launch_mlp<32>(p, s);

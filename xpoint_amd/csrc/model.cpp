@@ -15,6 +15,7 @@ namespace {
 
 struct Param { std::string name; size_t offset; size_t numel; };
 struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset; };   // a GEMM weight and its split-bf16 copy
+struct MlpPack { std::string block; int C, H4; size_t byte_offset; };                     // fused-MLP weight stream of one VSS block
 
 struct Ctx {
     xp_model_cfg cfg;
@@ -22,6 +23,7 @@ struct Ctx {
     int dims[4], ranks[4];
     std::vector<Param> params;
     std::vector<SplitW> split;
+    std::vector<MlpPack> packs;
     size_t total, split_bytes;
     size_t add(const std::string& n, size_t numel) {
         size_t off = total;
@@ -44,13 +46,17 @@ struct Ctx {
         for (auto& p : split) if (p.name == n) return p.byte_offset;
         return (size_t)-1;
     }
+    size_t pack_off(const std::string& block) const {
+        for (auto& p : packs) if (p.block == block) return p.byte_offset;
+        return (size_t)-1;
+    }
 };
 
 int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1
 
 void build_layout(Ctx& c) {
     const int E = c.cfg.embed_dim, N = c.cfg.d_state;
-    c.total = 0; c.split_bytes = 0; c.split.clear();
+    c.total = 0; c.split_bytes = 0; c.split.clear(); c.packs.clear();
     c.add("stem.w", 9 * (E / 2)); c.add("stem.b", E / 2); c.add("stem.ln_w", E / 2); c.add("stem.ln_b", E / 2);
     c.add_gemm("pe2.w", E, 9 * (E / 2)); c.add("pe2.b", E); c.add("pe2.ln_w", E); c.add("pe2.ln_b", E);
     for (int s = 0; s < c.nstages; ++s) {
@@ -68,6 +74,10 @@ void build_layout(Ctx& c) {
             c.add(b + "ln2_w", C); c.add(b + "ln2_b", C);
             c.add_gemm(b + "fc1_w", (int)H4, (int)C); c.add(b + "fc1_b", H4);
             c.add_gemm(b + "fc2_w", (int)C, (int)H4); c.add(b + "fc2_b", C);
+            if (xp_mlp_fused_x3_supported((int)C, (int)H4)) {      // the wide stages run the MLP as one launch (csrc/mlp_fused.hip)
+                c.packs.push_back({b, (int)C, (int)H4, c.split_bytes});
+                c.split_bytes += (xp_mlp_fused_x3_pack_bytes((int)C, (int)H4) + 255) / 256 * 256;
+            }
         }
         if (s < c.nstages - 1) {
             std::string d = "s" + std::to_string(s) + ".ds.";
@@ -184,6 +194,9 @@ extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* w
         XP_CHECK_ARG(e.K % 4 == 0, "xp_prepare_split_weights: %s has K = %d, not a multiple of 4", e.name.c_str(), e.K);
         RUN(xp_split_weights_x3(weights + e.src_offset, (char*)wsplit + e.byte_offset, e.N, e.K, stream));
     }
+    for (auto& e : c->packs)
+        RUN(xp_mlp_fused_x3_pack((char*)wsplit + c->split_off(e.block + "fc1_w"), (char*)wsplit + c->split_off(e.block + "fc2_w"),
+                                 (char*)wsplit + e.byte_offset, e.C, e.H4, stream));
     return XP_OK;
 }
 
@@ -238,10 +251,10 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
                                  T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
             RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
             // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
-            if (fuse_mlp && xp_mlp_fused_x3_supported(C, H4)) {
+            if (fuse_mlp && c->pack_off(b) != (size_t)-1) {
                 // one launch, the (M, 4C) hidden activation stays in registers (csrc/mlp_fused.hip)
-                RUN(xp_mlp_fused_x3(X, P(b + "ln2_w"), P(b + "ln2_b"), (const char*)wsplit + c->split_off(b + "fc1_w"), P(b + "fc1_b"),
-                                    (const char*)wsplit + c->split_off(b + "fc2_w"), P(b + "fc2_b"), M, C, H4, eps, stream));
+                RUN(xp_mlp_fused_x3(X, P(b + "ln2_w"), P(b + "ln2_b"), (const char*)wsplit + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"),
+                                    M, C, H4, eps, stream));
                 continue;
             }
             RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
