@@ -102,15 +102,17 @@ __device__ __forceinline__ float mlp_gelu(float x) {
     return fmaf(-z, e, fmaxf(x, 0.f));
 }
 
-template <int C>
-__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p) {
     using T = MlpTile<C>;
     constexpr int KS = T::KS, NT = T::NT;
+    constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
+    static_assert(T::NI * 4 % NW == 0, "image pieces must divide among the waves");
     extern __shared__ __align__(16) unsigned char lds[];       // [3 image slots][b1 (H4 floats)] — ONE array (LDS-DMA waits)
     unsigned char* const bias_lds = lds + 3 * T::IMGP;
     const int lane = threadIdx.x & 63, fr = lane & 31, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = blockIdx.x * (NW * 32) + wave * 32;
     const int mrow = (m0 + fr < p.M) ? m0 + fr : p.M - 1;      // rows past M are computed on a copy of the last row, never stored
     const int NC = p.H4 / 32, NIMG = 2 * NC;
 
@@ -120,17 +122,17 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
         const unsigned char* src = p.Wpack + (size_t)n * T::IMGP + wave * 1024 + lane * 16;
         unsigned char* dst = lds + slot * T::IMGP + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < T::NI; ++i) __builtin_amdgcn_global_load_lds(src + i * 4096, (lds_ptr_t)(dst + i * 4096), 16, 0, 0);
+        for (int i = 0; i < NI; ++i) __builtin_amdgcn_global_load_lds(src + i * (NW * 1024), (lds_ptr_t)(dst + i * (NW * 1024)), 16, 0, 0);
     };
     // all but the most recently issued image have landed
     auto wait_images = [&]() {
-        if constexpr (T::NI == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else if constexpr (T::NI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if constexpr (T::NI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if constexpr (T::NI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if constexpr (T::NI == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        if constexpr (NI == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        static_assert(T::NI <= 6, "wait_images");
+        static_assert(NI <= 6, "wait_images");
     };
     auto barrier = [&]() { if (!(XP_MLP_DBG & 4)) __builtin_amdgcn_s_barrier(); };
 
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
             xv[s][1] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
         }
     }
-    for (int i = threadIdx.x; i < p.H4 / 4; i += 256)
+    for (int i = threadIdx.x; i < p.H4 / 4; i += NW * 64)
         reinterpret_cast<float4*>(bias_lds)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     float sum = 0.f;
 #pragma unroll
@@ -321,13 +323,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpParams p) {
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int C>
+template <int C, int NW>
 int launch_mlp(const MlpParams& p, hipStream_t s) {
     using T = MlpTile<C>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
@@ -335,7 +337,7 @@ int launch_mlp(const MlpParams& p, hipStream_t s) {
     if (by_shape) tag += "_M" + std::to_string(p.M) + "_C" + std::to_string(C);
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
     XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4, 12.0 * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C>), dim3(xp_cdiv(p.M, 128)), dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -377,9 +379,10 @@ extern "C" int xp_mlp_fused_x3(float* X, const float* ln_w, const float* ln_b, c
                  "xp_mlp_fused_x3: pointers must be 16-byte aligned");
     MlpParams p{X, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
     hipStream_t s = (hipStream_t)stream;
+    static const bool nw8 = getenv("XP_MLP_NW8") != nullptr && atoi(getenv("XP_MLP_NW8")) != 0;     // tuning experiment
     switch (C) {
-        case 32: return launch_mlp<32>(p, s);
-        case 64: return launch_mlp<64>(p, s);
-        default: return launch_mlp<96>(p, s);
+        case 32: return nw8 ? launch_mlp<32, 8>(p, s) : launch_mlp<32, 4>(p, s);
+        case 64: return nw8 ? launch_mlp<64, 8>(p, s) : launch_mlp<64, 4>(p, s);
+        default: return nw8 ? launch_mlp<96, 8>(p, s) : launch_mlp<96, 4>(p, s);
     }
 }
