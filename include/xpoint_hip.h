@@ -88,15 +88,19 @@ int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* b
  * VMamba.py:1230-1234 VSSBlock.forward second residual, :110-128 Mlp; LayerNorm over C, biased variance, eps;
  * exact-erf GELU).  One launch replaces xp_layernorm + two xp_gemm_nt_x3 calls; the (M, hidden) activation is never
  * written to memory (it goes from the fc1 accumulators to the fc2 operand registers).  Same split-bf16 arithmetic
- * as xp_gemm_nt_x3.  The two weight matrices are passed as ONE packed stream in the order the kernel consumes them:
- * xp_mlp_fused_x3_pack converts fc1.weight (hidden, C) and fc2.weight (C, hidden), both already in
- * xp_split_weights_x3 layout, into xp_mlp_fused_x3_pack_bytes(C, hidden) bytes, once per weight upload.
- * Supported shapes: xp_mlp_fused_x3_supported(C, hidden) != 0 (C in {32, 64, 96}, hidden % 32 == 0,
- * 64 <= hidden <= 4096); other shapes return an argument error — callers use the three separate entry points. */
+ * as xp_gemm_nt_x3.
+ * Optionally the block's first residual is folded in as well: with T1 != NULL the kernel first does
+ * X <- X + T1 W0^T  (VMamba.py:663 SS2D out_proj, bias-free, and :1229 x = x + op(norm(x))), T1 (M, C) not aliasing X.
+ * The weight matrices are passed as ONE packed stream in the order the kernel consumes them: xp_mlp_fused_x3_pack
+ * converts fc1.weight (hidden, C), fc2.weight (C, hidden) and, if W0x3 != NULL, W0 (C, C) — all already in
+ * xp_split_weights_x3 layout — into xp_mlp_fused_x3_pack_bytes(C, hidden, W0x3 != NULL) bytes, once per weight upload.
+ * A stream packed with W0 must be used with T1 != NULL and vice versa.
+ * Supported shapes: xp_mlp_fused_x3_supported(C, hidden) != 0 (C in {32, 64, 96, 128, 192}, hidden % 32 == 0,
+ * 64 <= hidden <= 4096); other shapes return an argument error — callers use the separate entry points. */
 int xp_mlp_fused_x3_supported(int C, int hidden);
-size_t xp_mlp_fused_x3_pack_bytes(int C, int hidden);
-int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, void* out, int C, int hidden, void* stream);
-int xp_mlp_fused_x3(float* X, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
+size_t xp_mlp_fused_x3_pack_bytes(int C, int hidden, int with_proj);
+int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, const void* W0x3, void* out, int C, int hidden, void* stream);
+int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
                     const float* b2, int M, int C, int hidden, float eps, void* stream);
 
 /* Glue kernels (HBM-bound). */

@@ -121,41 +121,50 @@ def test_gemm_nt_x3(gpu_lib, M, N, K, act, res):
     assert err <= 2.0 * err32 + 1e-7, (err, err32)
 
 
-@pytest.mark.parametrize("M,C,H4", [(128, 96, 384), (300, 96, 384), (1000, 32, 128), (517, 64, 256), (4480, 96, 384), (77, 96, 96), (200, 64, 64), (130, 32, 512)])
-def test_mlp_fused_x3(gpu_lib, M, C, H4):
-    """x + fc2(GELU(fc1(LN(x)))) in one launch (VMamba.py:1230-1234, :110-128) vs fp64 torch, and vs the three-launch form
-    (xp_layernorm + 2 x xp_gemm_nt_x3) it replaces: same arithmetic, so agreement to f32 rounding.  Ragged M included."""
+@pytest.mark.parametrize("proj", [False, True])
+@pytest.mark.parametrize("M,C,H4", [(128, 96, 384), (300, 96, 384), (1000, 32, 128), (517, 64, 256), (4480, 96, 384), (77, 96, 96),
+                                    (200, 64, 64), (130, 32, 512), (300, 192, 768), (129, 128, 512), (2400, 192, 768)])
+def test_mlp_fused_x3(gpu_lib, M, C, H4, proj):
+    """x + fc2(GELU(fc1(LN(x)))) in one launch (VMamba.py:1230-1234, :110-128), optionally preceded by x += t W0^T (SS2D out_proj +
+    first residual, VMamba.py:663, :1229), vs fp64 torch, and vs the separate launches (xp_gemm_nt_x3 / xp_layernorm) it replaces:
+    same arithmetic, so agreement to f32 rounding.  Ragged M included."""
     L = _lib()
     X = _u(f"mx{M}{C}", (M, C), -2.0, 2.0); lw = _u(f"mlw{C}", (C,), 0.5, 1.5); lb = _u(f"mlb{C}", (C,), -0.5, 0.5)
     W1 = _u(f"mw1{C}{H4}", (H4, C), -0.2, 0.2); b1 = _u(f"mb1{H4}", (H4,), -0.5, 0.5)
     W2 = _u(f"mw2{C}{H4}", (C, H4), -0.1, 0.1); b2 = _u(f"mb2{C}", (C,), -0.5, 0.5)
+    T1 = _u(f"mt{M}{C}", (M, C), -1.0, 1.0); W0 = _u(f"mw0{C}", (C, C), -0.2, 0.2)
     Xd = X.double()
+    if proj:
+        Xd = Xd + F.linear(T1.double(), W0.double())
     ref = Xd + F.linear(F.gelu(F.linear(F.layer_norm(Xd, (C,), lw.double(), lb.double(), 1e-5), W1.double(), b1.double())), W2.double(), b2.double())
     assert L.load().xp_mlp_fused_x3_supported(C, H4) == 1
-    Xg = X.cuda(); lwd, lbd, b1d, b2d = lw.cuda(), lb.cuda(), b1.cuda(), b2.cuda()
-    W1x, W2x = _split_x3(L, W1.cuda()), _split_x3(L, W2.cuda())
+    Xg = X.cuda(); lwd, lbd, b1d, b2d, T1d = lw.cuda(), lb.cuda(), b1.cuda(), b2.cuda(), T1.cuda()
+    W1x, W2x, W0x = _split_x3(L, W1.cuda()), _split_x3(L, W2.cuda()), _split_x3(L, W0.cuda())
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
     st = L.current_stream()
-    pack = torch.empty(L.load().xp_mlp_fused_x3_pack_bytes(C, H4), dtype=torch.uint8, device="cuda")
-    L.call("xp_mlp_fused_x3_pack", ctypes.c_void_p(W1x.data_ptr()), ctypes.c_void_p(W2x.data_ptr()), ctypes.c_void_p(pack.data_ptr()), C, H4, st)
-    L.call("xp_mlp_fused_x3", L.ptr(Xg), L.ptr(lwd), L.ptr(lbd), ctypes.c_void_p(pack.data_ptr()), L.ptr(b1d), L.ptr(b2d), M, C, H4, 1e-5, st)
+    pack = torch.empty(L.load().xp_mlp_fused_x3_pack_bytes(C, H4, int(proj)), dtype=torch.uint8, device="cuda")
+    L.call("xp_mlp_fused_x3_pack", vp(W1x), vp(W2x), vp(W0x) if proj else None, vp(pack), C, H4, st)
+    L.call("xp_mlp_fused_x3", L.ptr(Xg), L.ptr(T1d) if proj else None, L.ptr(lwd), L.ptr(lbd), vp(pack), L.ptr(b1d), L.ptr(b2d), M, C, H4, 1e-5, st)
     err = float((Xg.cpu().double() - ref).abs().max())
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
-    # the three-launch form
+    # the separate launches
     X3 = X.cuda(); T = torch.empty((M, C), device="cuda"); Hb = torch.empty((M, H4), device="cuda")
+    if proj:
+        L.call("xp_gemm_nt_x3", L.ptr(T1d), vp(W0x), L.ptr(X3), None, None, None, L.ptr(X3), M, C, C, C, C, C, 0, st)
     L.call("xp_layernorm", L.ptr(X3), L.ptr(T), L.ptr(lwd), L.ptr(lbd), M, C, 1e-5, 0, st)
-    L.call("xp_gemm_nt_x3", L.ptr(T), ctypes.c_void_p(W1x.data_ptr()), L.ptr(Hb), L.ptr(b1d), None, None, None, M, H4, C, C, H4, 0, 1, st)
-    L.call("xp_gemm_nt_x3", L.ptr(Hb), ctypes.c_void_p(W2x.data_ptr()), L.ptr(X3), L.ptr(b2d), None, None, L.ptr(X3), M, C, H4, H4, C, C, 0, st)
+    L.call("xp_gemm_nt_x3", L.ptr(T), vp(W1x), L.ptr(Hb), L.ptr(b1d), None, None, None, M, H4, C, C, H4, 0, 1, st)
+    L.call("xp_gemm_nt_x3", L.ptr(Hb), vp(W2x), L.ptr(X3), L.ptr(b2d), None, None, L.ptr(X3), M, C, H4, H4, C, C, 0, st)
     err3 = float((X3.cpu().double() - ref).abs().max())
     assert err <= 2.0 * err3 + 1e-6, (err, err3)
-    assert float((Xg - X3).abs().max()) < 1e-5
+    assert float((Xg - X3).abs().max()) < 2e-5
 
 
 def test_mlp_fused_x3_rejects_unsupported(gpu_lib):
     L = _lib()
-    assert L.load().xp_mlp_fused_x3_supported(192, 768) == 0
-    X = torch.zeros((8, 192), device="cuda")
+    assert L.load().xp_mlp_fused_x3_supported(384, 1536) == 0
+    X = torch.zeros((8, 384), device="cuda")
     with pytest.raises(Exception):
-        L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), 8, 192, 768, 1e-5, L.current_stream())
+        L.call("xp_mlp_fused_x3", L.ptr(X), None, L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), L.ptr(X), 8, 384, 1536, 1e-5, L.current_stream())
 
 
 def test_gemm_x3_error_bound_wide_dynamic_range(gpu_lib):

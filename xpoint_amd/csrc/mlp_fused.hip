@@ -39,6 +39,7 @@ namespace {
 
 struct MlpParams {
     float* X;                 // (M, C) in / out
+    const float* T1;          // PRE: (M, C) input of the preceding bias-free projection  X <- X + T1 W0^T  (SS2D out_proj), else null
     const float* ln_w; const float* ln_b;
     const unsigned char* Wpack;   // xp_mlp_fused_x3_pack output
     const float* b1;
@@ -64,15 +65,25 @@ __device__ __forceinline__ int mlp_swap23(int r) { return (r & 0x13) | ((r & 4) 
 
 // One thread per 16-byte unit of the packed stream (see the header comment for the image order).
 template <int C>
-__global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2, uint4* __restrict__ out, int H4) {
+__global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2, const uint4* __restrict__ W0, uint4* __restrict__ out, int H4) {
     using T = MlpTile<C>;
-    const int NC = H4 / 32;
+    const int NC = H4 / 32, NPRE = W0 ? T::NT : 0;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int upi = T::IMGP / 16;
-    if (id >= (int64_t)2 * NC * upi) return;
-    const int n = (int)(id / upi), u = (int)(id - (int64_t)n * upi);
+    if (id >= (int64_t)(NPRE + 2 * NC) * upi) return;
+    int n = (int)(id / upi);
+    const int u = (int)(id - (int64_t)n * upi);
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     const int row = u / 7, k = u - row * 7;
+    if (n < NPRE) {          // the (C, C) projection ahead of the MLP, as NT images in the W1 format (32 permuted output rows x all k slabs)
+        if (u < T::UNITS && k < 6) {
+            const int s = row >> 5, h = 32 * n + mlp_swap23(row & 31);
+            v = W0[((int64_t)s * C + h) * X3_SLAB_UNITS + k];
+        }
+        out[id] = v;
+        return;
+    }
+    n -= NPRE;
     if (u < T::UNITS && k < 6) {
         // image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1); n = 2NC-1 -> W2(NC-1)
         const bool is_w1 = (n == 0) || ((n & 1) && n < 2 * NC - 1);
@@ -102,8 +113,8 @@ __device__ __forceinline__ float mlp_gelu(float x) {
     return fmaf(-z, e, fmaxf(x, 0.f));
 }
 
-template <int C, int NW>
-__global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p) {
+template <int C, int NW, bool PRE>
+__global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_kernel(MlpParams p) {
     using T = MlpTile<C>;
     constexpr int KS = T::KS, NT = T::NT;
     constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * (NW * 32) + wave * 32;
     const int mrow = (m0 + fr < p.M) ? m0 + fr : p.M - 1;      // rows past M are computed on a copy of the last row, never stored
-    const int NC = p.H4 / 32, NIMG = 2 * NC;
+    const int NC = p.H4 / 32, NIMG = 2 * NC + (PRE ? T::NT : 0);
 
     // image n of the packed stream -> ring slot; every wave moves NI KiB-sized pieces (source: scalar base + lane * 16)
     auto issue_image = [&](int n, int slot) {
@@ -126,13 +137,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p)
     };
     // all but the most recently issued image have landed
     auto wait_images = [&]() {
-        if constexpr (NI == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if constexpr (NI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        static_assert(NI <= 6, "wait_images");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NI) : "memory");
+        static_assert(NI <= 63, "wait_images");
     };
     auto barrier = [&]() { if (!(XP_MLP_DBG & 4)) __builtin_amdgcn_s_barrier(); };
 
@@ -148,37 +154,52 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p)
     }
     for (int i = threadIdx.x; i < p.H4 / 4; i += NW * 64)
         reinterpret_cast<float4*>(bias_lds)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-        sum += ((xv[s][0].x + xv[s][0].y) + (xv[s][0].z + xv[s][0].w)) + ((xv[s][1].x + xv[s][1].y) + (xv[s][1].z + xv[s][1].w));
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum / (float)C;
-    float q2 = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float dx = xv[s][e].x - mean, dy = xv[s][e].y - mean, dz = xv[s][e].z - mean, dw = xv[s][e].w - mean;
-            q2 = fmaf(dx, dx, q2); q2 = fmaf(dy, dy, q2); q2 = fmaf(dz, dz, q2); q2 = fmaf(dw, dw, q2);
+    bf16x8 xp[KS][3];          // planes of the B operand of the fc1-type MFMAs: LN(x) of this wave's rows (PRE: first the T1 rows)
+    auto layer_norm_split = [&]() {
+        float sum = 0.f;
+    #pragma unroll
+        for (int s = 0; s < KS; ++s)
+            sum += ((xv[s][0].x + xv[s][0].y) + (xv[s][0].z + xv[s][0].w)) + ((xv[s][1].x + xv[s][1].y) + (xv[s][1].z + xv[s][1].w));
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum / (float)C;
+        float q2 = 0.f;
+    #pragma unroll
+        for (int s = 0; s < KS; ++s)
+    #pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float dx = xv[s][e].x - mean, dy = xv[s][e].y - mean, dz = xv[s][e].z - mean, dw = xv[s][e].w - mean;
+                q2 = fmaf(dx, dx, q2); q2 = fmaf(dy, dy, q2); q2 = fmaf(dz, dz, q2); q2 = fmaf(dw, dw, q2);
+            }
+        q2 += __shfl_xor(q2, 32, 64);
+        const float rstd = 1.f / sqrtf(q2 / (float)C + p.eps);
+    #pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g), w1 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g), c1 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g + 4);
+            float4 lo, hi;
+            lo.x = (xv[s][0].x - mean) * rstd * w0.x + c0.x; lo.y = (xv[s][0].y - mean) * rstd * w0.y + c0.y;
+            lo.z = (xv[s][0].z - mean) * rstd * w0.z + c0.z; lo.w = (xv[s][0].w - mean) * rstd * w0.w + c0.w;
+            hi.x = (xv[s][1].x - mean) * rstd * w1.x + c1.x; hi.y = (xv[s][1].y - mean) * rstd * w1.y + c1.y;
+            hi.z = (xv[s][1].z - mean) * rstd * w1.z + c1.z; hi.w = (xv[s][1].w - mean) * rstd * w1.w + c1.w;
+            union { uint4 u; bf16x8 v; } c[3];
+            xp_split8(lo, hi, c[0].u, c[1].u, c[2].u);
+            xp[s][0] = c[0].v; xp[s][1] = c[1].v; xp[s][2] = c[2].v;
         }
-    q2 += __shfl_xor(q2, 32, 64);
-    const float rstd = 1.f / sqrtf(q2 / (float)C + p.eps);
-    bf16x8 xp[KS][3];                                           // LN(x) planes: the B operand of every fc1 MFMA of this wave
+    };
+    if (PRE) {                 // rows of T1 in the same lane layout, split into planes
+        const float* tr = p.T1 + (int64_t)mrow * C + 8 * g;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g), w1 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g + 4);
-        const float4 c0 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g), c1 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g + 4);
-        float4 lo, hi;
-        lo.x = (xv[s][0].x - mean) * rstd * w0.x + c0.x; lo.y = (xv[s][0].y - mean) * rstd * w0.y + c0.y;
-        lo.z = (xv[s][0].z - mean) * rstd * w0.z + c0.z; lo.w = (xv[s][0].w - mean) * rstd * w0.w + c0.w;
-        hi.x = (xv[s][1].x - mean) * rstd * w1.x + c1.x; hi.y = (xv[s][1].y - mean) * rstd * w1.y + c1.y;
-        hi.z = (xv[s][1].z - mean) * rstd * w1.z + c1.z; hi.w = (xv[s][1].w - mean) * rstd * w1.w + c1.w;
-        union { uint4 u; bf16x8 v; } c[3];
-        xp_split8(lo, hi, c[0].u, c[1].u, c[2].u);
-        xp[s][0] = c[0].v; xp[s][1] = c[1].v; xp[s][2] = c[2].v;
+        for (int s = 0; s < KS; ++s) {
+            const float4 lo = *reinterpret_cast<const float4*>(tr + 16 * s), hi = *reinterpret_cast<const float4*>(tr + 16 * s + 4);
+            union { uint4 u; bf16x8 v; } c[3];
+            xp_split8(lo, hi, c[0].u, c[1].u, c[2].u);
+            xp[s][0] = c[0].v; xp[s][1] = c[1].v; xp[s][2] = c[2].v;
+        }
+    } else {
+        layer_norm_split();
     }
     // every ordinary global load above has been consumed: from here to the epilogue the only VMEM traffic is LDS-DMA
+    // (PRE: plus the stores of the updated rows)
     issue_image(0, 0);
     issue_image(1, 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -268,11 +289,40 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p)
     };
     auto next_slot = [](int s) { return s == 2 ? 0 : s + 1; };
 
-    // phase 0: fc1 of chunk 0 (image 0 in slot 0); image 2 -> slot 2
     f32x16 h0, h1;
     int n = 0, slot = 0;                   // image used by the current phase and its ring slot; image n + 2 goes to slot - 1 (mod 3)
     auto begin_phase = [&]() { if (!(XP_MLP_DBG & 2)) issue_image(n + 2, slot == 0 ? 2 : slot - 1); };
     auto end_phase = [&]() { wait_images(); barrier(); ++n; slot = next_slot(slot); };
+    if (PRE) {
+        // x <- x + T1 W0^T (reference VMamba.py:663 out_proj, :1229 first residual): one fc1-type phase per 32 output channels.  With
+        // the permuted weight rows the accumulator registers 8jj .. 8jj+7 of lane-half g are channels 16 (2t + jj) + 8g + 0..7 — the
+        // lane layout of xv — so the sum never leaves the registers; the updated rows are stored for the epilogue's residual read.
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            begin_phase();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h0[r] = 0.f;
+            fc1(slot, h0, h1, std::integral_constant<int, 0>{});
+            end_phase();
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float4& lo = xv[2 * t + jj][0]; float4& hi = xv[2 * t + jj][1];
+                lo.x = lo.x + h0[8 * jj + 0]; lo.y = lo.y + h0[8 * jj + 1]; lo.z = lo.z + h0[8 * jj + 2]; lo.w = lo.w + h0[8 * jj + 3];
+                hi.x = hi.x + h0[8 * jj + 4]; hi.y = hi.y + h0[8 * jj + 5]; hi.z = hi.z + h0[8 * jj + 6]; hi.w = hi.w + h0[8 * jj + 7];
+            }
+        }
+        if (m0 + fr < p.M) {
+            float* xw = p.X + (int64_t)(m0 + fr) * C + 8 * g;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                *reinterpret_cast<float4*>(xw + 16 * s) = xv[s][0];
+                *reinterpret_cast<float4*>(xw + 16 * s + 4) = xv[s][1];
+            }
+        }
+        layer_norm_split();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores and plain loads retired: the counted waits below see only LDS-DMA
+    }
+    // phase 0 of the MLP: fc1 of chunk 0
     begin_phase();
     load_bias(0, h0);
     fc1(slot, h0, h1, std::integral_constant<int, 0>{});
@@ -310,7 +360,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-                rv[r] = xb[((INTERIOR || m0 + rl < p.M) ? rl : 0) * C + col];
+                const float* rp = xb + ((INTERIOR || m0 + rl < p.M) ? rl : 0) * C + col;
+                rv[r] = PRE ? __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *rp;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -323,66 +374,76 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void mlp_fused_kernel(MlpParams p)
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int C, int NW>
-int launch_mlp(const MlpParams& p, hipStream_t s) {
+template <int C, int NW, bool PRE>
+int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     using T = MlpTile<C>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = "mlp_fused_x3";
+    std::string tag = PRE ? "proj_mlp_fused_x3" : "mlp_fused_x3";
     if (by_shape) tag += "_M" + std::to_string(p.M) + "_C" + std::to_string(C);
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
-    XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4, 12.0 * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
+    XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
+                     (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, PRE>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
 
+template <int C, int NW>
+int launch_mlp(const MlpParams& p, hipStream_t s) { return p.T1 ? launch_mlp_pre<C, NW, true>(p, s) : launch_mlp_pre<C, NW, false>(p, s); }
+
 template <int C>
-size_t pack_bytes(int H4) { return (size_t)2 * (H4 / 32) * MlpTile<C>::IMGP; }
+size_t pack_bytes(int H4, int with_proj) { return (size_t)(2 * (H4 / 32) + (with_proj ? MlpTile<C>::NT : 0)) * MlpTile<C>::IMGP; }
 
 }  // namespace
 
 extern "C" int xp_mlp_fused_x3_supported(int C, int H4) {
-    return (C == 32 || C == 64 || C == 96) && H4 >= 64 && H4 % 32 == 0 && H4 <= 4096;
+    return (C == 32 || C == 64 || C == 96 || C == 128 || C == 192) && H4 >= 64 && H4 % 32 == 0 && H4 <= 4096;
 }
 
-extern "C" size_t xp_mlp_fused_x3_pack_bytes(int C, int H4) {
+extern "C" size_t xp_mlp_fused_x3_pack_bytes(int C, int H4, int with_proj) {
     if (!xp_mlp_fused_x3_supported(C, H4)) return 0;
-    return C == 32 ? pack_bytes<32>(H4) : C == 64 ? pack_bytes<64>(H4) : pack_bytes<96>(H4);
+    const int w = with_proj;
+    return C == 32 ? pack_bytes<32>(H4, w) : C == 64 ? pack_bytes<64>(H4, w) : C == 96 ? pack_bytes<96>(H4, w) : C == 128 ? pack_bytes<128>(H4, w) : pack_bytes<192>(H4, w);
 }
 
-extern "C" int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, void* out, int C, int H4, void* stream) {
+extern "C" int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, const void* W0x3, void* out, int C, int H4, void* stream) {
     XP_CHECK_ARG(W1x3 && W2x3 && out, "xp_mlp_fused_x3_pack: null pointer");
     XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3_pack: unsupported shape C = %d, hidden = %d", C, H4);
-    XP_CHECK_ARG((((uintptr_t)W1x3 | (uintptr_t)W2x3 | (uintptr_t)out) & 15) == 0, "xp_mlp_fused_x3_pack: pointers must be 16-byte aligned");
-    const int64_t units = (int64_t)(xp_mlp_fused_x3_pack_bytes(C, H4) / 16);
+    XP_CHECK_ARG((((uintptr_t)W1x3 | (uintptr_t)W2x3 | (uintptr_t)W0x3 | (uintptr_t)out) & 15) == 0, "xp_mlp_fused_x3_pack: pointers must be 16-byte aligned");
+    const int64_t units = (int64_t)(xp_mlp_fused_x3_pack_bytes(C, H4, W0x3 != nullptr) / 16);
     const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (uint4*)out, H4);
-    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (uint4*)out, H4);
-    else hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (uint4*)out, H4);
+    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
+    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
+    else if (C == 96) hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
+    else if (C == 128) hipLaunchKernelGGL(mlp_pack_kernel<128>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
+    else hipLaunchKernelGGL(mlp_pack_kernel<192>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
 
-extern "C" int xp_mlp_fused_x3(float* X, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
+extern "C" int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
                                const float* b2, int M, int C, int H4, float eps, void* stream) {
     XP_CHECK_ARG(X && ln_w && ln_b && Wpack && b1 && b2, "xp_mlp_fused_x3: null pointer");
     XP_CHECK_ARG(M > 0, "xp_mlp_fused_x3: bad M %d", M);
-    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3: unsupported shape C = %d, hidden = %d (C in {32, 64, 96}, hidden %% 32 == 0, 64 <= hidden <= 4096)", C, H4);
-    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)Wpack | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
+    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3: unsupported shape C = %d, hidden = %d (C in {32, 64, 96, 128, 192}, hidden %% 32 == 0, 64 <= hidden <= 4096)", C, H4);
+    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)T1 | (uintptr_t)Wpack | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
                  "xp_mlp_fused_x3: pointers must be 16-byte aligned");
-    MlpParams p{X, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
+    XP_CHECK_ARG(T1 != X, "xp_mlp_fused_x3: T1 must not alias X");
+    MlpParams p{X, T1, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
     hipStream_t s = (hipStream_t)stream;
     static const bool nw8 = getenv("XP_MLP_NW8") != nullptr && atoi(getenv("XP_MLP_NW8")) != 0;     // tuning experiment
     switch (C) {
         case 32: return nw8 ? launch_mlp<32, 8>(p, s) : launch_mlp<32, 4>(p, s);
         case 64: return nw8 ? launch_mlp<64, 8>(p, s) : launch_mlp<64, 4>(p, s);
-        default: return nw8 ? launch_mlp<96, 8>(p, s) : launch_mlp<96, 4>(p, s);
+        case 96: return nw8 ? launch_mlp<96, 8>(p, s) : launch_mlp<96, 4>(p, s);
+        case 128: return launch_mlp<128, 4>(p, s);
+        default: return launch_mlp<192, 4>(p, s);
     }
 }

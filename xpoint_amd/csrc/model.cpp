@@ -76,7 +76,7 @@ void build_layout(Ctx& c) {
             c.add_gemm(b + "fc2_w", (int)C, (int)H4); c.add(b + "fc2_b", C);
             if (xp_mlp_fused_x3_supported((int)C, (int)H4)) {      // the wide stages run the MLP as one launch (csrc/mlp_fused.hip)
                 c.packs.push_back({b, (int)C, (int)H4, c.split_bytes});
-                c.split_bytes += (xp_mlp_fused_x3_pack_bytes((int)C, (int)H4) + 255) / 256 * 256;
+                c.split_bytes += (xp_mlp_fused_x3_pack_bytes((int)C, (int)H4, 1) + 255) / 256 * 256;
             }
         }
         if (s < c.nstages - 1) {
@@ -196,7 +196,7 @@ extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* w
     }
     for (auto& e : c->packs)
         RUN(xp_mlp_fused_x3_pack((char*)wsplit + c->split_off(e.block + "fc1_w"), (char*)wsplit + c->split_off(e.block + "fc2_w"),
-                                 (char*)wsplit + e.byte_offset, e.C, e.H4, stream));
+                                 (char*)wsplit + c->split_off(e.block + "out_w"), (char*)wsplit + e.byte_offset, e.C, e.H4, stream));
     return XP_OK;
 }
 
@@ -249,14 +249,15 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
             RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
             RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
                                  T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
-            RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
-            // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
             if (fuse_mlp && c->pack_off(b) != (size_t)-1) {
-                // one launch, the (M, 4C) hidden activation stays in registers (csrc/mlp_fused.hip)
-                RUN(xp_mlp_fused_x3(X, P(b + "ln2_w"), P(b + "ln2_b"), (const char*)wsplit + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"),
+                // out_proj + first residual + LN + MLP + second residual in one launch; the (M, 4C) hidden activation stays in
+                // registers (csrc/mlp_fused.hip)
+                RUN(xp_mlp_fused_x3(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), (const char*)wsplit + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"),
                                     M, C, H4, eps, stream));
                 continue;
             }
+            RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
+            // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
             RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
             RUN(gemm(T1, b + "fc1_w", HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
             RUN(gemm(HB, b + "fc2_w", X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));
