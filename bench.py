@@ -221,9 +221,9 @@ def main():
 
     if rank == 0:
         avg_s = dom["ms"] / max(dom["launches"], 1) * 1e-3
-        if dom["flops"] > 0 and (dominant.startswith("gemm") or dominant.startswith("conv3x3")):
+        if dom["flops"] > 0 and dominant.startswith(("gemm", "conv3x3", "mlp_fused", "proj_mlp_fused")):
             ach = dom["flops"] / dom["launches"] / avg_s / 1e12
-            x3 = "_x3_" in dominant
+            x3 = "_x3" in dominant
             # split-bf16 kernels: algorithmic (f32-equivalent) 2MNK flops against the bf16 dense peak / 6 products per multiply
             peak = MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS if x3 else MFMA_F32_PEAK_TFLOPS
             roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -239,12 +239,16 @@ def main():
                     "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 3)}
         # HBM traffic of that kernel from the committed rocprofv3 PMC run (cannot be collected from inside this process)
         try:
-            tiles = dominant.rsplit("_", 1)[1].split("x")
-            cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2",
-                    ("128", "32"): "4, 1, 1, 1"}
-            kname = f"{'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, {1 if dominant.startswith('conv3x3') else 0}>"
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
+            if "mlp_fused" in dominant:     # tag (proj_)mlp_fused_x3_c<C>  <->  mlp_fused_kernel<C, 4, PRE>
+                kname = f"mlp_fused_kernel<{dominant.rsplit('_c', 1)[1]}, 4, {'true' if dominant.startswith('proj_') else 'false'}>"
+                roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
+            else:
+                tiles = dominant.rsplit("_", 1)[1].split("x")
+                cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2",
+                        ("128", "32"): "4, 1, 1, 1"}
+                kname = f"{'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, {1 if dominant.startswith('conv3x3') else 0}>"
+                roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
         except Exception:
             pass

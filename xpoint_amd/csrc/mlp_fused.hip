@@ -384,8 +384,8 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = PRE ? "proj_mlp_fused_x3" : "mlp_fused_x3";
-    if (by_shape) tag += "_M" + std::to_string(p.M) + "_C" + std::to_string(C);
+    std::string tag = std::string(PRE ? "proj_mlp_fused_x3_c" : "mlp_fused_x3_c") + std::to_string(C);      // one tag per kernel instance
+    if (by_shape) tag += "_M" + std::to_string(p.M);
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
     XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
                      (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
