@@ -49,8 +49,12 @@ int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, co
  *   u (batch, H, W, C) = SiLU(dwconv(in_proj(x)));  xdbl (batch*H*W, 4*(R+2)) = u @ x_proj^T with the four
  *   directions stored in the order (0, 2, 1, 3), each [dt_rank values, B, C];  wdt (4, R, C) (= dt_projs_weight transposed: channel-contiguous), dt_bias (4, C),
  *   A (4, C) = -exp(A_logs), Ds (4, C) in the same direction order;  ln_w/ln_b = out_norm;  out (batch, H, W, C).
- *   d_state must be 1 (the XPoint config; general d_state: xp_selective_scan_fwd). */
+ *   d_state must be 1 (the XPoint config; general d_state: xp_selective_scan_fwd).
+ *   Two internal forms with the same results to f32 rounding: chunked three-pass (long sequences) and sequential per
+ *   (image, route, 64 channels) wave (short sequences with many channels: the deep encoder stages); chosen per call
+ *   shape, or forced with xp_ss2d_core_set_mode(0 chunked / 1 sequential / -1 automatic) for tests and A/B timing. */
 size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C);
+int xp_ss2d_core_set_mode(int mode);
 int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const float* dt_bias, const float* A,
                      const float* Ds, const float* ln_w, const float* ln_b, float* out, float* workspace,
                      size_t workspace_bytes, int batch, int H, int W, int C, int R, int dstate, float eps,

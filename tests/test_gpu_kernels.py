@@ -288,11 +288,14 @@ def test_softmax_shuffle_and_l2norm(gpu_lib):
 
 
 # ------------------------------------------------------------------------------------------------ fused SS2D core
-@pytest.mark.parametrize("B,C,H,W", [(2, 96, 16, 24), (1, 192, 8, 12), (1, 384, 7, 10), (1, 768, 15, 20), (2, 32, 16, 24), (1, 96, 33, 58)])
-def test_ss2d_core_vs_oracle(gpu_lib, B, C, H, W):
+@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("B,C,H,W", [(2, 96, 16, 24), (1, 192, 8, 12), (1, 384, 7, 10), (1, 768, 15, 20), (2, 32, 16, 24), (1, 96, 33, 58),
+                                     (3, 384, 30, 40)])
+def test_ss2d_core_vs_oracle(gpu_lib, B, C, H, W, form):
     """Fused pixel-layout core == reference forward_corev2 (VMamba.py:601-646): cross_scan, x_proj, dt_proj,
     selective scan, cross_merge (incl. the (y0+y2)+(y1+y3) order), out_norm.  Includes H,W not multiples of
-    the chunk/tile sizes (33x58 is the reference's own odd-size check, csm_triton.py:670)."""
+    the chunk/tile sizes (33x58 is the reference's own odd-size check, csm_triton.py:670).  Both internal forms
+    (0: chunked three-pass, 1: sequential per route wave) on every shape."""
     L = _lib()
     R, N = (C + 15) // 16, 1
     pre = "op."
@@ -315,8 +318,13 @@ def test_ss2d_core_vs_oracle(gpu_lib, B, C, H, W):
     dtw = sd[pre + "dt_projs_weight"][order].permute(0, 2, 1).contiguous().cuda(); dtb = sd[pre + "dt_projs_bias"][order].contiguous().cuda()
     Dd = sd[pre + "Ds"].view(4, C)[order].contiguous().cuda()
     lnw, lnb = sd[pre + "out_norm.weight"].cuda(), sd[pre + "out_norm.bias"].cuda()
-    L.call("xp_ss2d_core_fwd", L.ptr(u), L.ptr(xdbl), L.ptr(dtw), L.ptr(dtb), L.ptr(A), L.ptr(Dd), L.ptr(lnw), L.ptr(lnb), L.ptr(out),
-           L.ptr(ws), nbytes, B, H, W, C, R, 1, 1e-5, L.current_stream())
+    L.call("xp_ss2d_core_set_mode", form)
+    try:
+        L.call("xp_ss2d_core_fwd", L.ptr(u), L.ptr(xdbl), L.ptr(dtw), L.ptr(dtb), L.ptr(A), L.ptr(Dd), L.ptr(lnw), L.ptr(lnb), L.ptr(out),
+               L.ptr(ws), nbytes, B, H, W, C, R, 1, 1e-5, L.current_stream())
+        torch.cuda.synchronize()
+    finally:
+        L.call("xp_ss2d_core_set_mode", -1)
     err = float((out.cpu() - ref).abs().max())
     assert err < 2e-5, err
 

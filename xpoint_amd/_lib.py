@@ -27,6 +27,7 @@ _SIGNATURES = {
     "xp_device_info": [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
     "xp_selective_scan_fwd": [c_p] * 9 + [c_i] * 7 + [c_p],
     "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
+    "xp_ss2d_core_set_mode": [c_i],
     "xp_gemm_nt": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc": [c_p] * 6 + [c_i] * 8 + [c_p],
     "xp_split_weights_x3": [c_p, c_p, c_i, c_i, c_p],

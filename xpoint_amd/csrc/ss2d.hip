@@ -18,7 +18,9 @@
 // Directions are stored in the order (0, 2, 1, 3) so that a pair's operands are adjacent.
 #include <stdlib.h>
 
+#include <atomic>
 #include <string>
+#include <type_traits>
 
 #include "xp_common.h"
 
@@ -372,6 +374,161 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sequential form for the deepest stage (short sequences, many channels: L = 300 x C = 768 at 480 x 640; measured slower than the
+// chunked form at L = 1200 x C = 384, where 1200 dependent steps of one wave per SIMD outlast the three passes).  With 3072-float LDS tiles the chunks above shrink to 8 pixels there, every step is evaluated twice (summary
+// pass + re-run) and the three passes cost as much as at stage 1 for a half / a quarter of the steps.  Here one wave
+// walks ONE route of 64 channels of one image from end to end — every step evaluated once, no carry pass — and writes the
+// route's y; a second kernel adds the four routes in the reference's order (y0 + y2) + (y1 + y3) (csm_triton.py:60-62) and applies
+// out_norm.  batch * 4 * C / 64 independent waves (768 at both deep stages of a 16-image batch); u and the route's xdbl rows
+// are fetched a 32-pixel tile ahead.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SEQ_TP = 32;
+template <int R>
+__global__ __launch_bounds__(64) void ss2d_seq_scan(SS2DParams p, float* __restrict__ ys) {
+    constexpr int RW = R + 2, HW2 = RW / 2;                             // floats / float2 pieces per xdbl row of one route
+    static_assert(HW2 <= 32, "two rows per staging instruction");
+    __shared__ __align__(16) float s_x[2][SEQ_TP * RW];
+    const int lane = threadIdx.x, d = blockIdx.y, b = blockIdx.z;
+    const int pair = d >> 1, back = d & 1;                              // directions in the stored order (0, 2, 1, 3)
+    const int c = blockIdx.x * 64 + lane;                               // C % 64 == 0 (host)
+    const int L = p.H * p.W, XD = 4 * RW;
+    float w[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = p.wdt[((int64_t)d * R + r) * p.C + c];
+    const float bias = p.dtb[d * p.C + c], Av = p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
+    const float* ub = p.u + (int64_t)b * L * p.C + c;
+    const float* xb = p.xdbl + (int64_t)b * L * XD + pair * 2 * RW + back * RW + 2 * (lane & 31);
+    float* yb = ys + ((int64_t)d * p.Bn + b) * L * p.C + c;
+    // sequence index i -> pixel: forward routes walk l = i, backward routes l = L - 1 - i (the flipped sequence, csm_triton.py:33-36);
+    // column-major routes need (w, h) = (l / H, l % H): one division per tile, then stepping (a division per step and use —
+    // three per step — was a third of this kernel).  Indices past the end repeat the last pixel (loaded, never stored).
+    auto tile_pixels = [&](int t, int (&px)[SEQ_TP]) {
+        const int i0 = t * SEQ_TP;
+        if (pair == 0) {
+#pragma unroll
+            for (int j = 0; j < SEQ_TP; ++j) { const int i = min(i0 + j, L - 1); px[j] = back ? L - 1 - i : i; }
+        } else {
+            const int l0 = back ? L - 1 - i0 : i0;
+            int ww = l0 / p.H, hh = l0 - ww * p.H;
+#pragma unroll
+            for (int j = 0; j < SEQ_TP; ++j) {
+                px[j] = hh * p.W + ww;
+                if (i0 + j < L - 1) {
+                    if (back) { if (--hh < 0) { hh = p.H - 1; --ww; } }
+                    else { if (++hh == p.H) { hh = 0; ++ww; } }
+                }
+            }
+        }
+    };
+    const int ntile = (L + SEQ_TP - 1) / SEQ_TP;
+    float ucur[SEQ_TP], unext[SEQ_TP];
+    int pxc[SEQ_TP], pxn[SEQ_TP];          // wave-uniform
+    float2 xreg[SEQ_TP / 2];
+    auto load_u = [&](const int (&px)[SEQ_TP], float (&uv)[SEQ_TP]) {
+#pragma unroll
+        for (int j = 0; j < SEQ_TP; ++j) uv[j] = ub[px[j] * p.C];      // 32-bit offsets (host checks H*W*C < 2^31)
+    };
+    // two xdbl rows per instruction: lanes 0..31 row 2q, lanes 32..63 row 2q+1, float2 piece lane & 31 (lanes past the row
+    // length load a valid neighbour and are not stored)
+    const bool xok = (lane & 31) < HW2;
+    auto load_x = [&](const int (&px)[SEQ_TP]) {
+#pragma unroll
+        for (int q = 0; q < SEQ_TP / 2; ++q) {
+            const int pj = (lane >> 5) ? px[2 * q + 1] : px[2 * q];
+            xreg[q] = *reinterpret_cast<const float2*>(xb + (xok ? (int64_t)pj * XD : 0));
+        }
+    };
+    const int xdst = (lane >> 5) * RW + 2 * (lane & 31);
+    auto store_x = [&](int buf) {
+        if (xok) {
+#pragma unroll
+            for (int q = 0; q < SEQ_TP / 2; ++q) *reinterpret_cast<float2*>(&s_x[buf][2 * q * RW + xdst]) = xreg[q];
+        }
+    };
+    tile_pixels(0, pxc);
+    load_u(pxc, ucur); load_x(pxc); store_x(0);
+    float h = 0.f;
+    // four steps at a time: their operand evaluation (projection, softplus, exp) is independent and interleaves; only the
+    // h update is a chain.  Full tiles carry no bounds tests; the last, partial tile evaluates on valid LDS rows and masks its stores.
+    auto run_tile = [&](const float* sx, int nj, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int j0 = 0; j0 < SEQ_TP; j0 += 4) {
+            if (FULL || j0 < nj) {                                      // uniform
+                float a[4], bb[4], cv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) step_vals<R>(sx + (j0 + k) * RW, w, bias, Av, ucur[j0 + k], a[k], bb[k], cv[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    h = a[k] * h + bb[k];
+                    if (FULL || j0 + k < nj) yb[pxc[j0 + k] * p.C] = cv[k] * h + Dv * ucur[j0 + k];   // y = C*h + D*u (csms6s.py:61,67)
+                }
+            }
+        }
+    };
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) { tile_pixels(t + 1, pxn); load_u(pxn, unext); load_x(pxn); }
+        const int nj = L - t * SEQ_TP;
+        if (nj >= SEQ_TP) run_tile(s_x[t & 1], SEQ_TP, std::true_type{});
+        else run_tile(s_x[t & 1], nj, std::false_type{});
+        if (t + 1 < ntile) {
+            store_x((t + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < SEQ_TP; ++j) { ucur[j] = unext[j]; pxc[j] = pxn[j]; }
+        }
+    }
+}
+
+// out[b][px][:] = LayerNorm_C((y0 + y2) + (y1 + y3)); one wave per pixel, the row held in registers (C <= 768)
+__global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const float* __restrict__ ys) {
+    const int lane = threadIdx.x & 63;
+    const int64_t M = (int64_t)p.Bn * p.H * p.W;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t plane = M * p.C;
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int cc = q * 64 + lane;
+        v[q] = 0.f;
+        if (cc < p.C) {
+            const float* y = ys + row * p.C + cc;
+            v[q] = (y[0] + y[plane]) + (y[2 * plane] + y[3 * plane]);
+            s += v[q];
+        }
+    }
+    const float mean = xp_wave_sum(s) / (float)p.C;
+    float q2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) if (q * 64 + lane < p.C) { const float dd = v[q] - mean; q2 = fmaf(dd, dd, q2); }
+    const float rstd = 1.f / sqrtf(xp_wave_sum(q2) / (float)p.C + p.eps);
+    float* orow = p.out + row * p.C;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int cc = q * 64 + lane;
+        if (cc < p.C) orow[cc] = (v[q] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+    }
+}
+
+template <int R>
+int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s) {
+    const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * 4 * (R + 2);
+    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
+    const std::string sfx = by_shape ? "_C" + std::to_string(p.C) : std::string();
+    {   // every route reads u and its quarter of xdbl, writes its y
+        XpProfScope prof(("ss2d_seq_scan" + sfx).c_str(), s, 4.0 * MC * (2.0 * R + 14.0), 4.0 * (8.0 * MC + MX));
+        hipLaunchKernelGGL(ss2d_seq_scan<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+    }
+    {
+        XpProfScope prof(("ss2d_seq_merge_ln" + sfx).c_str(), s, 12.0 * MC, 4.0 * 5.0 * MC);
+        hipLaunchKernelGGL(ss2d_seq_merge_ln, dim3(xp_cdiv((int64_t)p.Bn * p.H * p.W, 4)), dim3(256), 0, s, p, ys);
+    }
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
 template <int R>
 int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     constexpr int XW = 2 * (R + 2);
@@ -406,11 +563,21 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
 
 }  // namespace
 
+// -1 (default): chosen per call shape; 0: chunked three-pass form; 1: sequential form.  XP_SS2D_SEQ=0/1 presets it.
+static std::atomic<int> g_ss2d_mode{getenv("XP_SS2D_SEQ") ? atoi(getenv("XP_SS2D_SEQ")) : -1};
+extern "C" int xp_ss2d_core_set_mode(int mode) {
+    XP_CHECK_ARG(mode >= -1 && mode <= 1, "xp_ss2d_core_set_mode: mode must be -1 (auto), 0 (chunked) or 1 (sequential)");
+    g_ss2d_mode.store(mode);
+    return XP_OK;
+}
+
 extern "C" size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C) {
     // P and S: (B, 2, nc, 2, C) each with the smallest chunk (T = 8) -> upper bound; + ya (B,H,W,C)
     const int64_t L = (int64_t)H * W;
     const int64_t nc = (L + 7) / 8;
-    return (size_t)(2 * (int64_t)batch * 2 * nc * 2 * C + (int64_t)batch * L * C) * sizeof(float);
+    const int64_t chunked = 2 * (int64_t)batch * 2 * nc * 2 * C + (int64_t)batch * L * C;
+    const int64_t sequential = 4 * (int64_t)batch * L * C;     // y of the four routes (deep stages, ss2d_seq_scan)
+    return (size_t)(chunked > sequential ? chunked : sequential) * sizeof(float);
 }
 
 extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const float* dt_bias,
@@ -442,6 +609,24 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
     const int64_t nps = (int64_t)batch * 2 * p.nc * 2 * C;
     p.wsP = workspace; p.wsS = workspace + nps; p.ya = workspace + 2 * nps;
     hipStream_t s = (hipStream_t)stream;
+    // deep stages: short sequences and enough (image, route, 64-channel) waves to cover the chip -> the sequential form
+    const int64_t seq_waves = (int64_t)batch * 4 * xp_cdiv(C, 64);
+    const int mode = g_ss2d_mode.load();
+    static const int64_t min_waves = getenv("XP_SS2D_SEQ_WAVES") ? atoi(getenv("XP_SS2D_SEQ_WAVES")) : 384;
+    const bool seq = mode >= 0 ? mode != 0 : (L <= 512 && seq_waves >= min_waves);
+    if (seq && C <= 768 && C % 64 == 0) {
+        switch (R) {
+            case 2: return launch_ss2d_seq<2>(p, workspace, s);
+            case 4: return launch_ss2d_seq<4>(p, workspace, s);
+            case 6: return launch_ss2d_seq<6>(p, workspace, s);
+            case 8: return launch_ss2d_seq<8>(p, workspace, s);
+            case 12: return launch_ss2d_seq<12>(p, workspace, s);
+            case 16: return launch_ss2d_seq<16>(p, workspace, s);
+            case 24: return launch_ss2d_seq<24>(p, workspace, s);
+            case 48: return launch_ss2d_seq<48>(p, workspace, s);
+            default: break;
+        }
+    }
     switch (R) {
         case 2: return launch_ss2d<2>(p, s);
         case 4: return launch_ss2d<4>(p, s);
