@@ -119,6 +119,12 @@ int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, float eps, voi
 int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int C, void* stream);
 int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_t n, void* stream);
 int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream);
+/* Data ingest (reference datasets/ImagePairDataset.py:199-208 cv2.imread + COLOR_BGR2GRAY + / 255.0, :254-274 crop):
+ * src = decoded 8-bit image on the device, (H0, W0, channels) interleaved with channels 1 (gray), 3 (R,G,B) or 4 (R,G,B,A);
+ * dst (h, w) f32 = lut256[gray] of the crop at (top, left), gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14 (OpenCV's 8-bit
+ * fixed-point BGR2GRAY), lut256[k] = float32(k / 255.0) supplied by the host (double-precision division as numpy's). */
+int xp_ingest_u8(const uint8_t* src, int H0, int W0, int channels, int top, int left, int h, int w,
+                 const float* lut256, float* dst, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Model forward.  Replaces xpoint.models.XPoint.forward_impl (xpoint/models/XPoint.py:283-323) with the

@@ -2,6 +2,7 @@
 host-side logic that needs no GPU (context / parameter layout / weight packing / config and error behaviour)
 is correct.  No compute entry point is called here."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -120,3 +121,59 @@ def test_evaluation_host_logic_vs_reference_golden(golden):
     assert np.allclose(ev.warp_keypoints(kp, h, float), [[6.5, 22.5], [-3.5, 2.5], [1.5, 3.5]])
     assert ev.filter_points(np.array([[-1, 2], [3, 4], [5, 200], [9, 9]]), (10, 100)).tolist() == [[3, 4], [9, 9]]
     assert ev.warp_keypoints(np.zeros((0, 2)), h).shape == (0, 2)
+
+
+# ------------------------------------------------------------------------------------------------ data ingest (folder mode)
+def _write_pair_folder(root, n=3, H0=70, W0=100, gray_thermal=True):
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    os.makedirs(os.path.join(root, "optical")); os.makedirs(os.path.join(root, "thermal"))
+    raw = []
+    for i in range(n):
+        o = rng.integers(0, 256, (H0, W0, 3), dtype=np.uint8)
+        t = rng.integers(0, 256, (H0, W0) if gray_thermal else (H0, W0, 3), dtype=np.uint8)
+        Image.fromarray(o).save(os.path.join(root, "optical", f"im{i}.png"))
+        Image.fromarray(t).save(os.path.join(root, "thermal", f"im{i}.png"))
+        raw.append((o, t))
+    open(os.path.join(root, "optical", "notes.txt"), "w").write("ignored")
+    return raw
+
+
+def test_image_pair_dataset_folder_mode(tmp_path):
+    """ImagePairDataset folder mode (reference datasets/ImagePairDataset.py:48-74,122-128,199-208,254-274,331-420): member list,
+    gray conversion (OpenCV 8-bit fixed point, restated), / 255, crop to multiples of 32 with the reference's RNG call order,
+    output structure, error behaviour."""
+    import random
+    from xpoint_amd.datasets import ImagePairDataset, rgb_to_gray_u8, gray_lut
+    raw = _write_pair_folder(str(tmp_path))
+    ds = ImagePairDataset({"foldername": str(tmp_path), "height": 70, "width": 100})
+    assert len(ds) == 3 and ds.memberslist == ["im0.png", "im1.png", "im2.png"]
+    random.seed(3)
+    s = ds[1]
+    random.seed(3)
+    i_h = random.randint(0, 70 - 64); i_w = random.randint(0, 100 - 96)          # 70 // 32 * 32 = 64, 100 // 32 * 32 = 96
+    o, t = raw[1]
+    g = ((o[..., 2].astype(np.int64) * 1868 + o[..., 1].astype(np.int64) * 9617 + o[..., 0].astype(np.int64) * 4899 + 8192) >> 14)
+    assert np.array_equal(rgb_to_gray_u8(o), g.astype(np.uint8))
+    exp_o = (g / 255.0)[i_h:i_h + 64, i_w:i_w + 96].astype(np.float32)
+    exp_t = (t / 255.0)[i_h:i_h + 64, i_w:i_w + 96].astype(np.float32)
+    assert s["optical"]["image"].shape == (1, 64, 96) and s["optical"]["image"].dtype == torch.float32
+    assert np.array_equal(s["optical"]["image"][0].numpy(), exp_o) and np.array_equal(s["thermal"]["image"][0].numpy(), exp_t)
+    assert s["optical"]["valid_mask"].dtype == torch.bool and bool(s["optical"]["valid_mask"].all())
+    assert s["optical"]["is_optical"].tolist() == [True] and s["thermal"]["is_optical"].tolist() == [False] and s["name"] == "im1.png"
+    assert np.array_equal(gray_lut()[g], (g / 255.0).astype(np.float32))           # the device path's table == numpy's division
+    # no size requested -> whole image; the known gray values: pure R / G / B / white
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]]], dtype=np.uint8)
+    assert rgb_to_gray_u8(px).tolist() == [[76, 150, 29, 255]]
+    # errors, as the reference raises them
+    with pytest.raises(ValueError):
+        ImagePairDataset({"foldername": str(tmp_path / "missing")})
+    with pytest.raises(ValueError):
+        ImagePairDataset({})
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(ValueError):
+        ImagePairDataset({"foldername": str(tmp_path / "empty")})
+    with pytest.raises(ValueError):
+        ImagePairDataset({"foldername": str(tmp_path), "height": 128, "width": 96})[0]      # larger than the images
+    with pytest.raises(NotImplementedError):
+        ImagePairDataset({"foldername": str(tmp_path), "augmentation": {"photometric": {"enable": True}}})

@@ -1,6 +1,7 @@
 """GPU parity of every HIP kernel class against the oracle (same seeded inputs), through the C ABI.
 Tolerances are written per test; integer / index results are exact."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -458,3 +459,43 @@ def test_match_batched_ragged_counts(gpu_lib):
         oms = xo.get_matches(d1[i, :n1[i]], d2[i, :n2[i]])
         assert [(int(a), int(b)) for a, b in zip(res["match_q"][i, :nm].cpu(), res["match_t"][i, :nm].cpu())] == \
                [(m.queryIdx, m.trainIdx) for m in oms]
+
+
+# ------------------------------------------------------------------------------------------------ data ingest
+@pytest.mark.parametrize("ch", [1, 3, 4])
+def test_ingest_u8_exact(gpu_lib, ch):
+    """xp_ingest_u8 == gray (OpenCV 8-bit fixed point) / 255.0 -> float32 of the crop, bit for bit (datasets.rgb_to_gray_u8 + numpy)."""
+    from xpoint_amd.datasets import rgb_to_gray_u8, gray_lut
+    L = _lib()
+    rng = np.random.default_rng(ch)
+    H0, W0, top, left, h, w = 75, 301, 7, 13, 64, 288
+    a = rng.integers(0, 256, (H0, W0) if ch == 1 else (H0, W0, ch), dtype=np.uint8)
+    exp = (rgb_to_gray_u8(a) / 255.0)[top:top + h, left:left + w].astype(np.float32)
+    d = torch.from_numpy(a).cuda(); lut = torch.from_numpy(gray_lut()).cuda(); out = torch.empty((h, w), device="cuda")
+    L.call("xp_ingest_u8", ctypes.c_void_p(d.data_ptr()), H0, W0, ch, top, left, h, w, L.ptr(lut), L.ptr(out), L.current_stream())
+    assert np.array_equal(out.cpu().numpy(), exp)
+    with pytest.raises(Exception):
+        L.call("xp_ingest_u8", ctypes.c_void_p(d.data_ptr()), H0, W0, ch, top, left, h + 100, w, L.ptr(lut), L.ptr(out), L.current_stream())
+
+
+def test_image_pair_dataset_load_batch_equals_getitem(gpu_lib, tmp_path):
+    """Device ingest (host decode -> u8 upload -> xp_ingest_u8) == the host path of ImagePairDataset.__getitem__, bit for bit,
+    and the batch feeds XPoint.forward's input structure."""
+    import random
+    from PIL import Image
+    from xpoint_amd.datasets import ImagePairDataset
+    rng = np.random.default_rng(9)
+    os.makedirs(tmp_path / "optical"); os.makedirs(tmp_path / "thermal")
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (80, 120, 3), dtype=np.uint8)).save(tmp_path / "optical" / f"p{i}.png")
+        Image.fromarray(rng.integers(0, 256, (80, 120), dtype=np.uint8)).save(tmp_path / "thermal" / f"p{i}.png")
+    ds = ImagePairDataset({"foldername": str(tmp_path), "height": 64, "width": 96, "random_pairs": True})
+    random.seed(11)
+    host = [ds[i] for i in (2, 0, 1)]
+    random.seed(11)
+    dev = ds.load_batch([2, 0, 1], "cuda:0")
+    assert dev["optical"]["image"].shape == (3, 1, 64, 96) and dev["name"] == ["p2.png", "p0.png", "p1.png"]
+    for k in ("optical", "thermal"):
+        assert torch.equal(dev[k]["image"].cpu(), torch.stack([h[k]["image"] for h in host]))
+        assert torch.equal(dev[k]["is_optical"].cpu(), torch.stack([h[k]["is_optical"] for h in host]))
+        assert dev[k]["valid_mask"].dtype == torch.bool and bool(dev[k]["valid_mask"].all())

@@ -327,6 +327,23 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
     y[idx] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(int64_t)W * C], p[(int64_t)W * C + C]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Data ingest (reference datasets/ImagePairDataset.py:199-208, :254-274 folder mode): a decoded 8-bit image ->
+// gray -> / 255 -> crop, straight into a slot of the (B, 1, h, w) f32 batch.  Gray = OpenCV's COLOR_BGR2GRAY for 8-bit
+// images, fixed point with 14 fractional bits: (B*1868 + G*9617 + R*4899 + 8192) >> 14.  `lut` = float32(k / 255.0)
+// for k = 0..255 computed by the host in double precision, as numpy does for the reference.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ingest_u8_kernel(const uint8_t* __restrict__ src, int H0, int W0, int ch, int top, int left,
+                                                        int h, int w, const float* __restrict__ lut, float* __restrict__ dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* px = src + ((int64_t)(top + y) * W0 + (left + x)) * ch;
+    int g;
+    if (ch == 1) g = px[0];
+    else g = (px[2] * 1868 + px[1] * 9617 + px[0] * 4899 + 8192) >> 14;      // src is R, G, B(, A) interleaved
+    dst[(int64_t)y * w + x] = lut[g];
+}
+
 }  // namespace
 
 extern "C" int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps,
@@ -430,6 +447,18 @@ extern "C" int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int 
     const int64_t total = (int64_t)batch * (H / 2) * (W / 2) * C;
     XpProfScope prof("maxpool2", (hipStream_t)stream, 3.0 * total, 20.0 * total);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_ingest_u8(const uint8_t* src, int H0, int W0, int channels, int top, int left, int h, int w,
+                            const float* lut256, float* dst, void* stream) {
+    XP_CHECK_ARG(src && lut256 && dst, "xp_ingest_u8: null pointer");
+    XP_CHECK_ARG(channels == 1 || channels == 3 || channels == 4, "xp_ingest_u8: channels must be 1 (gray), 3 (RGB) or 4 (RGBA), got %d", channels);
+    XP_CHECK_ARG(h > 0 && w > 0 && top >= 0 && left >= 0 && top + h <= H0 && left + w <= W0,
+                 "xp_ingest_u8: crop (%d,%d)+(%dx%d) outside the %dx%d image", top, left, h, w, H0, W0);
+    XpProfScope prof("ingest_u8", (hipStream_t)stream, 6.0 * h * w, (double)h * w * (channels + 4));
+    hipLaunchKernelGGL(ingest_u8_kernel, dim3(xp_cdiv(w, 256), h), dim3(256), 0, (hipStream_t)stream, src, H0, W0, channels, top, left, h, w, lut256, dst);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
