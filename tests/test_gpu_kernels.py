@@ -160,6 +160,33 @@ def test_mlp_fused_x3(gpu_lib, M, C, H4, proj):
     assert float((Xg - X3).abs().max()) < 2e-5
 
 
+def test_mlp_fused_x3_race_screen(gpu_lib):
+    """The fused kernel's LDS-DMA ring is ordered by counted waits + barriers only; a misplaced wait would show up as rare wrong
+    tiles.  The kernel is deterministic, so 30 runs at the full stage-0 / stage-1 sizes must be bit-identical."""
+    L = _lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = L.current_stream()
+    for (M, C, H4) in [(307200, 96, 384), (76800, 192, 768)]:
+        g = torch.Generator(device="cuda").manual_seed(M)
+        X0 = torch.randn((M, C), device="cuda", generator=g); T1 = torch.randn((M, C), device="cuda", generator=g)
+        lw = torch.rand((C,), device="cuda", generator=g) + 0.5; lb = torch.randn((C,), device="cuda", generator=g) * 0.1
+        W1 = torch.randn((H4, C), device="cuda", generator=g) * 0.1; b1 = torch.randn((H4,), device="cuda", generator=g) * 0.1
+        W2 = torch.randn((C, H4), device="cuda", generator=g) * 0.05; b2 = torch.randn((C,), device="cuda", generator=g) * 0.1
+        W0 = torch.randn((C, C), device="cuda", generator=g) * 0.1
+        W1x, W2x, W0x = _split_x3(L, W1), _split_x3(L, W2), _split_x3(L, W0)
+        pack = torch.empty(L.load().xp_mlp_fused_x3_pack_bytes(C, H4, 1), dtype=torch.uint8, device="cuda")
+        L.call("xp_mlp_fused_x3_pack", vp(W1x), vp(W2x), vp(W0x), vp(pack), C, H4, st)
+        first = None
+        for it in range(30):
+            X = X0.clone()
+            L.call("xp_mlp_fused_x3", L.ptr(X), L.ptr(T1), L.ptr(lw), L.ptr(lb), vp(pack), L.ptr(b1), L.ptr(b2), M, C, H4, 1e-5, st)
+            if first is None:
+                first = X
+            else:
+                assert torch.equal(X, first), (M, C, it, int((X != first).sum()))
+        assert bool(torch.isfinite(first).all())
+
+
 def test_mlp_fused_x3_rejects_unsupported(gpu_lib):
     L = _lib()
     assert L.load().xp_mlp_fused_x3_supported(384, 1536) == 0

@@ -238,8 +238,12 @@ struct GemmTileX3 {
     __device__ static __forceinline__ int au_id(int s) { const int id = (int)threadIdx.x + s * NT; return (s + 1) * NT <= AU_TOT ? id : (id < AU_TOT ? id : AU_TOT - 1); }
     __device__ static __forceinline__ int au_row(int s) { return au_id(s) / X3_SLAB_UNITS; }
     __device__ static __forceinline__ int au_unit(int s) { return au_id(s) % X3_SLAB_UNITS; }
-    template <class LA, class LB>
+    // NPROD = 6: all partial products of weight >= 2^-16 (f32-grade result); NPROD = 3: a0 b0 + a0 b1 + a1 b0 only — the dropped
+    // terms are bounded by 3 * 2^-16 * sum_k |a_k||b_k| (|x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|), half the matrix work: for consumers
+    // that only need a bounded-error result (the matcher's nomination pass).
+    template <int NPROD = 6, class LA, class LB>
     __device__ static __forceinline__ void run_presplit(unsigned char* lds, int K, LA ldAu, LB ldBu, f32x16 (&acc)[TM][TN]) {
+        static_assert(NPROD == 6 || NPROD == 3, "NPROD");
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave / WN, wn = wave % WN;
         const int fr = lane & 31, fh = lane >> 5;
@@ -274,9 +278,9 @@ struct GemmTileX3 {
             }
         };
         auto mfmas = [&](int pp0, int pp1) {
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // NPROD = 3: the last three
 #pragma unroll
-            for (int pp = pp0; pp < pp1; ++pp)
+            for (int pp = pp0 + (6 - NPROD); pp < pp1 + (6 - NPROD); ++pp)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -301,12 +305,12 @@ struct GemmTileX3 {
             constexpr int U = decltype(u_tag)::value;          // t % 2
             frags(bufs[U]);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(0, 2);
+            mfmas(0, NPROD / 3);
             __builtin_amdgcn_sched_barrier(0);
             lstore(ra[U ^ 1], rb[U ^ 1], bufs[U ^ 1]);       // slab t+1, loaded during slab t-2
             __builtin_amdgcn_sched_barrier(0);
             gload(ra[U ^ 1], rb[U ^ 1], t + 3);
-            mfmas(2, 6);
+            mfmas(NPROD / 3, NPROD);
             xp_lds_barrier();
         };
         for (int t = 0; t < nslab; t += 2) { step(t, std::integral_constant<int, 0>{}); step(t + 1, std::integral_constant<int, 1>{}); }

@@ -22,7 +22,14 @@
 namespace {
 
 constexpr int CAND_CAP = 16;
-constexpr float MATCH_EPS = 2e-5f;   // relative to (|a|^2 + |b|^2): >= 2x the fp32 Gram-form error bound
+// The Gram pass runs THREE of the six split-bf16 partial products (a0 b0 + a0 b1 + a1 b0: half the matrix work).  Error of an
+// approximate d2 = |a|^2 + |b|^2 - 2 a.b, relative to (|a|^2 + |b|^2):
+//   dropped products   2 * 3 * 2^-16 * sum|a_k||b_k| <= 2 * 4.6e-5 * |a||b| <= 4.6e-5 (|a|^2 + |b|^2)      (Cauchy-Schwarz, AM-GM)
+//   f32 accumulation   <= 1e-5 (|a|^2 + |b|^2)                                                               (K = 256, as before)
+// EPS must cover the error of BOTH values it compares (the candidate's and the running minimum's): 2 * 5.6e-5 -> 1.2e-4.
+// Only the number of nominated candidates depends on it (a few per cent of the rows get a second one), never the result.
+constexpr int MATCH_NPROD = 3;
+constexpr float MATCH_EPS = MATCH_NPROD == 3 ? 1.2e-4f : 2e-5f;   // relative to (|a|^2 + |b|^2)
 
 struct MatchParams {
     const float* d1; const float* d2;            // (cap, D) per pair
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_
         if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(&s_max[1]), __float_as_int(mx));
     }
     f32x16 acc[2][2];
-    T::run_presplit(reinterpret_cast<unsigned char*>(lds), p.nslab * X3_BK, ldA, ldB, acc);   // ends with a barrier, so the s_col init is visible
+    T::template run_presplit<MATCH_NPROD>(reinterpret_cast<unsigned char*>(lds), p.nslab * X3_BK, ldA, ldB, acc);   // ends with a barrier, so the s_col init is visible
 
     const int lane = threadIdx.x & 63;
     const float na_max = s_max[0], nb_max = s_max[1];
