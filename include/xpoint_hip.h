@@ -87,6 +87,15 @@ int xp_gemm_nt_x3(const float* A, const void* Wx3, float* C, const float* bias, 
 int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* bias, const float* scale,
                        const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
                        int act, void* stream);
+/* Precision class of the "x3" kernels (xp_gemm_nt_x3, xp_conv3x3_nhwc_x3, xp_mlp_fused_x3 and every dense layer of
+ * xp_xpoint_forward with wsplit != NULL), process-wide, read at launch time:
+ *   6 (default)  all six partial products of weight >= 2^-16: f32-grade (the class pinned against the reference, 1e-4 bar)
+ *   3            a0 b0 + a0 b1 + a1 b0: operands carried to 16 bits, error <= 3 * 2^-16 * sum|a||b| per dot product, half the matrix work
+ *   1            a0 b0: bf16 operands, f32 accumulate — the arithmetic class of the reference's `mixed_precision` autocast
+ *                (XPoint.py:182); activations, LayerNorm, scan and post-processing stay f32.
+ * The same weight buffers serve all three. */
+int xp_set_dense_products(int n);
+int xp_get_dense_products(void);
 
 /* Fused VSS-block MLP branch, in place:  X <- X + fc2(GELU(fc1(LayerNorm(X)) + b1)) + b2   (reference
  * VMamba.py:1230-1234 VSSBlock.forward second residual, :110-128 Mlp; LayerNorm over C, biased variance, eps;

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "xp_selective_scan_fwd": [c_p] * 9 + [c_i] * 7 + [c_p],
     "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
     "xp_ss2d_core_set_mode": [c_i],
+    "xp_set_dense_products": [c_i],
     "xp_gemm_nt": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc": [c_p] * 6 + [c_i] * 8 + [c_p],
     "xp_split_weights_x3": [c_p, c_p, c_i, c_i, c_p],
@@ -75,6 +76,7 @@ _SIZE_QUERIES = {
     "xp_split_weights_x3_bytes": (c_sz, [c_i] * 2),
     "xp_split_weights_bytes": (c_sz, [c_p]),
     "xp_mlp_fused_x3_supported": (c_i, [c_i, c_i]),
+    "xp_get_dense_products": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_find_homography_workspace_bytes": (c_sz, [c_i]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),

@@ -95,3 +95,14 @@ extern "C" int xp_prof_get(int index, char* tag, int tag_len, double* total_ms, 
     if (flops) *flops = it->second.flops; if (bytes) *bytes = it->second.bytes;
     return XP_OK;
 }
+
+// ---- precision class of the split-bf16 dense kernels -------------------------------------------------------------------
+#include <atomic>
+static std::atomic<int> g_dense_products{[] { const char* e = getenv("XP_DENSE_PRODUCTS"); const int v = e ? atoi(e) : 6; return (v == 1 || v == 3) ? v : 6; }()};
+int xp_dense_products_value() { return g_dense_products.load(); }
+extern "C" int xp_get_dense_products(void) { return g_dense_products.load(); }
+extern "C" int xp_set_dense_products(int n) {
+    XP_CHECK_ARG(n == 6 || n == 3 || n == 1, "xp_set_dense_products: 6 (f32-grade, default), 3 (two-plane operands) or 1 (plain bf16 operands); got %d", n);
+    g_dense_products.store(n);
+    return XP_OK;
+}

@@ -31,9 +31,9 @@ __global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restr
     o[0] = p0; o[2] = p1; o[4] = p2;
 }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, int NP>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
-    using T = GemmTileX3<WM, WN, TM, TN>;
+    using T = GemmTileX3<WM, WN, TM, TN, NP>;
     extern __shared__ __align__(16) unsigned char lds_x3[];
     // XCD-aware tile order (same bijective remap as gemm.hip: each XCD gets a contiguous run of logical tiles, the
     // N-tiles of one M-tile adjacent, so the A rows they share come from that XCD's L2)
@@ -102,27 +102,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_x3_kernel(GemmParams p) {
     gemm_epilogue<T, TM, TN>(p, m0, n0, acc);
 }
 
-template <int WM, int WN, int TM, int TN>
-void launch(const GemmParams& p, hipStream_t s) {
-    using T = GemmTileX3<WM, WN, TM, TN>;
+template <int WM, int WN, int TM, int TN, int NP>
+void launch_np(const GemmParams& p, hipStream_t s) {
+    using T = GemmTileX3<WM, WN, TM, TN, NP>;
     static bool attr_set = false;
     if (!attr_set && T::kLdsBytes > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<WM, WN, TM, TN, 0>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<WM, WN, TM, TN, 0, NP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<WM, WN, TM, TN, 1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<WM, WN, TM, TN, 1, NP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
         attr_set = true;
     }
     dim3 grid(xp_cdiv(p.N, T::BN) * xp_cdiv(p.M, T::BM));
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     std::string tag = std::string(p.mode ? "conv3x3_x3_mfma_" : "gemm_x3_mfma_") + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    if (NP != 6) tag += "_np" + std::to_string(NP);
     if (by_shape) tag += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
     const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
-    // flops = algorithmic 2MNK (f32-equivalent); the matrix pipe executes 6x that in bf16
+    // flops = algorithmic 2MNK (f32-equivalent); the matrix pipe executes NP x that in bf16
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K,
                      4.0 * (in_elems + 1.5 * (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
-    if (p.mode == 0) hipLaunchKernelGGL((gemm_x3_kernel<WM, WN, TM, TN, 0>), grid, dim3(T::NT), T::kLdsBytes, s, p);
-    else hipLaunchKernelGGL((gemm_x3_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+    if (p.mode == 0) hipLaunchKernelGGL((gemm_x3_kernel<WM, WN, TM, TN, 0, NP>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+    else hipLaunchKernelGGL((gemm_x3_kernel<WM, WN, TM, TN, 1, NP>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+}
+
+template <int WM, int WN, int TM, int TN>
+void launch(const GemmParams& p, hipStream_t s) {
+    switch (xp_dense_products_value()) {
+        case 1: launch_np<WM, WN, TM, TN, 1>(p, s); break;
+        case 3: launch_np<WM, WN, TM, TN, 3>(p, s); break;
+        default: launch_np<WM, WN, TM, TN, 6>(p, s); break;
+    }
 }
 
 int dispatch(const GemmParams& p, hipStream_t s) {

@@ -59,11 +59,17 @@ __device__ __forceinline__ void xp_split8(const float4& lo, const float4& hi, ui
     xp_split2(hi.z, hi.w, p0.w, p1.w, p2.w);
 }
 
-template <int WM, int WN, int TM, int TN>
+// NP = partial products per multiply: 6 (default; every product of weight >= 2^-16: f32-grade), 3 (a0 b0 + a0 b1 + a1 b0: error
+// <= 3 * 2^-16 * sum|a||b|, half the matrix work) or 1 (a0 b0: plain bf16 operands, f32 accumulate — the "autocast" class).
+// Planes that no product reads are neither split, stored nor loaded.
+template <int WM, int WN, int TM, int TN, int NP = 6>
 struct GemmTileX3 {
+    static_assert(NP == 6 || NP == 3 || NP == 1, "NP");
+    static constexpr int NPL = NP == 6 ? 3 : (NP == 3 ? 2 : 1);     // operand planes in use
+    static constexpr int B_UNITS = 2 * NPL;                          // 16-byte units of a weight row per slab that are staged
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     static constexpr int A_TOT = BM * 4;                    // (row, k-quad) staging slots per slab: 16 B of f32 each
-    static constexpr int B_TOT = BN * X3_SLAB_UNITS;        // 16-byte units per slab
+    static constexpr int B_TOT = BN * B_UNITS;              // 16-byte units per slab
     static constexpr int A_LD = (A_TOT + NT - 1) / NT, B_LD = (B_TOT + NT - 1) / NT;
     static constexpr int kBufBytes = (BM + BN) * X3_ROWB;
     static constexpr size_t kLdsBytes = 2 * (size_t)kBufBytes;
@@ -74,8 +80,8 @@ struct GemmTileX3 {
     __device__ static __forceinline__ int b_id(int s) { const int id = (int)threadIdx.x + s * NT; return (s + 1) * NT <= B_TOT ? id : (id < B_TOT ? id : B_TOT - 1); }
     __device__ static __forceinline__ int a_row(int s) { return a_id(s) >> 2; }
     __device__ static __forceinline__ int a_quad(int s) { return a_id(s) & 3; }
-    __device__ static __forceinline__ int b_row(int s) { return b_id(s) / X3_SLAB_UNITS; }
-    __device__ static __forceinline__ int b_unit(int s) { return b_id(s) % X3_SLAB_UNITS; }   // plane * 2 + octet
+    __device__ static __forceinline__ int b_row(int s) { return b_id(s) / B_UNITS; }
+    __device__ static __forceinline__ int b_unit(int s) { return b_id(s) % B_UNITS; }   // plane * 2 + octet
 
     struct RawA { float4 a[A_LD]; bool ok[A_LD]; };      // f32 A values of one slab as loaded
     struct SplitA { uint2 p[A_LD][3]; };                 // the same slab split into its three bf16 planes
@@ -141,8 +147,8 @@ struct GemmTileX3 {
             for (int s = 0; s < A_LD; ++s) {
                 unsigned char* d = buf + a_dst[s];
                 *reinterpret_cast<uint2*>(d) = sa.p[s][0];
-                *reinterpret_cast<uint2*>(d + 32) = sa.p[s][1];
-                *reinterpret_cast<uint2*>(d + 64) = sa.p[s][2];
+                if (NPL > 1) *reinterpret_cast<uint2*>(d + 32) = sa.p[s][1];
+                if (NPL > 2) *reinterpret_cast<uint2*>(d + 64) = sa.p[s][2];
             }
 #pragma unroll
             for (int s = 0; s < B_LD; ++s) *reinterpret_cast<uint4*>(buf + b_dst[s]) = rb.b[s];
@@ -153,7 +159,7 @@ struct GemmTileX3 {
         auto frags = [&](const unsigned char* buf) {
             if ((XP_X3_DBG & 32) && buf != lds) return;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(buf + a_frag + pl * 32 + i * 32 * X3_ROWB);
 #pragma unroll
@@ -162,14 +168,14 @@ struct GemmTileX3 {
         };
         auto mfmas = [&](int pp0, int pp1) {
             // smallest partial products first; the TM*TN independent accumulators separate dependent MFMAs
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};      // NP = 3: the last three, NP = 1: the last
 #pragma unroll
-            for (int pp = pp0; pp < pp1; ++pp)
+            for (int pp = pp0 + (6 - NP); pp < pp1 + (6 - NP); ++pp)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (XP_X3_DBG & 4) { if (pp == 0) acc[i][j][0] += (float)af[0][i][0] * (float)bf[0][j][0] + (float)af[1][i][1] * (float)bf[1][j][1] + (float)af[2][i][2] * (float)bf[2][j][2]; }
+                        if (XP_X3_DBG & 4) { if (pp == 6 - NP) acc[i][j][0] += (float)af[0][i][0] * (float)bf[0][j][0] + (float)af[1][i][1] * (float)bf[1][j][1] + (float)af[2][i][2] * (float)bf[2][j][2]; }
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pp]][i], bf[PB[pp]][j], acc[i][j], 0, 0, 0);
                     }
         };
@@ -178,7 +184,7 @@ struct GemmTileX3 {
         // at once queue up in the texture-address unit with the MFMAs stuck behind them.
         auto pipeline = [&]() {      // for the second part of a slab: 4 partial products with the loads and the split VALU between them
 #if !defined(XP_X3_NO_SGB)
-            constexpr int NMFMA = 4 * TM * TN, NLOAD = A_LD + B_LD, NVALU = 30 * A_LD + 8 + 4 * NLOAD;
+            constexpr int NMFMA = (NP - NP / 3) * TM * TN, NLOAD = A_LD + B_LD, NVALU = 30 * A_LD + 8 + 4 * NLOAD;
             constexpr int VPER = (NVALU + NMFMA - 1) / NMFMA;
             constexpr int LEVERY = NMFMA / (2 * NLOAD) > 0 ? NMFMA / (2 * NLOAD) : 1;       // loads in the first half of this MFMA stream
 #pragma unroll
@@ -213,12 +219,12 @@ struct GemmTileX3 {
             constexpr int U = decltype(u_tag)::value;          // t % 4, compile-time so that every register index is static
             frags(bufs[U & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(0, 2);                                        // the LDS is busy with every wave's fragment reads right now:
+            mfmas(0, NP / 3);                                   // the LDS is busy with every wave's fragment reads right now:
             __builtin_amdgcn_sched_barrier(0);                  // the stores of slab t+1 go out once a third of the MFMAs are queued
             lstore(sp, rb[(U + 1) & 1], bufs[(U + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             if (LOADS) { gloadB(rb[(U + 1) & 1], t + 3); gloadA(ra[(U + 1) & 3], t + 5); }
-            mfmas(2, 6);
+            mfmas(NP / 3, NP);
             split(ra[(U + 2) & 3], sp);
             pipeline();
             xp_lds_barrier();
@@ -244,6 +250,7 @@ struct GemmTileX3 {
     template <int NPROD = 6, class LA, class LB>
     __device__ static __forceinline__ void run_presplit(unsigned char* lds, int K, LA ldAu, LB ldBu, f32x16 (&acc)[TM][TN]) {
         static_assert(NPROD == 6 || NPROD == 3, "NPROD");
+        static_assert(NP == 6, "run_presplit stages all six units of both operands: use the default tile");
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave / WN, wn = wave % WN;
         const int fr = lane & 31, fh = lane >> 5;

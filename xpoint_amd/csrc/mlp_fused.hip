@@ -113,8 +113,9 @@ __device__ __forceinline__ float mlp_gelu(float x) {
     return fmaf(-z, e, fmaxf(x, 0.f));
 }
 
-template <int C, int NW, bool PRE>
+template <int C, int NW, bool PRE, int NP>
 __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_kernel(MlpParams p) {
+    static_assert(NP == 6 || NP == 3 || NP == 1, "partial products per multiply (gemm_x3_core.h)");
     using T = MlpTile<C>;
     constexpr int KS = T::KS, NT = T::NT;
     constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
@@ -252,12 +253,12 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pp = 0; pp < 6; ++pp) {
-                const int m = s * 6 + pp;
-                if (XP_MLP_DBG & 16) { if (pp == 0) nxt[0] += (float)a[s & 1][0][0] * (float)xp[s][0][0] + (float)a[s & 1][1][1] * (float)xp[s][1][1] + (float)a[s & 1][2][2] * (float)xp[s][2][2]; }
+            for (int pp = 6 - NP; pp < 6; ++pp) {
+                const int m = s * NP + pp - (6 - NP);
+                if (XP_MLP_DBG & 16) { if (pp == 5) nxt[0] += (float)a[s & 1][0][0] * (float)xp[s][0][0]; }
                 else nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][PA[pp]], xp[s][PB[pp]], nxt, 0, 0, 0);
 #pragma unroll
-                for (int k = (m * NSL + 6 * KS - 1) / (6 * KS); k < ((m + 1) * NSL + 6 * KS - 1) / (6 * KS); ++k) slice(k, cur);
+                for (int k = (m * NSL + NP * KS - 1) / (NP * KS); k < ((m + 1) * NSL + NP * KS - 1) / (NP * KS); ++k) slice(k, cur);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -279,10 +280,13 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pp = 0; pp < 6; ++pp) {
-                if (XP_MLP_DBG & 16) { if (pp == 0) oacc[t][0] += __uint_as_float(hp[j][0][0]) * (float)b[i & 1][0][0] + __uint_as_float(hp[j][1][1]) * (float)b[i & 1][1][1] + __uint_as_float(hp[j][2][2]) * (float)b[i & 1][2][2]; }
+            for (int pp = 6 - NP; pp < 6; ++pp) {
+                if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * (float)b[i & 1][0][0]; }
                 else oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hfrag(j, PA[pp]), b[i & 1][PB[pp]], oacc[t], 0, 0, 0);
-                if (i == 0 && pp < 4) slice(20 + pp, cur);
+                if (i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (NP >= 4 ? q == pp - (6 - NP) : true) slice(20 + q, cur);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -374,24 +378,34 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int C, int NW, bool PRE>
-int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
+template <int C, int NW, bool PRE, int NP>
+int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     using T = MlpTile<C>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, PRE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     std::string tag = std::string(PRE ? "proj_mlp_fused_x3_c" : "mlp_fused_x3_c") + std::to_string(C);      // one tag per kernel instance
+    if (NP != 6) tag += "_np" + std::to_string(NP);
     if (by_shape) tag += "_M" + std::to_string(p.M);
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
     XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
                      (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, PRE>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, PRE, NP>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
+}
+
+template <int C, int NW, bool PRE>
+int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
+    switch (xp_dense_products_value()) {      // precision class of the dense kernels (xp_set_dense_products)
+        case 1: return launch_mlp_np<C, 4, PRE, 1>(p, s);
+        case 3: return launch_mlp_np<C, 4, PRE, 3>(p, s);
+        default: return launch_mlp_np<C, NW, PRE, 6>(p, s);
+    }
 }
 
 template <int C, int NW>

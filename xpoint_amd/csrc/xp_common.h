@@ -52,6 +52,9 @@ private:
 
 static inline int xp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Partial products per multiply of the split-bf16 dense kernels (xp_set_dense_products): 6 (default), 3 or 1.
+int xp_dense_products_value();
+
 #ifdef __HIPCC__
 // softplus with torch semantics (beta 1, threshold 20): reference csms6s.py:49-50 /
 // selective_scan_fwd_kernel_oflex.cuh:124-127.

@@ -31,6 +31,7 @@ class _ModelCfg(ctypes.Structure):
 _LoadResult = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 _DIR_ORDER = [0, 2, 1, 3]   # device order of the four scan routes (row pair, then column pair)
+_DENSE_PRODUCTS = {"x3": 6, "x2": 3, "bf16": 1, "f32": 6}   # gemm_mode -> partial products of the split-bf16 kernels
 
 
 class XPoint(torch.nn.Module):
@@ -69,7 +70,9 @@ class XPoint(torch.nn.Module):
         self._wsplit: Optional[torch.Tensor] = None      # split-bf16 copies of the GEMM weights, derived from _blob on the device
         self._blob_t: Optional[torch.Tensor] = None      # multispectral only: the THERMAL encoder + the same heads
         self._wsplit_t: Optional[torch.Tensor] = None
-        # "x3": dense layers on the bf16 matrix pipe with split operands (fp32-accurate); "f32": exact-f32 MFMA kernels
+        # "x3": dense layers on the bf16 matrix pipe with split operands, 6 partial products (fp32-accurate; the default and the
+        # class pinned against the reference); "f32": exact-f32 MFMA kernels; "x2": 3 partial products (operands to 16 bits);
+        # "bf16": 1 product = bf16 operands, f32 accumulate — the class of the reference's mixed_precision autocast (XPoint.py:182)
         self.gemm_mode = os.environ.get("XP_GEMM_MODE", "x3")
         self._device = torch.device("cpu")
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -342,11 +345,12 @@ class XPoint(torch.nn.Module):
             self._wsplit = None
         n, _, H, W = images.shape
         lib = _lib.load()
-        if self.gemm_mode not in ("x3", "f32"):
-            raise RuntimeError(f"XPoint.gemm_mode must be 'x3' or 'f32', got {self.gemm_mode!r}")
+        if self.gemm_mode not in _DENSE_PRODUCTS:
+            raise RuntimeError(f"XPoint.gemm_mode must be one of {sorted(_DENSE_PRODUCTS)}, got {self.gemm_mode!r}")
+        split_mode = self.gemm_mode != "f32"
         blob = self._blob_t if thermal else self._blob
         ws_split = self._wsplit_t if thermal else self._wsplit
-        if self.gemm_mode == "x3" and ws_split is None:
+        if split_mode and ws_split is None:
             nb = lib.xp_split_weights_bytes(self._ctx)
             ws_split = torch.empty(nb, dtype=torch.uint8, device=dev)
             _lib.check(lib.xp_prepare_split_weights(self._ctx, ptr(blob), ptr(ws_split), ctypes.c_size_t(nb),
@@ -355,7 +359,7 @@ class XPoint(torch.nn.Module):
                 self._wsplit_t = ws_split
             else:
                 self._wsplit = ws_split
-        wsplit = ptr(ws_split) if self.gemm_mode == "x3" else None
+        wsplit = ptr(ws_split) if split_mode else None
         Hc = c_i(); Wc = c_i(); Ce = c_i()
         _lib.check(lib.xp_forward_shapes(self._ctx, n, H, W, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)), "xp_forward_shapes")
         Hc, Wc, Ce = Hc.value, Wc.value, Ce.value
@@ -368,9 +372,18 @@ class XPoint(torch.nn.Module):
         elif tuple(out["enc_nhwc"].shape) != (n, Hc, Wc, Ce) or (want_prob and out.get("prob") is None) or \
                 (want_desc and out.get("desc_nhwc") is None) or (want_logits and out.get("logits_nhwc") is None):
             raise RuntimeError("forward_raw(out=...): buffers do not match this call")
-        _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
-                                         ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
-                                         _lib.current_stream()), "xp_xpoint_forward")
+        # the precision class is process-wide in the library and read when a kernel is launched: set for the duration of this
+        # (host-synchronous) enqueue, then back to the default
+        nprod = _DENSE_PRODUCTS[self.gemm_mode]
+        if nprod != 6:
+            _lib.call("xp_set_dense_products", nprod)
+        try:
+            _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
+                                             ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
+                                             _lib.current_stream()), "xp_xpoint_forward")
+        finally:
+            if nprod != 6:
+                _lib.call("xp_set_dense_products", 6)
         return out
 
     @staticmethod
