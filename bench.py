@@ -255,13 +255,14 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
             if "mlp_fused" in dominant:     # tag (proj_)mlp_fused_x3_c<C>  <->  mlp_fused_kernel<C, 4, PRE>
-                kname = f"mlp_fused_kernel<{dominant.rsplit('_c', 1)[1]}, 4, {'true' if dominant.startswith('proj_') else 'false'}>"
+                kname = f"mlp_fused_kernel<{dominant.rsplit('_c', 1)[1]}, 4, {'true' if dominant.startswith('proj_') else 'false'}, 6>"
                 roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
             else:
                 tiles = dominant.rsplit("_", 1)[1].split("x")
                 cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2",
                         ("128", "32"): "4, 1, 1, 1"}
-                kname = f"{'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, {1 if dominant.startswith('conv3x3') else 0}>"
+                kname = (f"{'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, {1 if dominant.startswith('conv3x3') else 0}"
+                         + (", 6>" if "_x3_" in dominant else ">"))
                 roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
         except Exception:
