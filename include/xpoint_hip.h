@@ -115,6 +115,14 @@ size_t xp_mlp_fused_x3_pack_bytes(int C, int hidden, int with_proj);
 int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, const void* W0x3, void* out, int C, int hidden, void* stream);
 int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
                     const float* b2, int M, int C, int hidden, float eps, void* stream);
+/* The head of the block in the same row-stationary form:  Out (M, N) = LayerNorm(X) W0^T   (VMamba.py:1229 norm + :649
+ * in_proj, bias-free), one launch instead of xp_layernorm + xp_gemm_nt_x3, the normalised rows never written to memory.
+ * W0 (N, C) is passed as the packed stream built by xp_ln_proj_x3_pack from its xp_split_weights_x3 form
+ * (xp_ln_proj_x3_pack_bytes(C, N) bytes; 0 = unsupported: C in {32, 64, 96, 128, 192}, N % 32 == 0).  Out must not alias X. */
+size_t xp_ln_proj_x3_pack_bytes(int C, int N);
+int xp_ln_proj_x3_pack(const void* W0x3, void* out, int C, int N, void* stream);
+int xp_ln_proj_x3(const float* X, const float* ln_w, const float* ln_b, const void* Wpack, float* Out, int M, int C, int N,
+                  float eps, void* stream);
 
 /* Glue kernels (HBM-bound). */
 int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps, int gelu,

@@ -160,6 +160,32 @@ def test_mlp_fused_x3(gpu_lib, M, C, H4, proj):
     assert float((Xg - X3).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("M,C,N", [(300, 96, 96), (1000, 32, 64), (517, 64, 64), (4480, 96, 96), (77, 192, 192), (129, 128, 128), (260, 96, 32)])
+def test_ln_proj_x3(gpu_lib, M, C, N):
+    """LayerNorm + bias-free projection in one launch (VMamba.py:1229 norm + :649 in_proj) vs fp64 torch and vs xp_layernorm + xp_gemm_nt_x3."""
+    L = _lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = L.current_stream()
+    X = _u(f"lpx{M}{C}", (M, C), -2.0, 2.0); lw = _u(f"lpw{C}", (C,), 0.5, 1.5); lb = _u(f"lpb{C}", (C,), -0.5, 0.5); W0 = _u(f"lpW{C}{N}", (N, C), -0.3, 0.3)
+    ref = F.linear(F.layer_norm(X.double(), (C,), lw.double(), lb.double(), 1e-5), W0.double())
+    Xd, lwd, lbd = X.cuda(), lw.cuda(), lb.cuda()
+    W0x = _split_x3(L, W0.cuda())
+    nb = L.load().xp_ln_proj_x3_pack_bytes(C, N)
+    assert nb > 0
+    pack = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    L.call("xp_ln_proj_x3_pack", vp(W0x), vp(pack), C, N, st)
+    out = torch.empty((M, N), device="cuda")
+    L.call("xp_ln_proj_x3", L.ptr(Xd), L.ptr(lwd), L.ptr(lbd), vp(pack), L.ptr(out), M, C, N, 1e-5, st)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    T = torch.empty((M, C), device="cuda"); out2 = torch.empty((M, N), device="cuda")
+    L.call("xp_layernorm", L.ptr(Xd), L.ptr(T), L.ptr(lwd), L.ptr(lbd), M, C, 1e-5, 0, st)
+    L.call("xp_gemm_nt_x3", L.ptr(T), vp(W0x), L.ptr(out2), None, None, None, None, M, N, C, C, N, 0, 0, st)
+    assert float((out - out2).abs().max()) < 1e-5
+    assert torch.equal(Xd.cpu(), X)                       # X is read-only
+    assert L.load().xp_ln_proj_x3_pack_bytes(C, N + 8) == 0 and L.load().xp_ln_proj_x3_pack_bytes(384, 384) == 0
+
+
 def test_dense_precision_classes_kernel_level(gpu_lib):
     """xp_set_dense_products(6 / 3 / 1): a GEMM and the fused block tail against the exact restatement of each class (operands replaced by
     their first bf16 planes, products a0 b0 [+ a0 b1 + a1 b0], wide accumulation): agreement orders of magnitude tighter than the

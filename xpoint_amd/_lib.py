@@ -36,6 +36,8 @@ _SIGNATURES = {
     "xp_conv3x3_nhwc_x3": [c_p] * 6 + [c_i] * 8 + [c_p],
     "xp_mlp_fused_x3": [c_p] * 7 + [c_i] * 3 + [c_f, c_p],
     "xp_mlp_fused_x3_pack": [c_p] * 4 + [c_i] * 2 + [c_p],
+    "xp_ln_proj_x3_pack": [c_p] * 2 + [c_i] * 2 + [c_p],
+    "xp_ln_proj_x3": [c_p] * 5 + [c_i] * 3 + [c_f, c_p],
     "xp_layernorm": [c_p] * 4 + [c_l, c_i, c_f, c_i, c_p],
     "xp_dwconv3x3_silu": [c_p] * 3 + [c_i] * 4 + [c_p],
     "xp_stem_conv_ln_gelu": [c_p] * 6 + [c_i] * 4 + [c_f, c_p],
@@ -78,6 +80,7 @@ _SIZE_QUERIES = {
     "xp_mlp_fused_x3_supported": (c_i, [c_i, c_i]),
     "xp_get_dense_products": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
+    "xp_ln_proj_x3_pack_bytes": (c_sz, [c_i, c_i]),
     "xp_find_homography_workspace_bytes": (c_sz, [c_i]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_match_workspace_bytes": (c_sz, [c_i] * 4),

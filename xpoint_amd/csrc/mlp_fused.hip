@@ -40,6 +40,8 @@ namespace {
 struct MlpParams {
     float* X;                 // (M, C) in / out
     const float* T1;          // PRE: (M, C) input of the preceding bias-free projection  X <- X + T1 W0^T  (SS2D out_proj), else null
+    float* Out;               // projection-only mode: (M, Nout) = LN(X) W0^T, X read-only
+    int Nout;
     const float* ln_w; const float* ln_b;
     const unsigned char* Wpack;   // xp_mlp_fused_x3_pack output
     const float* b1;
@@ -65,9 +67,10 @@ __device__ __forceinline__ int mlp_swap23(int r) { return (r & 0x13) | ((r & 4) 
 
 // One thread per 16-byte unit of the packed stream (see the header comment for the image order).
 template <int C>
-__global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2, const uint4* __restrict__ W0, uint4* __restrict__ out, int H4) {
+__global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2, const uint4* __restrict__ W0, uint4* __restrict__ out, int H4,
+                                int n0) {      // n0 = rows of W0 (C for out_proj ahead of an MLP; any multiple of 32 for a projection-only stream)
     using T = MlpTile<C>;
-    const int NC = H4 / 32, NPRE = W0 ? T::NT : 0;
+    const int NC = H4 / 32, NPRE = W0 ? n0 / 32 : 0;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int upi = T::IMGP / 16;
     if (id >= (int64_t)(NPRE + 2 * NC) * upi) return;
@@ -78,7 +81,7 @@ __global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __res
     if (n < NPRE) {          // the (C, C) projection ahead of the MLP, as NT images in the W1 format (32 permuted output rows x all k slabs)
         if (u < T::UNITS && k < 6) {
             const int s = row >> 5, h = 32 * n + mlp_swap23(row & 31);
-            v = W0[((int64_t)s * C + h) * X3_SLAB_UNITS + k];
+            v = W0[((int64_t)s * n0 + h) * X3_SLAB_UNITS + k];
         }
         out[id] = v;
         return;
@@ -113,9 +116,12 @@ __device__ __forceinline__ float mlp_gelu(float x) {
     return fmaf(-z, e, fmaxf(x, 0.f));
 }
 
-template <int C, int NW, bool PRE, int NP>
+// MODE 0: MLP branch; 1: out_proj + first residual, then the MLP branch; 2: LayerNorm + one bias-free projection only
+// (Out = LN(X) W0^T: the block's norm + in_proj, VMamba.py:1229 / :649), the same row-stationary phases without the MLP.
+template <int C, int NW, int MODE, int NP>
 __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_kernel(MlpParams p) {
     static_assert(NP == 6 || NP == 3 || NP == 1, "partial products per multiply (gemm_x3_core.h)");
+    constexpr bool PRE = MODE == 1, PROJ_ONLY = MODE == 2;
     using T = MlpTile<C>;
     constexpr int KS = T::KS, NT = T::NT;
     constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * (NW * 32) + wave * 32;
     const int mrow = (m0 + fr < p.M) ? m0 + fr : p.M - 1;      // rows past M are computed on a copy of the last row, never stored
-    const int NC = p.H4 / 32, NIMG = 2 * NC + (PRE ? T::NT : 0);
+    const int NC = p.H4 / 32, NIMG = PROJ_ONLY ? p.Nout / 32 : 2 * NC + (PRE ? T::NT : 0);
 
     // image n of the packed stream -> ring slot; every wave moves NI KiB-sized pieces (source: scalar base + lane * 16)
     auto issue_image = [&](int n, int slot) {
@@ -153,8 +159,9 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
             xv[s][1] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
         }
     }
-    for (int i = threadIdx.x; i < p.H4 / 4; i += NW * 64)
-        reinterpret_cast<float4*>(bias_lds)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    if (!PROJ_ONLY)
+        for (int i = threadIdx.x; i < p.H4 / 4; i += NW * 64)
+            reinterpret_cast<float4*>(bias_lds)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     bf16x8 xp[KS][3];          // planes of the B operand of the fc1-type MFMAs: LN(x) of this wave's rows (PRE: first the T1 rows)
     auto layer_norm_split = [&]() {
         float sum = 0.f;
@@ -297,6 +304,28 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     int n = 0, slot = 0;                   // image used by the current phase and its ring slot; image n + 2 goes to slot - 1 (mod 3)
     auto begin_phase = [&]() { if (!(XP_MLP_DBG & 2)) issue_image(n + 2, slot == 0 ? 2 : slot - 1); };
     auto end_phase = [&]() { wait_images(); barrier(); ++n; slot = next_slot(slot); };
+    if constexpr (PROJ_ONLY) {
+        // one fc1-type phase per 32 output columns; registers 8jj .. 8jj+7 of lane-half g are columns 32t + 16jj + 8g + 0..7 of row
+        // m0 + fr (the permuted weight rows again), stored as two float4 per jj
+        float* ow = p.Out + (int64_t)(m0 + fr) * p.Nout + 8 * g;
+        const bool rok = m0 + fr < p.M;
+        for (int t = 0; t < NIMG; ++t) {
+            begin_phase();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h0[r] = 0.f;
+            fc1(slot, h0, h1, std::integral_constant<int, 0>{});
+            end_phase();
+            if (rok) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    *reinterpret_cast<float4*>(ow + 32 * t + 16 * jj) = make_float4(h0[8 * jj + 0], h0[8 * jj + 1], h0[8 * jj + 2], h0[8 * jj + 3]);
+                    *reinterpret_cast<float4*>(ow + 32 * t + 16 * jj + 4) = make_float4(h0[8 * jj + 4], h0[8 * jj + 5], h0[8 * jj + 6], h0[8 * jj + 7]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs past the last image
+        return;
+    }
     if (PRE) {
         // x <- x + T1 W0^T (reference VMamba.py:663 out_proj, :1229 first residual): one fc1-type phase per 32 output channels.  With
         // the permuted weight rows the accumulator registers 8jj .. 8jj+7 of lane-half g are channels 16 (2t + jj) + 8g + 0..7 — the
@@ -378,38 +407,42 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int C, int NW, bool PRE, int NP>
+template <int C, int NW, int MODE, int NP>
 int launch_mlp_np(const MlpParams& p, hipStream_t s) {
+    constexpr bool PRE = MODE == 1;
     using T = MlpTile<C>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, PRE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = std::string(PRE ? "proj_mlp_fused_x3_c" : "mlp_fused_x3_c") + std::to_string(C);      // one tag per kernel instance
+    std::string tag = std::string(MODE == 2 ? "ln_proj_x3_c" : PRE ? "proj_mlp_fused_x3_c" : "mlp_fused_x3_c") + std::to_string(C);      // one tag per kernel instance
     if (NP != 6) tag += "_np" + std::to_string(NP);
     if (by_shape) tag += "_M" + std::to_string(p.M);
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
-    XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
-                     (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, PRE, NP>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
+    XpProfScope prof(tag.c_str(), s, MODE == 2 ? 2.0 * p.M * C * (double)p.Nout : 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
+                     MODE == 2 ? 4.0 * p.M * (C + (double)p.Nout) + 6.0 * C * (double)p.Nout : (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
 
-template <int C, int NW, bool PRE>
+template <int C, int NW, int MODE>
 int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     switch (xp_dense_products_value()) {      // precision class of the dense kernels (xp_set_dense_products)
-        case 1: return launch_mlp_np<C, 4, PRE, 1>(p, s);
-        case 3: return launch_mlp_np<C, 4, PRE, 3>(p, s);
-        default: return launch_mlp_np<C, NW, PRE, 6>(p, s);
+        case 1: return launch_mlp_np<C, 4, MODE, 1>(p, s);
+        case 3: return launch_mlp_np<C, 4, MODE, 3>(p, s);
+        default: return launch_mlp_np<C, NW, MODE, 6>(p, s);
     }
 }
 
 template <int C, int NW>
-int launch_mlp(const MlpParams& p, hipStream_t s) { return p.T1 ? launch_mlp_pre<C, NW, true>(p, s) : launch_mlp_pre<C, NW, false>(p, s); }
+int launch_mlp(const MlpParams& p, hipStream_t s) {
+    if (p.Out) return launch_mlp_pre<C, 4, 2>(p, s);
+    return p.T1 ? launch_mlp_pre<C, NW, 1>(p, s) : launch_mlp_pre<C, NW, 0>(p, s);
+}
 
 template <int C>
 size_t pack_bytes(int H4, int with_proj) { return (size_t)(2 * (H4 / 32) + (with_proj ? MlpTile<C>::NT : 0)) * MlpTile<C>::IMGP; }
@@ -433,11 +466,11 @@ extern "C" int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, const vo
     const int64_t units = (int64_t)(xp_mlp_fused_x3_pack_bytes(C, H4, W0x3 != nullptr) / 16);
     const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
-    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
-    else if (C == 96) hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
-    else if (C == 128) hipLaunchKernelGGL(mlp_pack_kernel<128>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
-    else hipLaunchKernelGGL(mlp_pack_kernel<192>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4);
+    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
+    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
+    else if (C == 96) hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
+    else if (C == 128) hipLaunchKernelGGL(mlp_pack_kernel<128>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
+    else hipLaunchKernelGGL(mlp_pack_kernel<192>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -450,13 +483,53 @@ extern "C" int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, con
     XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)T1 | (uintptr_t)Wpack | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
                  "xp_mlp_fused_x3: pointers must be 16-byte aligned");
     XP_CHECK_ARG(T1 != X, "xp_mlp_fused_x3: T1 must not alias X");
-    MlpParams p{X, T1, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
+    MlpParams p{X, T1, nullptr, 0, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
     hipStream_t s = (hipStream_t)stream;
     static const bool nw8 = getenv("XP_MLP_NW8") != nullptr && atoi(getenv("XP_MLP_NW8")) != 0;     // tuning experiment
     switch (C) {
         case 32: return nw8 ? launch_mlp<32, 8>(p, s) : launch_mlp<32, 4>(p, s);
         case 64: return nw8 ? launch_mlp<64, 8>(p, s) : launch_mlp<64, 4>(p, s);
         case 96: return nw8 ? launch_mlp<96, 8>(p, s) : launch_mlp<96, 4>(p, s);
+        case 128: return launch_mlp<128, 4>(p, s);
+        default: return launch_mlp<192, 4>(p, s);
+    }
+}
+
+extern "C" size_t xp_ln_proj_x3_pack_bytes(int C, int N) {
+    if (!xp_mlp_fused_x3_supported(C, 64) || N <= 0 || N % 32) return 0;
+    return xp_mlp_fused_x3_pack_bytes(C, 64, 0) / 4 * (size_t)(N / 32);      // one image per 32 output columns (the 64-wide MLP stream has 4)
+}
+
+extern "C" int xp_ln_proj_x3_pack(const void* W0x3, void* out, int C, int N, void* stream) {
+    XP_CHECK_ARG(W0x3 && out, "xp_ln_proj_x3_pack: null pointer");
+    XP_CHECK_ARG(xp_ln_proj_x3_pack_bytes(C, N) != 0, "xp_ln_proj_x3_pack: unsupported shape C = %d, N = %d (C in {32, 64, 96, 128, 192}, N %% 32 == 0)", C, N);
+    XP_CHECK_ARG((((uintptr_t)W0x3 | (uintptr_t)out) & 15) == 0, "xp_ln_proj_x3_pack: pointers must be 16-byte aligned");
+    const int64_t units = (int64_t)(xp_ln_proj_x3_pack_bytes(C, N) / 16);
+    const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const uint4* w0 = (const uint4*)W0x3;
+    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
+    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
+    else if (C == 96) hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
+    else if (C == 128) hipLaunchKernelGGL(mlp_pack_kernel<128>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
+    else hipLaunchKernelGGL(mlp_pack_kernel<192>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_ln_proj_x3(const float* X, const float* ln_w, const float* ln_b, const void* Wpack, float* Out, int M, int C, int N,
+                             float eps, void* stream) {
+    XP_CHECK_ARG(X && ln_w && ln_b && Wpack && Out, "xp_ln_proj_x3: null pointer");
+    XP_CHECK_ARG(M > 0, "xp_ln_proj_x3: bad M %d", M);
+    XP_CHECK_ARG(xp_ln_proj_x3_pack_bytes(C, N) != 0, "xp_ln_proj_x3: unsupported shape C = %d, N = %d (C in {32, 64, 96, 128, 192}, N %% 32 == 0)", C, N);
+    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)Out | (uintptr_t)Wpack | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0, "xp_ln_proj_x3: pointers must be 16-byte aligned");
+    XP_CHECK_ARG((const float*)Out != X, "xp_ln_proj_x3: Out must not alias X");
+    MlpParams p{const_cast<float*>(X), nullptr, Out, N, ln_w, ln_b, (const unsigned char*)Wpack, nullptr, nullptr, M, 64, eps};
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 32: return launch_mlp<32, 4>(p, s);
+        case 64: return launch_mlp<64, 4>(p, s);
+        case 96: return launch_mlp<96, 4>(p, s);
         case 128: return launch_mlp<128, 4>(p, s);
         default: return launch_mlp<192, 4>(p, s);
     }

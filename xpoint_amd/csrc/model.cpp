@@ -15,7 +15,7 @@ namespace {
 
 struct Param { std::string name; size_t offset; size_t numel; };
 struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset; };   // a GEMM weight and its split-bf16 copy
-struct MlpPack { std::string block; int C, H4; size_t byte_offset; };                     // fused-MLP weight stream of one VSS block
+struct MlpPack { std::string block; int C, H4; size_t byte_offset, in_offset; };          // weight streams of one VSS block's fused tail (out_proj + MLP) and head (in_proj)
 
 struct Ctx {
     xp_model_cfg cfg;
@@ -50,6 +50,10 @@ struct Ctx {
         for (auto& p : packs) if (p.block == block) return p.byte_offset;
         return (size_t)-1;
     }
+    size_t in_pack_off(const std::string& block) const {
+        for (auto& p : packs) if (p.block == block) return p.in_offset;
+        return (size_t)-1;
+    }
 };
 
 int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1
@@ -75,8 +79,10 @@ void build_layout(Ctx& c) {
             c.add_gemm(b + "fc1_w", (int)H4, (int)C); c.add(b + "fc1_b", H4);
             c.add_gemm(b + "fc2_w", (int)C, (int)H4); c.add(b + "fc2_b", C);
             if (xp_mlp_fused_x3_supported((int)C, (int)H4)) {      // the wide stages run the MLP as one launch (csrc/mlp_fused.hip)
-                c.packs.push_back({b, (int)C, (int)H4, c.split_bytes});
+                c.packs.push_back({b, (int)C, (int)H4, c.split_bytes, 0});
                 c.split_bytes += (xp_mlp_fused_x3_pack_bytes((int)C, (int)H4, 1) + 255) / 256 * 256;
+                c.packs.back().in_offset = c.split_bytes;
+                c.split_bytes += (xp_ln_proj_x3_pack_bytes((int)C, (int)C) + 255) / 256 * 256;
             }
         }
         if (s < c.nstages - 1) {
@@ -197,6 +203,8 @@ extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* w
     for (auto& e : c->packs)
         RUN(xp_mlp_fused_x3_pack((char*)wsplit + c->split_off(e.block + "fc1_w"), (char*)wsplit + c->split_off(e.block + "fc2_w"),
                                  (char*)wsplit + c->split_off(e.block + "out_w"), (char*)wsplit + e.byte_offset, e.C, e.H4, stream));
+    for (auto& e : c->packs)
+        RUN(xp_ln_proj_x3_pack((char*)wsplit + c->split_off(e.block + "in_w"), (char*)wsplit + e.in_offset, e.C, e.C, stream));
     return XP_OK;
 }
 
@@ -243,8 +251,12 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
         for (int j = 0; j < c->cfg.depths[s]; ++j) {
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
-            RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
-            RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
+            if (fuse_mlp && c->pack_off(b) != (size_t)-1) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
+                RUN(xp_ln_proj_x3(X, P(b + "ln1_w"), P(b + "ln1_b"), (const char*)wsplit + c->in_pack_off(b), T2, M, C, C, eps, stream));
+            } else {
+                RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
+                RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
+            }
             RUN(xp_dwconv3x3_silu(T2, P(b + "dw_w"), T3, batch, sh.H[s], sh.W[s], C, stream));
             RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
             RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
