@@ -177,3 +177,22 @@ def test_image_pair_dataset_folder_mode(tmp_path):
         ImagePairDataset({"foldername": str(tmp_path), "height": 128, "width": 96})[0]      # larger than the images
     with pytest.raises(NotImplementedError):
         ImagePairDataset({"foldername": str(tmp_path), "augmentation": {"photometric": {"enable": True}}})
+
+
+def test_product_never_imports_the_oracle_and_has_no_cpu_fallback():
+    """oracle/ is test infrastructure: no module of the product package may import it, and the product path raises (instead of
+    silently computing on the CPU) when handed CPU tensors."""
+    import glob
+    import re
+    pkg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "xpoint_amd")
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        src = open(f).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+    from xpoint_amd import models
+    H, W = 64, 96
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = models.XPoint(cfg)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(cfg).items()}, strict=True)
+    data = synth.to_torch(synth.make_pair_batch(0, 1, H, W))            # CPU tensors
+    with pytest.raises(Exception):
+        net.eval()(data)
