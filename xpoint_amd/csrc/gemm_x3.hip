@@ -152,7 +152,8 @@ int dispatch(const GemmParams& p, hipStream_t s) {
     if (N <= 32) launch<4, 1, 1, 1>(p, s);                                   // 128 x 32
     else if (N <= 64) launch<4, 1, 1, 2>(p, s);                              // 128 x 64
     else if (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) launch<4, 1, 1, 3>(p, s);   // 128 x 96  (N = 65..96, 192)
-    else if (p.M <= 8192 && N >= 512) launch<2, 2, 1, 2>(p, s);              // 64 x 128: more blocks when M is small
+    else if (p.M <= 8192 && N >= 512 && (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 512)
+        launch<2, 2, 1, 2>(p, s);                                            // 64 x 128: more blocks when 128 x 128 tiles would not fill the 2 x 256 slots once
     else launch<2, 2, 2, 2>(p, s);                                           // 128 x 128
     XP_LAUNCH_CHECK();
     return XP_OK;
