@@ -16,9 +16,15 @@
 // of a chunk in LDS with bits 2 and 3 of the row index swapped makes that "row" the hidden unit 8g + (r&7) + 16(r>>3), i.e.
 // registers 0..7 / 8..15 are two natural 16-wide k slabs and W2 needs no permutation.
 //
-// Software pipeline (one wave): the fc1 MFMAs of chunk c+1 are issued with the GELU of chunk c between them (the VALU work
-// runs while the matrix pipe executes), then the fc2 MFMAs of chunk c with the bf16 split of its second half between
-// them.  Two accumulator sets for the hidden chunk alternate.
+// Issue order (one wave): the fc1 MFMAs of chunk c+1 with the GELU of chunk c between them, then the fc2 MFMAs of chunk c with the
+// bf16 split of its second half between them; two accumulator sets for the hidden chunk alternate.  (Inside ONE wave VALU work
+// does not hide under a dependent MFMA chain on this part — tools/coexec_probe.hip — the order only evens out the instruction mix
+// that the second resident wave of the SIMD overlaps with.)
+//
+// The same phases also serve the rest of the block (template MODE): MODE 1 first folds in the SS2D out_proj and the block's first
+// residual (x += t W0^T: fc1-type phases with the t rows as the resident operand; the result lands in the lane layout of the loaded
+// x rows), MODE 2 is LayerNorm + one projection only (the block's norm + in_proj).  NP = 6 / 3 / 1 partial products per multiply
+// (xp_set_dense_products).
 //
 // Only the weights go through LDS, shared by the 4 waves of a workgroup (128 rows).  xp_mlp_fused_x3_pack lays them out once
 // per weight upload as the exact sequence of LDS images the kernel consumes — W1(0), W1(1), W2(0), W1(2), W2(1), ... — each
