@@ -3,7 +3,10 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from xpoint_amd.kernels import selective_scan_fn
 torch.manual_seed(0)
-for (B, K, C, N, L) in [(16, 4, 96, 1, 19200), (16, 4, 192, 1, 4800), (16, 4, 384, 1, 1200), (16, 4, 768, 1, 300), (4, 4, 96, 1, 65536), (8, 4, 96, 16, 4096)]:
+shapes = [(16, 4, 96, 1, 19200), (16, 4, 192, 1, 4800), (16, 4, 384, 1, 1200), (16, 4, 768, 1, 300), (4, 4, 96, 1, 65536), (8, 4, 96, 16, 4096)]
+if os.environ.get("SCAN_ONLY"):
+    shapes = [shapes[int(i)] for i in os.environ["SCAN_ONLY"].split(",")]
+for (B, K, C, N, L) in shapes:
     D = K * C
     u = torch.randn(B, D, L, device="cuda"); delta = 0.5 * torch.rand(B, D, L, device="cuda")
     A = -0.5 * torch.rand(D, N, device="cuda"); Bm = torch.randn(B, K, N, L, device="cuda"); Cm = torch.randn(B, K, N, L, device="cuda")

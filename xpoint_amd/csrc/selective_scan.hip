@@ -10,6 +10,8 @@
 // instruction).  The linear recurrence h_l = a_l h_{l-1} + b_l is evaluated as a scan of
 // (a, b) pairs with op (a1*a0, a1*b0 + b1): 4 items serially per lane, 6 shuffle steps across
 // the wave, and a register carry between chunks.  No LDS, no barriers; HBM-bound.
+#include <stdlib.h>
+
 #include "xp_common.h"
 
 namespace {
@@ -175,6 +177,129 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_n1_kernel(
     if (last_state && lane == 0) last_state[row] = h;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d_state == 1, 16-byte aligned rows: 8 items per lane (512-element chunks), full chunks on a branch-free path (the per-lane
+// `rem` tests of the generic kernel compile to exec-mask branches around every load and store), the 64-lane scan of the
+// (a, b) pairs on DPP moves (row_shr 1/2/4/8, row_bcast 15/31; hipcc lowers __shfl_up to ds_bpermute: 16 LDS crossbar round
+// trips per chunk on the serial path), delta and exp(delta*A) from one logarithm as in the fused SS2D core.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float xp_dpp(float identity, float v) {      // lanes without a source (or outside ROW_MASK) get `identity`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// inclusive scan over the wave of h -> a h + b maps, earlier lanes first: (a, b) <- (a * ea, a * eb + b) with (ea, eb) the incoming prefix
+__device__ __forceinline__ void xp_wave_scan_ab(float& a, float& b) {
+#define XP_SCAN_STEP(CTRL, MASK) { const float ea = xp_dpp<CTRL, MASK>(1.f, a), eb = xp_dpp<CTRL, MASK>(0.f, b); b = fmaf(a, eb, b); a = a * ea; }
+    XP_SCAN_STEP(0x111, 0xf)      // row_shr:1
+    XP_SCAN_STEP(0x112, 0xf)      // row_shr:2
+    XP_SCAN_STEP(0x114, 0xf)      // row_shr:4
+    XP_SCAN_STEP(0x118, 0xf)      // row_shr:8
+    XP_SCAN_STEP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    XP_SCAN_STEP(0x143, 0xc)      // row_bcast:31 into rows 2 and 3
+#undef XP_SCAN_STEP
+}
+
+constexpr int kItems8 = 8, kChunk8 = 64 * kItems8;
+__global__ __launch_bounds__(256) void selective_scan_fwd_n1v2_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv,
+    const float* __restrict__ delta_bias, float* __restrict__ out, float* __restrict__ last_state,
+    int batch, int dim, int delta_dim, int L, int G, int softplus) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)batch * dim) return;
+    const int b = (int)(row / dim), d = (int)(row % dim);
+    const int g = d / (dim / G), dd = d / (dim / delta_dim);
+    const float* up = u + row * L + lane * kItems8;
+    const float* dp = delta + ((int64_t)b * delta_dim + dd) * L + lane * kItems8;
+    const float* Bp = Bm + ((int64_t)b * G + g) * L + lane * kItems8;
+    const float* Cp = Cm + ((int64_t)b * G + g) * L + lane * kItems8;
+    float* op = out + row * L + lane * kItems8;
+    const float Dval = Dv ? Dv[d] : 0.f, bias = delta_bias ? delta_bias[dd] : 0.f, An = A[d];
+    float h = 0.f;
+    // one step's (a, b): delta = softplus(x) (torch threshold 20), a = exp(delta * A); below the threshold both from ONE logarithm:
+    // delta = ln(1 + e^x), a = (1 + e^x)^A = 2^(A log2(1 + e^x))   (same arithmetic as step_vals in ss2d.hip)
+    auto step = [&](float x, float Bu, float& a, float& bb) {
+        float dl;
+        if (!softplus) { dl = x; a = xp_exp_fast(x * An); }
+        else if (x <= 20.f) {
+            const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+            const float uu = 1.f + e;
+            const float l2 = __builtin_amdgcn_logf(uu);
+            const float cc = ((uu - 1.f) - e) * __builtin_amdgcn_rcpf(uu);
+            dl = l2 * 0.693147180559945309f - cc;
+            a = __builtin_amdgcn_exp2f(An * fmaf(cc, -1.44269504088896340736f, l2));
+        } else { dl = x; a = xp_exp_fast(x * An); }
+        bb = dl * Bu;
+    };
+    const int nfull = L / kChunk8;
+    float4 nu[2], nd[2], nb[2], nc[2];
+    auto fetch = [&](int c) {
+        const int o = c * kChunk8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            nu[q] = *reinterpret_cast<const float4*>(up + o + 4 * q); nd[q] = *reinterpret_cast<const float4*>(dp + o + 4 * q);
+            nb[q] = *reinterpret_cast<const float4*>(Bp + o + 4 * q); nc[q] = *reinterpret_cast<const float4*>(Cp + o + 4 * q);
+        }
+    };
+    if (nfull > 0) fetch(0);
+    for (int c = 0; c < nfull; ++c) {
+        float cu[8] = {nu[0].x, nu[0].y, nu[0].z, nu[0].w, nu[1].x, nu[1].y, nu[1].z, nu[1].w};
+        float cd[8] = {nd[0].x, nd[0].y, nd[0].z, nd[0].w, nd[1].x, nd[1].y, nd[1].z, nd[1].w};
+        float cb[8] = {nb[0].x, nb[0].y, nb[0].z, nb[0].w, nb[1].x, nb[1].y, nb[1].z, nb[1].w};
+        float cc[8] = {nc[0].x, nc[0].y, nc[0].z, nc[0].w, nc[1].x, nc[1].y, nc[1].z, nc[1].w};
+        if (c + 1 < nfull) fetch(c + 1);                   // next chunk in flight behind the arithmetic
+        float la[8], lb[8];
+        float pa = 1.f, pb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float a, bb;
+            step(cd[i] + bias, cb[i] * cu[i], a, bb);
+            pb = a * pb + bb; pa = a * pa;
+            la[i] = pa; lb[i] = pb;
+        }
+        float ta = pa, tb = pb;
+        xp_wave_scan_ab(ta, tb);
+        // prefix of the lanes before this one (wave_shr:1; lane 0 gets the identity), applied to the carried state
+        const float ea = xp_dpp<0x138, 0xf>(1.f, ta), eb = xp_dpp<0x138, 0xf>(0.f, tb);
+        const float hin = ea * h + eb;
+        float ov[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = Dval * cu[i] + cc[i] * (la[i] * hin + lb[i]);
+        h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta), 63)) * h + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb), 63));
+        const int o = c * kChunk8;
+        *reinterpret_cast<float4*>(op + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        *reinterpret_cast<float4*>(op + o + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+    }
+    // tail (L % 512 elements): the generic masked path, one 8-item group per lane
+    const int t0 = nfull * kChunk8;
+    if (t0 < L) {
+        const int rem = L - t0 - lane * kItems8;        // may be <= 0
+        float la[8], lb[8], cu[8], cc[8];
+        float pa = 1.f, pb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = i < rem;
+            cu[i] = ok ? up[t0 + i] : 0.f; cc[i] = ok ? Cp[t0 + i] : 0.f;
+            const float dvv = ok ? dp[t0 + i] : 0.f, bvv = ok ? Bp[t0 + i] : 0.f;
+            float a, bb;
+            step(dvv + bias, bvv * cu[i], a, bb);
+            a = ok ? a : 1.f; bb = ok ? bb : 0.f;          // identity past the end keeps last_state right
+            pb = a * pb + bb; pa = a * pa;
+            la[i] = pa; lb[i] = pb;
+        }
+        float ta = pa, tb = pb;
+        xp_wave_scan_ab(ta, tb);
+        const float ea = xp_dpp<0x138, 0xf>(1.f, ta), eb = xp_dpp<0x138, 0xf>(0.f, tb);
+        const float hin = ea * h + eb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i < rem) op[t0 + i] = Dval * cu[i] + cc[i] * (la[i] * hin + lb[i]);
+        h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta), 63)) * h + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb), 63));
+    }
+    if (last_state && lane == 0) last_state[row] = h;
+}
+
 }  // namespace
 
 extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
@@ -192,8 +317,16 @@ extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const f
     const bool vec = (seqlen % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)Bm | (uintptr_t)Cm | (uintptr_t)out) & 15) == 0);
     XpProfScope prof("selective_scan_fwd", s, (9.0 * dstate + 1.0) * batch * dim * (double)seqlen,
                      12.0 * batch * dim * (double)seqlen + 8.0 * batch * ngroups * dstate * (double)seqlen);
+    // d_state = 1: both kernels are VALU-co-limited (52 VALU + 4 transcendentals per element, 70 % VALU-busy at 4.5 TB/s); the 8-item
+    // DPP-scan kernel wins where few rows leave the SIMDs under-occupied (long rows, small batch: 3.9 vs 3.3 TB/s at 1536 rows x 65536),
+    // the 4-item kernel where >= 3 waves per SIMD hide its LDS-crossbar scan (XP_SCAN_V1 / XP_SCAN_V2 force one for A/B runs)
+    static const bool v1 = getenv("XP_SCAN_V1") != nullptr, v2 = getenv("XP_SCAN_V2") != nullptr;
+    const bool use_v2 = v2 || (!v1 && rows < 3072 && seqlen >= 1024);
     if (dstate == 1) {
-        if (vec)
+        if (vec && use_v2)
+            hipLaunchKernelGGL(selective_scan_fwd_n1v2_kernel, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out, last_state,
+                               batch, dim, delta_dim, seqlen, ngroups, delta_softplus);
+        else if (vec)
             hipLaunchKernelGGL(selective_scan_fwd_n1_kernel<true>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out, last_state,
                                batch, dim, delta_dim, seqlen, ngroups, delta_softplus);
         else
