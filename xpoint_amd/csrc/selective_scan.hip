@@ -148,8 +148,10 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_n1_kernel(
 #pragma unroll
         for (int i = 0; i < kItems; ++i) {
             const float t = cd[i] + bias;
-            const float dl = softplus ? xp_softplus_fast(t) : t;
-            const float a = (i < rem) ? xp_exp_fast(dl * An) : 1.f;
+            float dl, aa;
+            if (softplus) xp_softplus_decay(t, An, dl, aa);
+            else { dl = t; aa = xp_exp_fast(t * An); }
+            const float a = (i < rem) ? aa : 1.f;
             const float bb = (i < rem) ? dl * cb[i] * cu[i] : 0.f;
             pb = a * pb + bb; pa = a * pa;
             la[i] = pa; lb[i] = pb;
@@ -222,15 +224,8 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_n1v2_kernel(
     // delta = ln(1 + e^x), a = (1 + e^x)^A = 2^(A log2(1 + e^x))   (same arithmetic as step_vals in ss2d.hip)
     auto step = [&](float x, float Bu, float& a, float& bb) {
         float dl;
-        if (!softplus) { dl = x; a = xp_exp_fast(x * An); }
-        else if (x <= 20.f) {
-            const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
-            const float uu = 1.f + e;
-            const float l2 = __builtin_amdgcn_logf(uu);
-            const float cc = ((uu - 1.f) - e) * __builtin_amdgcn_rcpf(uu);
-            dl = l2 * 0.693147180559945309f - cc;
-            a = __builtin_amdgcn_exp2f(An * fmaf(cc, -1.44269504088896340736f, l2));
-        } else { dl = x; a = xp_exp_fast(x * An); }
+        if (softplus) xp_softplus_decay(x, An, dl, a);
+        else { dl = x; a = xp_exp_fast(x * An); }
         bb = dl * Bu;
     };
     const int nfull = L / kChunk8;

@@ -78,6 +78,37 @@ __device__ __forceinline__ float xp_log1p_fast(float e) {
     const float c = ((u - 1.f) - e) * __builtin_amdgcn_rcpf(u);
     return l - c;
 }
+// One scan step's delta = softplus(x) (torch semantics: beta 1, threshold 20; reference csms6s.py:49-50) and a = exp(delta * A),
+// shared by the fused SS2D core and the operator-boundary selective scan.
+//   e = e^x straight on the exp2 unit (x <= 20 wherever e is used, so the argument scaling costs at most |x| * 6e-8 relative);
+//   e <= 0.14 (the usual case: dt_projs_bias is initialised to softplus^-1 of [1e-3, 0.1], VMamba.py:196-211): ln(1 + e) by its
+//     alternating series to e^8 (truncation e^9 / 9 <= 2.3e-9) and a = 2^(A log2(e) delta): two transcendentals;
+//   else below the threshold: both from ONE logarithm — delta = ln(1 + e), a = (1 + e)^A = 2^(A log2(1 + e)), the logarithm being
+//     v_log_f32 plus the first-order (Kahan) correction for the rounding of 1 + e;
+//   above the threshold: delta = x.
+__device__ __forceinline__ void xp_softplus_decay(float x, float A, float& delta, float& a) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+    if (e <= 0.14f) {
+        float q = fmaf(e, -0.125f, 0.142857142857142857f);
+        q = fmaf(q, e, -0.166666666666666667f);
+        q = fmaf(q, e, 0.2f);
+        q = fmaf(q, e, -0.25f);
+        q = fmaf(q, e, 0.333333333333333333f);
+        q = fmaf(q, e, -0.5f);
+        q = fmaf(q, e, 1.f);
+        delta = q * e;
+        a = __builtin_amdgcn_exp2f(A * 1.44269504088896340736f * delta);
+    } else if (x <= 20.f) {
+        const float uu = 1.f + e;
+        const float l2 = __builtin_amdgcn_logf(uu);                                   // log2(1 + e), ~1 ulp
+        const float cc = ((uu - 1.f) - e) * __builtin_amdgcn_rcpf(uu);                // natural-log units
+        delta = l2 * 0.693147180559945309f - cc;
+        a = __builtin_amdgcn_exp2f(A * fmaf(cc, -1.44269504088896340736f, l2));
+    } else {
+        delta = x;
+        a = xp_exp_fast(x * A);
+    }
+}
 __device__ __forceinline__ float xp_softplus_fast(float x) { return x <= 20.f ? xp_log1p_fast(xp_exp_fast(x)) : x; }
 __device__ __forceinline__ float xp_silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + xp_exp_fast(-x)); }   // ~3 ulp
 __device__ __forceinline__ float xp_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
