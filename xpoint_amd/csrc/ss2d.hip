@@ -26,6 +26,8 @@
 
 namespace {
 
+constexpr float XP_L2E = 1.44269504088896340736f;   // log2(e): folded into the dt weights, the dt bias and A where they are loaded
+
 struct SS2DParams {
     const float* u;      // (B, H, W, C)   after dwconv + SiLU
     const float* xdbl;   // (B*H*W, 4*(R+2))  [pair][dir][dtr(R), B, C]
@@ -69,11 +71,12 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
             xv[2 * q] = t.x; xv[2 * q + 1] = t.y;
         }
     }
-    float dt = w[0] * xv[0];
+    // w, bias and A arrive pre-multiplied by log2(e) (XP_L2E at their loads): the chain below is x * log2(e) directly
+    float dt = fmaf(w[0], xv[0], bias);
 #pragma unroll
     for (int r = 1; r < R; ++r) dt = fmaf(w[r], xv[r], dt);
     float delta;
-    xp_softplus_decay(dt + bias, A, delta, a);     // softplus + exp(delta * A): xp_common.h
+    xp_softplus_decay_l2(dt, A, delta, a);          // softplus + exp(delta * A): xp_common.h
     b = delta * xv[R] * u;
     Cv = xv[R + 1];
 }
@@ -119,11 +122,11 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
         float w0[R], w1[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
-            w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
+            w0[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
+            w1[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
         }
-        const float b0 = p.dtb[(pair * 2 + 0) * p.C + c], b1 = p.dtb[(pair * 2 + 1) * p.C + c];
-        const float A0 = p.A[(pair * 2 + 0) * p.C + c], A1 = p.A[(pair * 2 + 1) * p.C + c];
+        const float b0 = XP_L2E * p.dtb[(pair * 2 + 0) * p.C + c], b1 = XP_L2E * p.dtb[(pair * 2 + 1) * p.C + c];
+        const float A0 = XP_L2E * p.A[(pair * 2 + 0) * p.C + c], A1 = XP_L2E * p.A[(pair * 2 + 1) * p.C + c];
         for (int i0 = 0; i0 < p.T; i0 += 4) {
             float uv[4];
             int px[4];
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     for (int route = 0; route < 2; ++route) {
         float w[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = p.wdt[((int64_t)(pair * 2 + route) * R + r) * p.C + c];
-        const float bias = p.dtb[(pair * 2 + route) * p.C + c], Av = p.A[(pair * 2 + route) * p.C + c];
+        for (int r = 0; r < R; ++r) w[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + route) * R + r) * p.C + c];
+        const float bias = XP_L2E * p.dtb[(pair * 2 + route) * p.C + c], Av = XP_L2E * p.A[(pair * 2 + route) * p.C + c];
         float Pr = 1.f, Sr = 0.f;
         for (int i0 = 0; i0 < p.T; i0 += 4) {
             float uv[4];
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
         // one route's projection weights live at a time (see pass 1)
         float w0[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w0[r] = p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
-        const float b0 = p.dtb[(pair * 2 + 0) * p.C + c];
-        const float A0 = p.A[(pair * 2 + 0) * p.C + c];
+        for (int r = 0; r < R; ++r) w0[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
+        const float b0 = XP_L2E * p.dtb[(pair * 2 + 0) * p.C + c];
+        const float A0 = XP_L2E * p.A[(pair * 2 + 0) * p.C + c];
         const float D0 = p.Dp[(pair * 2 + 0) * p.C + c];
         const float* ub = p.u + (int64_t)b * L * p.C + c;
         const int64_t o = ((((int64_t)b * 2 + pair) * p.nc + chunk) * 2) * p.C + c;
@@ -282,9 +285,9 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
         asm volatile("" ::: "memory");      // keep the second route's weight loads below the forward loop
         float w1[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w1[r] = p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
-        const float b1 = p.dtb[(pair * 2 + 1) * p.C + c];
-        const float A1 = p.A[(pair * 2 + 1) * p.C + c];
+        for (int r = 0; r < R; ++r) w1[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
+        const float b1 = XP_L2E * p.dtb[(pair * 2 + 1) * p.C + c];
+        const float A1 = XP_L2E * p.A[(pair * 2 + 1) * p.C + c];
         const float D1 = p.Dp[(pair * 2 + 1) * p.C + c];
         h = p.wsS[o + p.C];
         const float* prev = COLPAIR ? (p.ya + (int64_t)b * L * p.C + c) : nullptr;
@@ -378,8 +381,8 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan(SS2DParams p, float* __restr
     const int L = p.H * p.W, XD = 4 * RW;
     float w[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) w[r] = p.wdt[((int64_t)d * R + r) * p.C + c];
-    const float bias = p.dtb[d * p.C + c], Av = p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
+    for (int r = 0; r < R; ++r) w[r] = XP_L2E * p.wdt[((int64_t)d * R + r) * p.C + c];
+    const float bias = XP_L2E * p.dtb[d * p.C + c], Av = XP_L2E * p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
     const float* ub = p.u + (int64_t)b * L * p.C + c;
     const float* xb = p.xdbl + (int64_t)b * L * XD + pair * 2 * RW + back * RW + 2 * (lane & 31);
     float* yb = ys + ((int64_t)d * p.Bn + b) * L * p.C + c;

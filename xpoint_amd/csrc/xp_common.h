@@ -86,8 +86,14 @@ __device__ __forceinline__ float xp_log1p_fast(float e) {
 //   else below the threshold: both from ONE logarithm — delta = ln(1 + e), a = (1 + e)^A = 2^(A log2(1 + e)), the logarithm being
 //     v_log_f32 plus the first-order (Kahan) correction for the rounding of 1 + e;
 //   above the threshold: delta = x.
+// xl2 = x * log2(e) (callers that build x from a dot product fold the factor into the weights and the bias: one multiply per step less),
+// Al2 = A * log2(e).
+__device__ __forceinline__ void xp_softplus_decay_l2(float xl2, float Al2, float& delta, float& a);
 __device__ __forceinline__ void xp_softplus_decay(float x, float A, float& delta, float& a) {
-    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+    xp_softplus_decay_l2(x * 1.44269504088896340736f, A * 1.44269504088896340736f, delta, a);
+}
+__device__ __forceinline__ void xp_softplus_decay_l2(float xl2, float Al2, float& delta, float& a) {
+    const float e = __builtin_amdgcn_exp2f(xl2);
     if (e <= 0.14f) {
         float q = fmaf(e, -0.125f, 0.142857142857142857f);
         q = fmaf(q, e, -0.166666666666666667f);
@@ -97,16 +103,16 @@ __device__ __forceinline__ void xp_softplus_decay(float x, float A, float& delta
         q = fmaf(q, e, -0.5f);
         q = fmaf(q, e, 1.f);
         delta = q * e;
-        a = __builtin_amdgcn_exp2f(A * 1.44269504088896340736f * delta);
-    } else if (x <= 20.f) {
+        a = __builtin_amdgcn_exp2f(Al2 * delta);
+    } else if (xl2 <= 20.f * 1.44269504088896340736f) {
         const float uu = 1.f + e;
         const float l2 = __builtin_amdgcn_logf(uu);                                   // log2(1 + e), ~1 ulp
         const float cc = ((uu - 1.f) - e) * __builtin_amdgcn_rcpf(uu);                // natural-log units
         delta = l2 * 0.693147180559945309f - cc;
-        a = __builtin_amdgcn_exp2f(A * fmaf(cc, -1.44269504088896340736f, l2));
+        a = __builtin_amdgcn_exp2f(Al2 * delta);
     } else {
-        delta = x;
-        a = xp_exp_fast(x * A);
+        delta = xl2 * 0.693147180559945309f;
+        a = __builtin_amdgcn_exp2f(Al2 * delta);
     }
 }
 __device__ __forceinline__ float xp_softplus_fast(float x) { return x <= 20.f ? xp_log1p_fast(xp_exp_fast(x)) : x; }
