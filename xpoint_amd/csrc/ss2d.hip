@@ -332,13 +332,11 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
             const float* row = s_y + pi * SY;
             float s = 0.f;
             for (int cc = sub; cc < p.C; cc += 16) s += row[cc];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = xp_row16_sum(s);
             const float mean = s * invC;
             float v = 0.f;
             for (int cc = sub; cc < p.C; cc += 16) { const float d = row[cc] - mean; v = fmaf(d, d, v); }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            v = xp_row16_sum(v);
             const float rstd = 1.f / sqrtf(v * invC + p.eps);
             float* orow = p.out + ((int64_t)b * L + px) * p.C;
             for (int cc = sub; cc < p.C; cc += 16) orow[cc] = (row[cc] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];

@@ -134,14 +134,33 @@ __device__ __forceinline__ float xp_gelu_fast(float x) {
     return 0.5f * x * (x >= 0.f ? 2.f - erfc_abs : erfc_abs);
 }
 
-__device__ __forceinline__ float xp_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on DPP moves (VALU): hipcc lowers __shfl_xor to ds_bpermute_b32, an LDS crossbar round trip per step.
+// row_ror:n rotates inside a row of 16 lanes, so after the four steps every lane of a row holds the row's result.
+template <int CTRL>
+__device__ __forceinline__ float xp_dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xp_row16_sum(float v) {
+    v += xp_dpp_mov<0x128>(v);      // row_ror:8
+    v += xp_dpp_mov<0x124>(v);      // row_ror:4
+    v += xp_dpp_mov<0x122>(v);      // row_ror:2
+    v += xp_dpp_mov<0x121>(v);      // row_ror:1
     return v;
 }
-__device__ __forceinline__ float xp_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float xp_row16_max(float v) {
+    v = fmaxf(v, xp_dpp_mov<0x128>(v));
+    v = fmaxf(v, xp_dpp_mov<0x124>(v));
+    v = fmaxf(v, xp_dpp_mov<0x122>(v));
+    v = fmaxf(v, xp_dpp_mov<0x121>(v));
     return v;
+}
+__device__ __forceinline__ float xp_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float xp_wave_sum(float v) {        // every lane gets the sum of the 64 lanes
+    v = xp_row16_sum(v);
+    return (xp_lane(v, 0) + xp_lane(v, 16)) + (xp_lane(v, 32) + xp_lane(v, 48));
+}
+__device__ __forceinline__ float xp_wave_max(float v) {
+    v = xp_row16_max(v);
+    return fmaxf(fmaxf(xp_lane(v, 0), xp_lane(v, 16)), fmaxf(xp_lane(v, 32), xp_lane(v, 48)));
 }
 #endif
