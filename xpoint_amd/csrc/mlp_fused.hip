@@ -362,15 +362,19 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores and plain loads retired: the counted waits below see only LDS-DMA
     }
     // phase 0 of the MLP: fc1 of chunk 0
-    begin_phase();
+    // (the bias reads come BEFORE the phase's DMA issue: hipcc guards these ds_reads — not the fragment reads — with s_waitcnt vmcnt(0),
+    // which after the issue would wait for the image that was just requested; before it, it waits for one requested a phase ago)
     load_bias(0, h0);
+    __builtin_amdgcn_sched_barrier(0);
+    begin_phase();
     fc1(slot, h0, h1, std::integral_constant<int, 0>{});
     end_phase();
     // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
     //          phase B = fc2(c) (image 2 + 2c)
     auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
-        begin_phase();
         load_bias(c + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        begin_phase();
         fc1(slot, nxt, cur, std::integral_constant<int, 20>{});
         end_phase();
         begin_phase();
