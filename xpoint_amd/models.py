@@ -373,7 +373,8 @@ class XPoint(torch.nn.Module):
                 (want_desc and out.get("desc_nhwc") is None) or (want_logits and out.get("logits_nhwc") is None):
             raise RuntimeError("forward_raw(out=...): buffers do not match this call")
         # the precision class is process-wide in the library and read when a kernel is launched: set for the duration of this
-        # (host-synchronous) enqueue, then back to the default
+        # (host-synchronous) enqueue, then back to the default.  Not safe against OTHER host threads enqueueing dense kernels at the
+        # same time: one enqueueing thread per process (the reference's scripts are single-threaded; multi-GPU = one process per GPU)
         nprod = _DENSE_PRODUCTS[self.gemm_mode]
         if nprod != 6:
             _lib.call("xp_set_dense_products", nprod)
