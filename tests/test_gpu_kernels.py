@@ -609,3 +609,14 @@ def test_image_pair_dataset_load_batch_equals_getitem(gpu_lib, tmp_path):
         assert torch.equal(dev[k]["image"].cpu(), torch.stack([h[k]["image"] for h in host]))
         assert torch.equal(dev[k]["is_optical"].cpu(), torch.stack([h[k]["is_optical"] for h in host]))
         assert dev[k]["valid_mask"].dtype == torch.bool and bool(dev[k]["valid_mask"].all())
+    # ... and the batch is what XPoint.forward takes (reference: DataLoader batch of ImagePairDataset samples -> net(data))
+    from xpoint_amd import models
+    cfg = synth.xpoint_exp1_config(64, 96)
+    net = models.XPoint(cfg)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(cfg).items()}, strict=True)
+    net.to("cuda:0").eval()
+    with torch.no_grad():
+        po, pt, _ = net(dev)
+        ho = {k: {kk: torch.stack([h[k][kk] for h in host]).cuda() for kk in ("image", "valid_mask", "is_optical")} for k in ("optical", "thermal")}
+        qo, qt, _ = net(ho)
+    assert po["prob"].shape == (3, 1, 64, 96) and torch.equal(po["prob"], qo["prob"]) and torch.equal(pt["desc"], qt["desc"])
