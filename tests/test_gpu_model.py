@@ -366,3 +366,37 @@ def test_precision_classes_match_their_cpu_emulation(gpu_lib, mode, nprod, lo, h
     e_base = float((base["prob"].cpu() - ref["prob"]).abs().max())
     assert lo < e_ref < hi, e_ref                       # a genuinely different precision class ...
     assert e_base < 1e-4 and e_base < e_ref              # ... and the default one still meets the bar
+
+
+def test_cli_flows_end_to_end(gpu_lib, tmp_path):
+    """python -m xpoint_amd.cli align / keypoints with the reference scripts' -y / -m / -v / -i options (predict_align_image_pair.py:24-37):
+    YAML + <model-dir>/params.yaml + <version>.model + a folder dataset -> the same keypoints / matches as the library functions."""
+    import os
+    import yaml
+    from PIL import Image
+    from xpoint_amd import cli, datasets, models, predict
+    H, W = 64, 96
+    cfg = synth.xpoint_exp1_config(H, W)
+    rng = np.random.default_rng(3)
+    os.makedirs(tmp_path / "data" / "optical"); os.makedirs(tmp_path / "data" / "thermal"); os.makedirs(tmp_path / "model")
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(tmp_path / "data" / "optical" / f"s{i}.png")
+        Image.fromarray(rng.integers(0, 256, (H, W), dtype=np.uint8)).save(tmp_path / "data" / "thermal" / f"s{i}.png")
+    yaml.safe_dump({"dataset": {"type": "ImagePairDataset", "foldername": str(tmp_path / "data"), "height": H, "width": W},
+                    "prediction": {"detection_threshold": 0.015, "nms": 8, "cpu_nms": True, "topk": 0, "reprojection_threshold": 3,
+                                   "allow_gpu": True, "batchsize": 1, "num_worker": 0}}, open(tmp_path / "cfg.yaml", "w"))
+    yaml.safe_dump({"model": cfg}, open(tmp_path / "model" / "params.yaml", "w"))
+    sd = {"net__" + k: torch.from_numpy(np.array(v)) for k, v in synth.make_state_dict(cfg).items()}     # prefixed keys: fix_model_weigth_keys (utils.py:240-246)
+    torch.save(sd, tmp_path / "model" / "latest.model")
+    out = cli.main(["align", "-y", str(tmp_path / "cfg.yaml"), "-m", str(tmp_path / "model"), "-v", "latest", "-i", "0", "-n", "2", "-e",
+                    "-o", str(tmp_path / "out.npz")])
+    assert os.path.exists(tmp_path / "out.npz") and "1/matches" in out and out["0/H_est"].shape == (3, 3)
+    # the same through the library
+    conf = cli.load_config(str(tmp_path / "cfg.yaml"), str(tmp_path / "model"))
+    ds, net = cli.build(conf, str(tmp_path / "model"), "latest", "cuda:0")
+    with torch.no_grad():
+        _, _, res = predict.predict_align_image_pair(net, ds.load_batch([1], "cuda:0"), conf["prediction"] and {k: conf["prediction"][k] for k in ("detection_threshold", "nms", "cpu_nms", "topk")})
+    assert np.array_equal(out["1/kp_optical"], res[0]["kp_optical"].cpu().numpy())
+    assert out["1/matches"].tolist() == [[m.queryIdx, m.trainIdx] for m in res[0]["matches"]]
+    outk = cli.main(["keypoints", "-y", str(tmp_path / "cfg.yaml"), "-m", str(tmp_path / "model"), "-i", "1"])
+    assert outk["1/kp_thermal"].shape[1] == 2
