@@ -30,7 +30,8 @@
 // per weight upload as the exact sequence of LDS images the kernel consumes — W1(0), W1(1), W2(0), W1(2), W2(1), ... — each
 // 2C rows x 112 B in the padded row format of gemm_x3_core.h (conflict-free ds_read_b128 fragments) with the W1 rows already
 // permuted, so an image is one contiguous block and a wave's LDS-DMA (global_load_lds_dwordx4, no staging registers)
-// needs a scalar base and lane * 16.  Images land two phases ahead in a 3-slot ring; one counted wait + barrier per phase.
+// needs a scalar base and lane * 16.  Images land two phases ahead in a 3-slot ring (their pieces issued between the MFMA groups of
+// the phase); one counted wait + barrier per phase.
 #include <stdlib.h>
 
 #include <string>
@@ -148,6 +149,13 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
 #pragma unroll
         for (int i = 0; i < NI; ++i) __builtin_amdgcn_global_load_lds(src + i * (NW * 1024), (lds_ptr_t)(dst + i * (NW * 1024)), 16, 0, 0);
     };
+    // one piece (i < NI) of image n -> ring slot: lets a phase spread its DMA issue between its MFMA groups (XP_MLP_SPREAD_DMA)
+    auto issue_piece = [&](int n, int slot, int i) {
+        n = n < NIMG ? n : NIMG - 1;
+        const unsigned char* src = p.Wpack + (size_t)n * T::IMGP + wave * 1024 + lane * 16 + i * (NW * 1024);
+        unsigned char* dst = lds + slot * T::IMGP + wave * 1024 + i * (NW * 1024);
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+    };
     // all but the most recently issued image have landed
     auto wait_images = [&]() {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NI) : "memory");
@@ -171,22 +179,22 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     bf16x8 xp[KS][3];          // planes of the B operand of the fc1-type MFMAs: LN(x) of this wave's rows (PRE: first the T1 rows)
     auto layer_norm_split = [&]() {
         float sum = 0.f;
-    #pragma unroll
+#pragma unroll
         for (int s = 0; s < KS; ++s)
             sum += ((xv[s][0].x + xv[s][0].y) + (xv[s][0].z + xv[s][0].w)) + ((xv[s][1].x + xv[s][1].y) + (xv[s][1].z + xv[s][1].w));
         sum += __shfl_xor(sum, 32, 64);
         const float mean = sum / (float)C;
         float q2 = 0.f;
-    #pragma unroll
+#pragma unroll
         for (int s = 0; s < KS; ++s)
-    #pragma unroll
+#pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float dx = xv[s][e].x - mean, dy = xv[s][e].y - mean, dz = xv[s][e].z - mean, dw = xv[s][e].w - mean;
                 q2 = fmaf(dx, dx, q2); q2 = fmaf(dy, dy, q2); q2 = fmaf(dz, dz, q2); q2 = fmaf(dw, dw, q2);
             }
         q2 += __shfl_xor(q2, 32, 64);
         const float rstd = 1.f / sqrtf(q2 / (float)C + p.eps);
-    #pragma unroll
+#pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g), w1 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g + 4);
             const float4 c0 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g), c1 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g + 4);
@@ -243,6 +251,15 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         c.u = make_uint4(hp[j][pl][0], hp[j][pl][1], hp[j][pl][2], hp[j][pl][3]);
         return c.v;
     };
+    int n = 0, slot = 0;                   // image used by the current phase and its ring slot; image n + 2 goes to slot - 1 (mod 3)
+    // The DMA pieces of image n + 2 are issued BETWEEN the MFMA groups of phase n (one piece per k slab / output step), not in one
+    // burst at its start: a few per cent faster (363 vs 375 us at C = 192) — an LDS-DMA issued among MFMAs costs less than one issued
+    // next to other pieces and fragment reads.
+    auto spread = [&](int step, int nsteps) {      // called after MFMA group `step` of `nsteps`: the pieces due by then
+        if (XP_MLP_DBG & 2) return;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(n + 2, slot == 0 ? 2 : slot - 1, i);
+    };
     // VALU slices placed between MFMAs.  Slices 0..15: GELU of element r in place; 16..19 / 20..23: bf16 split of pair q of half 0 / 1.
     auto slice = [&](int k, f32x16& h) {
         if (k < 16) { h[k] = mlp_gelu(h[k]); return; }
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
                 for (int k = (m * NSL + NP * KS - 1) / (NP * KS); k < ((m + 1) * NSL + NP * KS - 1) / (NP * KS); ++k) slice(k, cur);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            spread(s, KS);
         }
     };
     // fc2 of one chunk from the W2 image in `slot`: hidden slab 0 for every output tile first, with the split of half 1
@@ -302,13 +320,12 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            spread(i, 2 * NT);
         }
     };
     auto next_slot = [](int s) { return s == 2 ? 0 : s + 1; };
 
     f32x16 h0, h1;
-    int n = 0, slot = 0;                   // image used by the current phase and its ring slot; image n + 2 goes to slot - 1 (mod 3)
-    auto begin_phase = [&]() { if (!(XP_MLP_DBG & 2)) issue_image(n + 2, slot == 0 ? 2 : slot - 1); };
     auto end_phase = [&]() { wait_images(); barrier(); ++n; slot = next_slot(slot); };
     if constexpr (PROJ_ONLY) {
         // one fc1-type phase per 32 output columns; registers 8jj .. 8jj+7 of lane-half g are columns 32t + 16jj + 8g + 0..7 of row
@@ -316,7 +333,6 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         float* ow = p.Out + (int64_t)(m0 + fr) * p.Nout + 8 * g;
         const bool rok = m0 + fr < p.M;
         for (int t = 0; t < NIMG; ++t) {
-            begin_phase();
 #pragma unroll
             for (int r = 0; r < 16; ++r) h0[r] = 0.f;
             fc1(slot, h0, h1, std::integral_constant<int, 0>{});
@@ -338,7 +354,6 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         // lane layout of xv — so the sum never leaves the registers; the updated rows are stored for the epilogue's residual read.
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            begin_phase();
 #pragma unroll
             for (int r = 0; r < 16; ++r) h0[r] = 0.f;
             fc1(slot, h0, h1, std::integral_constant<int, 0>{});
@@ -366,7 +381,6 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     // which after the issue would wait for the image that was just requested; before it, it waits for one requested a phase ago)
     load_bias(0, h0);
     __builtin_amdgcn_sched_barrier(0);
-    begin_phase();
     fc1(slot, h0, h1, std::integral_constant<int, 0>{});
     end_phase();
     // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
@@ -374,10 +388,8 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
         load_bias(c + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        begin_phase();
         fc1(slot, nxt, cur, std::integral_constant<int, 20>{});
         end_phase();
-        begin_phase();
         fc2(slot, cur);
         end_phase();
     };
