@@ -83,13 +83,15 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
 
 // Shared staging of one block's chunk(s): pixel indices and the xdbl rows of this route pair.
 template <int R>
-__device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair, int chunk0, int* s_pix, float* s_x) {
+__device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair, int chunk0, int* s_pix, int* s_off, float* s_x) {
     const int L = p.H * p.W;
     const int npx = p.cpb * p.T;
     for (int i = threadIdx.x; i < npx; i += blockDim.x) {
         int cl = i / p.T, ii = i - cl * p.T;
         int chunk = chunk0 + cl;
-        s_pix[i] = (chunk < p.nc) ? pixel_of(chunk * p.T + ii, L, p.H, p.W, pair == 1) : -1;
+        const int px = (chunk < p.nc) ? pixel_of(chunk * p.T + ii, L, p.H, p.W, pair == 1) : -1;
+        s_pix[i] = px;
+        s_off[i] = px >= 0 ? px * p.C : -1;      // element offset of the pixel's row: the step loops address u / ya / out with it (no v_mul_lo_u32 per step)
     }
     __syncthreads();
     constexpr int XW = 2 * (R + 2);
@@ -107,10 +109,11 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     extern __shared__ __align__(16) char smem[];
     const int npx = p.cpb * p.T;
     int* s_pix = reinterpret_cast<int*>(smem);
-    float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * npx);
+    int* s_off = s_pix + npx;
+    float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * 2 * npx);
     constexpr int XW = 2 * (R + 2);
     const int b = blockIdx.y, pair = blockIdx.z, chunk0 = blockIdx.x * p.cpb;
-    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_x);
+    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_off, s_x);
     const int cl = threadIdx.x / p.C, c = threadIdx.x - cl * p.C;
     const int chunk = chunk0 + cl;
     if (chunk >= p.nc) return;
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
             int px[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                px[k] = s_pix[cl * p.T + i0 + k];
-                const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];     // 32-bit offsets (host checks B*L*C < 2^31)
+                px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
+                const float t = ub[px[k] >= 0 ? px[k] : 0];             // 32-bit offsets (host checks B*L*C < 2^31)
                 uv[k] = (px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
             int px[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                px[k] = s_pix[cl * p.T + i0 + k];
-                const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];     // 32-bit offsets (host checks B*L*C < 2^31)
+                px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
+                const float t = ub[px[k] >= 0 ? px[k] : 0];             // 32-bit offsets (host checks B*L*C < 2^31)
                 uv[k] = (px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -240,13 +243,14 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     extern __shared__ __align__(16) char smem[];
     const int npx = p.cpb * p.T;
     int* s_pix = reinterpret_cast<int*>(smem);
-    float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * npx);
+    int* s_off = s_pix + npx;
+    float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * 2 * npx);
     constexpr int XW = 2 * (R + 2);
     float* s_y = s_x + npx * XW;   // [npx][C + 8]: the pad keeps the 16-lanes-per-pixel LayerNorm reads of 4 rows off the same banks
     const int SY = p.C + 8;
     const int pair = COLPAIR ? 1 : 0;
     const int b = blockIdx.y, chunk0 = blockIdx.x * p.cpb;
-    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_x);
+    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_off, s_x);
     const int cl = threadIdx.x / p.C, c = threadIdx.x - cl * p.C;
     const int chunk = chunk0 + cl;
     const int L = p.H * p.W;
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
             int px[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                px[k] = s_pix[cl * p.T + i0 + k];
-                const float t = ub[(px[k] >= 0 ? px[k] : 0) * p.C];
+                px[k] = s_off[cl * p.T + i0 + k];
+                const float t = ub[px[k] >= 0 ? px[k] : 0];
                 uv[k] = (px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -297,8 +301,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
             int px[4];
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
-                px[k] = s_pix[cl * p.T + i0 + k];
-                const int po = (px[k] >= 0 ? px[k] : 0) * p.C;
+                px[k] = s_off[cl * p.T + i0 + k];
+                const int po = px[k] >= 0 ? px[k] : 0;
                 const float t = ub[po];
                 uv[k] = (px[k] >= 0) ? t : 0.f;
                 if (COLPAIR) pv[k] = prev[po];
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 const float y2 = cv * h + D1 * uv[k];
                 const float tot = s_y[pi * SY + c] + y2;           // y_fwd + flip(y_bwd)
                 if (COLPAIR) s_y[pi * SY + c] = pv[k] + tot;      // (y0+y2) + (y1+y3)
-                else if (px[k] >= 0) dst[px[k] * p.C] = tot;
+                else if (px[k] >= 0) dst[px[k]] = tot;
             }
         }
     }
@@ -518,7 +522,7 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     constexpr int XW = 2 * (R + 2);
     const int npx = p.cpb * p.T;
     const int threads = p.cpb * p.C;
-    const size_t sm1 = sizeof(int) * npx + sizeof(float) * npx * XW;
+    const size_t sm1 = sizeof(int) * 2 * npx + sizeof(float) * npx * XW;
     const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * (p.C + 8);
     dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
     const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * XW;
