@@ -104,7 +104,9 @@ __device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair
     __syncthreads();
 }
 
-template <int R>
+// FULL: every chunk of every block is complete (L % T == 0 and nc % cpb == 0 — all shapes of the 480 x 640 model): the per-step
+// validity selects (compare + two cndmask per step) are compiled out
+template <int R, bool FULL>
 __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     extern __shared__ __align__(16) char smem[];
     const int npx = p.cpb * p.T;
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
-                const float t = ub[px[k] >= 0 ? px[k] : 0];             // 32-bit offsets (host checks B*L*C < 2^31)
-                uv[k] = (px[k] >= 0) ? t : 0.f;
+                const float t = ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
+                uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
-                const float t = ub[px[k] >= 0 ? px[k] : 0];             // 32-bit offsets (host checks B*L*C < 2^31)
-                uv[k] = (px[k] >= 0) ? t : 0.f;
+                const float t = ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
+                uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(64 * P2_G) void ss2d_pass2(SS2DParams p) {
     for (; jj < j1; ++jj) { const int64_t o = off(jj); const float Pj = p.wsP[o], Sj = p.wsS[o]; p.wsS[o] = h; h = fmaf(Pj, h, Sj); }
 }
 
-template <int R, bool COLPAIR>
+template <int R, bool COLPAIR, bool FULL>
 __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     extern __shared__ __align__(16) char smem[];
     const int npx = p.cpb * p.T;
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];
-                const float t = ub[px[k] >= 0 ? px[k] : 0];
-                uv[k] = (px[k] >= 0) ? t : 0.f;
+                const float t = ub[(FULL || px[k] >= 0) ? px[k] : 0];
+                uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -302,9 +304,9 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
                 px[k] = s_off[cl * p.T + i0 + k];
-                const int po = px[k] >= 0 ? px[k] : 0;
+                const int po = (FULL || px[k] >= 0) ? px[k] : 0;
                 const float t = ub[po];
-                uv[k] = (px[k] >= 0) ? t : 0.f;
+                uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
                 if (COLPAIR) pv[k] = prev[po];
             }
 #pragma unroll
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 const float y2 = cv * h + D1 * uv[k];
                 const float tot = s_y[pi * SY + c] + y2;           // y_fwd + flip(y_bwd)
                 if (COLPAIR) s_y[pi * SY + c] = pv[k] + tot;      // (y0+y2) + (y1+y3)
-                else if (px[k] >= 0) dst[px[k]] = tot;
+                else if (FULL || px[k] >= 0) dst[px[k]] = tot;
             }
         }
     }
@@ -522,6 +524,7 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     constexpr int XW = 2 * (R + 2);
     const int npx = p.cpb * p.T;
     const int threads = p.cpb * p.C;
+    const bool full = (p.H * p.W) % p.T == 0 && p.nc % p.cpb == 0;
     const size_t sm1 = sizeof(int) * 2 * npx + sizeof(float) * npx * XW;
     const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * (p.C + 8);
     dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
@@ -531,7 +534,8 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const double el = 4.0 * MC;   // (pixel, channel, direction) scan elements of the whole core
     {   // reads u + its half of xdbl for each of the two route pairs
         XpProfScope prof(("ss2d_pass1" + sfx).c_str(), s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
-        hipLaunchKernelGGL(ss2d_pass1<R>, grid1, dim3(threads), sm1, s, p);
+        if (full) hipLaunchKernelGGL((ss2d_pass1<R, true>), grid1, dim3(threads), sm1, s, p);
+        else hipLaunchKernelGGL((ss2d_pass1<R, false>), grid1, dim3(threads), sm1, s, p);
     }
     {
         XpProfScope prof(("ss2d_pass2" + sfx).c_str(), s, 0.0, 4.0 * 3.0 * (double)p.Bn * 4 * p.nc * p.C);
@@ -539,11 +543,13 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     }
     {   // read u, xdbl half; write ya
         XpProfScope prof(("ss2d_pass3_row" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
-        hipLaunchKernelGGL((ss2d_pass3<R, false>), grid3, dim3(threads), sm3, s, p);
+        if (full) hipLaunchKernelGGL((ss2d_pass3<R, false, true>), grid3, dim3(threads), sm3, s, p);
+        else hipLaunchKernelGGL((ss2d_pass3<R, false, false>), grid3, dim3(threads), sm3, s, p);
     }
     {   // read u, ya, xdbl half; write out (after out_norm)
         XpProfScope prof(("ss2d_pass3_col_ln" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (3.0 * MC + MX));
-        hipLaunchKernelGGL((ss2d_pass3<R, true>), grid3, dim3(threads), sm3, s, p);
+        if (full) hipLaunchKernelGGL((ss2d_pass3<R, true, true>), grid3, dim3(threads), sm3, s, p);
+        else hipLaunchKernelGGL((ss2d_pass3<R, true, false>), grid3, dim3(threads), sm3, s, p);
     }
     XP_LAUNCH_CHECK();
     return XP_OK;
