@@ -2,7 +2,11 @@
 """bench.py — XPoint hot path throughput on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), and as a plain `python bench.py --gpus N`, in which
+case this process only counts the devices and starts that launcher as a CHILD process (it never initialises the GPU
+itself and never exec()s), forwards its output and exits with its code; fewer than N visible GPUs is exit code 3.
 
 A "step" is one pass of the whole hot path (encode both images with the VMamba encoder, detector +
 descriptor heads, box NMS, keypoint extraction, descriptor sampling, mutual-NN matching) over one batch
@@ -37,7 +41,8 @@ def parse():
     ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (roofline events are then taken in a separate eager pass)")
-    ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (images uploaded from pinned host memory every step); never the headline value")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the extra PCIe-inclusive pass (pcie_inclusive_pairs_per_s: images uploaded from pinned host memory and "
+                                                          "keypoints / match lists downloaded every step; reported beside the headline, never as `value`)")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--split-encoder", type=int, default=2, help="encoder as S image groups on S streams (0/1 = whole batch on one stream); needs overlap")
     ap.add_argument("--register", action="store_true", help="also run the registration step (robust homography per pair) inside every step; not part of the headline metric's definition")
@@ -74,20 +79,53 @@ def cpu_baseline(n_pairs):
                       f"on 8 cores (BASELINE.md)"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the one-process-per-GPU job as a child.
+    Nothing here touches the GPU (torch.cuda.device_count() does not initialise HIP on this image) and nothing exec()s."""
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {visible} visible on this node\n")
+        raise SystemExit(3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run bench.py unwrapped)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    # RCCL is initialised at EVERY world size (world 1 included: a single-rank communicator), so that the weight
+    # broadcast and the result-header all-gather below run through the same code on 1 and on 8 GPUs
+    import torch.distributed as dist
+    rccl = {}
+    try:
+        if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    except Exception as e:
+        if world > 1:
+            raise
+        rccl["rccl_error"] = repr(e)      # world 1 only: the measurement goes on, the JSON line says RCCL did not come up
 
     from xpoint_amd import models, synth
     from xpoint_amd.predict import PairPipeline
@@ -97,8 +135,12 @@ def main():
     cfg = synth.xpoint_exp1_config(H, W)
     net = models.XPoint(cfg).eval()
     net.gemm_mode = args.gemm
-    # shared "pretrained" weights: rank 0 packs, ONE RCCL broadcast over xGMI to the other ranks (no other collective)
-    xdist.broadcast_weights(net, (lambda: synth.make_torch_state_dict(cfg)), src=0, device=dev)
+    # shared "pretrained" weights: rank 0 packs, ONE RCCL broadcast over xGMI to the other ranks (no data-path collective)
+    blob = xdist.broadcast_weights(net, (lambda: synth.make_torch_state_dict(cfg)), src=0, device=dev)
+    if dist.is_initialized():
+        rccl["rccl_ranks"] = dist.get_world_size()
+        rccl["weight_blob_mb"] = round(blob.numel() * 4 / 1e6, 1)
+        rccl["weight_bcast_ms"] = round(xdist.timed_broadcast(blob, src=0, repeats=5), 3)   # steady-state re-broadcasts of the same blob
 
     B = args.pairs
     first, _ = xdist.shard_pairs(world * B, world, rank)   # every rank owns its own contiguous block of pairs
@@ -113,7 +155,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -213,7 +255,7 @@ def main():
             pipe.run(opt, thr, mo, mt)          # leave the buffers holding the headline back end's results
             torch.cuda.synchronize()
     pcie = None
-    if args.h2d:
+    if not args.no_h2d:
         ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
         do, dth = torch.empty_like(opt), torch.empty_like(thr)
         with torch.no_grad():
@@ -228,10 +270,14 @@ def main():
             sync_all()
             pcie = world * B * args.steps / (time.perf_counter() - t1)
     res = pipe.fetch()
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # fixed-size result headers of every rank's last step, all-gathered (the only other collective)
+        hdr = xdist.gather_headers(first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res),
+                                   sum(len(r["match_q"]) for r in res), device=dev)
+        rccl["rank_headers"] = [dict(rank=i, first_pair=h[0], pairs=h[1], keypoints=h[2], matches=h[3]) for i, h in enumerate(hdr)]
 
     if rank == 0:
         avg_s = dom["ms"] / max(dom["launches"], 1) * 1e-3
@@ -300,6 +346,7 @@ def main():
                        "matches_per_pair_mean": round(sum(len(r["match_q"]) for r in res) / len(res), 1)},
             "roofline": roof,
         }
+        out.update(rccl)
         # the other large kernels of the step, each against its own bound (from the untimed single-stream breakdown pass; the
         # `roofline` object above is the dominant one, timed next to the timed region)
         tot_ms = sum(r["ms"] for r in breakdown) or 1.0
@@ -338,7 +385,7 @@ def main():
             except Exception as e:   # the baseline must never hide the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

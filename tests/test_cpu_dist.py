@@ -23,6 +23,25 @@ def test_shard_pairs_partition():
         xdist.shard_pairs(8, 2, 2)
 
 
+def test_headers_without_process_group():
+    assert xdist.gather_headers(5, 8, 33000, 9000) == [(5, 8, 33000, 9000)]
+    assert xdist.timed_broadcast(torch.zeros(4)) == 0.0
+
+
+def test_bench_self_launch_refuses_missing_gpus():
+    """`python bench.py --gpus N` outside torch.distributed.run starts the ranks itself; with fewer than N GPUs
+    visible (none in the CPU container) it must exit 3 with a clear message BEFORE touching any device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() >= 1 else 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    assert f"needs {n} GPUs" in r.stderr
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -46,6 +65,12 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)
     first, cnt = xdist.shard_pairs(6, world, rank)
+    ms = xdist.timed_broadcast(blob, src=0, repeats=2)
+    assert ms > 0.0
+    if rank == 0:
+        assert torch.equal(ref, blob)                                   # re-broadcasts leave the bytes alone
+    hdr = xdist.gather_headers(first, cnt, 100 + rank, 10 + rank)
+    assert hdr == [(0, 3, 100, 10), (3, 3, 101, 11)]
     q.put((rank, [g.tolist() for g in gathered], first, cnt))
     dist.destroy_process_group()
 

@@ -196,3 +196,19 @@ def test_product_never_imports_the_oracle_and_has_no_cpu_fallback():
     data = synth.to_torch(synth.make_pair_batch(0, 1, H, W))            # CPU tensors
     with pytest.raises(Exception):
         net.eval()(data)
+
+
+def test_vmamba_needs_four_stages():
+    """a 3-stage DEPTHS list would size the head for the wrong channel count / resolution; both the Python
+    constructor and the C ABI refuse it (the reference fails with a channel mismatch in the head convolution)."""
+    import ctypes
+    import pytest
+    from xpoint_amd import _lib, models, synth
+    cfg = synth.xpoint_exp1_config(64, 96, vssm={"EMBED_DIM": 32, "DEPTHS": [1, 1, 1]})
+    with pytest.raises(ValueError, match="4 stages"):
+        models.XPoint(cfg)
+    c = models._ModelCfg()
+    c.embed_dim = 32; c.n_stages = 3; c.d_state = 1; c.mlp_ratio = 4.0; c.head_channels = 256; c.desc_size = 256; c.det_channels = 65
+    ctx = ctypes.c_void_p()
+    assert _lib.load().xp_ctx_create(ctypes.byref(c), ctypes.byref(ctx)) != 0
+    assert b"4 stages" in _lib.load().xp_last_error()

@@ -1,0 +1,45 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` (unwrapped, self-launching) — RCCL initialised at every
+world size, one weight broadcast, an all-gather of the result headers, ONE JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(n, extra=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-other-backend", *extra]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+
+
+def test_bench_launcher_rccl_world():
+    world = min(2, torch.cuda.device_count())
+    assert world >= 1
+    r = _run(world)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["rccl_ranks"] == world, out
+    assert "rccl_error" not in out
+    assert out["weight_bcast_ms"] > 0 and out["weight_blob_mb"] > 80
+    hdr = out["rank_headers"]
+    assert [h["rank"] for h in hdr] == list(range(world))
+    assert [h["first_pair"] for h in hdr] == [8 * i for i in range(world)] and all(h["pairs"] == 8 for h in hdr)
+    assert all(h["keypoints"] > 8 * 2 * 3000 and h["matches"] > 8 * 500 for h in hdr), hdr
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["roofline"]["frac"] > 0
+    assert "pcie_inclusive_pairs_per_s" in out
+
+
+def test_bench_launcher_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count() + 1
+    r = _run(n)
+    assert r.returncode == 3 and f"needs {n} GPUs" in r.stderr, (r.returncode, r.stderr[-500:])

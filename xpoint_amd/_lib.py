@@ -143,6 +143,10 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def current_stream():
+def current_stream(device=None):
+    """The current HIP stream of `device` (a torch device / tensor; default: the current device).  Callers whose tensors
+    may live on a device other than the current one pass it, or wrap the call in `torch.cuda.device(...)`."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if device is not None and hasattr(device, "device"):
+        device = device.device
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -58,6 +58,10 @@ struct Ctx {
 
 int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1
 
+// channels of the encoder output = last stage's channels after depth_to_space(4); the one expression the weight layout,
+// xp_forward_shapes and the forward all use
+int enc_channels_of(const Ctx& c) { return c.dims[c.nstages - 1] / 16; }
+
 void build_layout(Ctx& c) {
     const int E = c.cfg.embed_dim, N = c.cfg.d_state;
     c.total = 0; c.split_bytes = 0; c.split.clear(); c.packs.clear();
@@ -90,7 +94,7 @@ void build_layout(Ctx& c) {
             c.add_gemm(d + "w", (int)(2 * C), (int)(9 * C)); c.add(d + "b", 2 * C); c.add(d + "ln_w", 2 * C); c.add(d + "ln_b", 2 * C);
         }
     }
-    const size_t HC = c.cfg.head_channels, EC = E / 2, DS = c.cfg.desc_size, DET = c.cfg.det_channels;
+    const size_t HC = c.cfg.head_channels, EC = enc_channels_of(c), DS = c.cfg.desc_size, DET = c.cfg.det_channels;
     c.add_gemm("head.w", (int)(2 * HC), (int)(9 * EC)); c.add("head.b", 2 * HC); c.add("head.scale", 2 * HC); c.add("head.shift", 2 * HC);
     c.add_gemm("det2.w", (int)DET, (int)HC); c.add("det2.b", DET); c.add("det2.scale", DET); c.add("det2.shift", DET);
     c.add_gemm("desc2.w", (int)DS, (int)HC); c.add("desc2.b", DS); c.add("desc2.scale", DS); c.add("desc2.shift", DS);
@@ -139,7 +143,11 @@ WsPlan plan_ws(const Ctx& c, int batch, const Shapes& s) {
 
 extern "C" int xp_ctx_create(const xp_model_cfg* cfg, void** ctx_out) {
     XP_CHECK_ARG(cfg && ctx_out, "xp_ctx_create: null pointer");
-    XP_CHECK_ARG(cfg->n_stages >= 1 && cfg->n_stages <= 4, "xp_ctx_create: n_stages must be 1..4");
+    // The heads hang off depth_to_space(4) of the LAST stage and the detector's PixelShuffle(8) (XPoint.py:112-125, VMamba.py:1500-1505):
+    // enc channels = dims[L] / 16 must equal embed_dim / 2 and Hc * 8 must equal H, which holds for 4 stages only.  The reference
+    // raises a channel mismatch for any other depth list; so does this.
+    XP_CHECK_ARG(cfg->n_stages == 4, "xp_ctx_create: the XPoint VMamba encoder has exactly 4 stages (got n_stages = %d): the head convolution "
+                 "expects embed_dim / 2 channels at 1/8 resolution", cfg->n_stages);
     XP_CHECK_ARG(cfg->embed_dim % 32 == 0 && (cfg->embed_dim == 96 || cfg->embed_dim == 32),
                  "xp_ctx_create: embed_dim must be 96 (XPoint config) or 32 (reduced test model), got %d", cfg->embed_dim);
     XP_CHECK_ARG(cfg->d_state == 1, "xp_ctx_create: the fused encoder implements d_state == 1 (XPoint config); got %d", cfg->d_state);
@@ -176,7 +184,7 @@ extern "C" int xp_forward_shapes(void* ctx, int batch, int H, int W, int* Hc, in
     XP_CHECK_ARG(ctx, "xp_forward_shapes: null ctx");
     Ctx* c = (Ctx*)ctx; Shapes s;
     XP_CHECK_ARG(shapes_of(*c, batch, H, W, s), "xp_forward_shapes: image too small");
-    if (Hc) *Hc = s.Hc; if (Wc) *Wc = s.Wc; if (enc_channels) *enc_channels = c->cfg.embed_dim / 2;
+    if (Hc) *Hc = s.Hc; if (Wc) *Wc = s.Wc; if (enc_channels) *enc_channels = enc_channels_of(*c);
     return XP_OK;
 }
 
@@ -217,6 +225,7 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     XP_CHECK_ARG(shapes_of(*c, batch, H, W, sh), "xp_xpoint_forward: image too small");
     // The reference mis-sizes its outputs when H or W is not a multiple of 32; the drop-in refuses instead.
     XP_CHECK_ARG(H % 32 == 0 && W % 32 == 0, "xp_xpoint_forward: H and W must be multiples of 32 for the VMamba encoder (got %dx%d)", H, W);
+    XP_CHECK_ARG(sh.Hc * 8 == H && sh.Wc * 8 == W, "xp_xpoint_forward: encoder output %dx%d is not 1/8 of the image", sh.Hc, sh.Wc);
     const WsPlan wp = plan_ws(*c, batch, sh);
     XP_CHECK_ARG(workspace_bytes >= wp.total_floats * sizeof(float), "xp_xpoint_forward: workspace too small");
     float* ws = (float*)workspace;
@@ -284,7 +293,7 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     RUN(xp_depth_to_space_nhwc(X, enc_nhwc, batch, sh.H[L], sh.W[L], c->dims[L], 4, stream));   // VMamba.py:1500-1505
 
     // heads (XPoint.py:112-138, :348-371): shared 3x3 trunk GEMM for both heads, then the two 1x1 convs
-    const int EC = c->dims[L] / 16, HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
+    const int EC = enc_channels_of(*c), HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
     const int Mc = batch * sh.Hc * sh.Wc;
     if (prob || logits_nhwc || desc_nhwc) {
         RUN(conv(enc_nhwc, "head.w", HB, P("head.b"), P("head.scale"), P("head.shift"), sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2));

@@ -159,7 +159,7 @@ class ImagePairDataset:
         imgs = {'optical': None, 'thermal': None}
         flags = {'optical': [], 'thermal': []}
         names = []
-        st = L.current_stream()
+        st = L.current_stream(device)
         keep = []
         for bi, index in enumerate(indices):
             opt8, th8 = self._decode(index)

@@ -39,3 +39,43 @@ def broadcast_weights(net, state_dict_fn=None, src: int = 0, device=None, group=
     if blob.is_cuda:
         net.set_weight_blob(blob)
     return blob
+
+
+def timed_broadcast(blob: torch.Tensor, src: int = 0, repeats: int = 5, group=None) -> float:
+    """Average wall time (ms) of one re-broadcast of `blob` (same bytes, so every rank's copy stays what it is):
+    device events on the current stream for GPU tensors (nccl/RCCL), perf_counter for CPU tensors (gloo).
+    The first, untimed broadcast absorbs communicator set-up.  With one rank the collective is RCCL's
+    single-rank path (no link traffic): the number then only shows that the code path runs."""
+    import time
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return 0.0
+    dist.broadcast(blob, src, group=group)
+    if blob.is_cuda:
+        torch.cuda.synchronize(blob.device)
+        dist.barrier(group=group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(repeats):
+            dist.broadcast(blob, src, group=group)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / repeats
+    dist.barrier(group=group)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        dist.broadcast(blob, src, group=group)
+    return (time.perf_counter() - t0) * 1e3 / repeats
+
+
+def gather_headers(first_pair: int, pairs: int, keypoints: int, matches: int, device=None, group=None):
+    """All-gather of the fixed-size result header (first pair index, pairs, keypoints, matches) of every rank.
+    Returns a list of 4-tuples indexed by rank (a one-element list without an initialised process group)."""
+    import torch.distributed as dist
+    mine = torch.tensor([first_pair, pairs, keypoints, matches], dtype=torch.int64,
+                        device=torch.device(device) if device is not None else torch.device("cpu"))
+    if not dist.is_initialized():
+        return [tuple(int(v) for v in mine.tolist())]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return [tuple(int(v) for v in t.tolist()) for t in out]

@@ -75,7 +75,7 @@ class XPoint(torch.nn.Module):
         # "bf16": 1 product = bf16 operands, f32 accumulate — the class of the reference's mixed_precision autocast (XPoint.py:182)
         self.gemm_mode = os.environ.get("XP_GEMM_MODE", "x3")
         self._device = torch.device("cpu")
-        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws: Dict[str, torch.Tensor] = {}
         self._conv_impl = None
         self._regnet_w = None
         self.encoder_downsample_ratio = 8
@@ -91,6 +91,10 @@ class XPoint(torch.nn.Module):
         if vssm.get('SSM_FORWARDTYPE', 'v05_noz') != 'v05_noz' or float(vssm.get('SSM_RATIO', 1.0)) != 1.0:
             raise NotImplementedError("only SSM_FORWARDTYPE v05_noz / SSM_RATIO 1.0 (the XPoint config) is implemented")
         depths = list(vssm['DEPTHS'])
+        if len(depths) != 4:
+            # the heads expect EMBED_DIM / 2 channels at 1/8 resolution = depth_to_space(4) of a FOURTH stage (XPoint.py:112-125,
+            # VMamba.py:1500-1505); the reference fails with a channel mismatch in the head convolution for any other depth list
+            raise ValueError(f"XPoint: the VMamba encoder needs exactly 4 stages (DEPTHS has {len(depths)} entries)")
         cfg = _ModelCfg()
         cfg.embed_dim = int(vssm['EMBED_DIM']); cfg.n_stages = len(depths)
         for i, d in enumerate(depths):
@@ -267,6 +271,9 @@ class XPoint(torch.nn.Module):
             if self._blob_t is not None and self._blob_t.device != self._device:
                 self._blob_t = self._blob_t.to(self._device)
                 self._wsplit_t = None
+            self._conv_impl = None          # device copies of the conv-encoder / RegNet weights are rebuilt on the new device
+            self._regnet_w = None
+            self._ws.clear()
         return self
 
     def cuda(self, device=None):
@@ -274,12 +281,13 @@ class XPoint(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, n_img, H, W, device):
-        key = (n_img, H, W, str(device))
-        if key not in self._ws:
-            nbytes = _lib.load().xp_forward_workspace_bytes(self._ctx, n_img, H, W)
-            if nbytes == 0:
-                raise RuntimeError(f"XPoint: invalid image size {H}x{W}")
-            self._ws.clear()
+        # one cached buffer per device, grown to the largest request seen (a mixed multispectral batch alternates between
+        # two sub-batch sizes: no reallocation per call)
+        nbytes = _lib.load().xp_forward_workspace_bytes(self._ctx, n_img, H, W)
+        if nbytes == 0:
+            raise RuntimeError(f"XPoint: invalid image size {H}x{W}")
+        key = str(device)
+        if key not in self._ws or self._ws[key].numel() < nbytes:
             self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws[key]
 
@@ -288,6 +296,15 @@ class XPoint(torch.nn.Module):
 
     def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
                     is_optical=None):
+        """See _forward_raw.  Runs with the images' device as the current device, so every launch below goes to THAT
+        device's current stream (the model may live on cuda:N while another device is current)."""
+        if not images.is_cuda:
+            raise RuntimeError("xpoint_amd.XPoint runs on the GPU only (no CPU fallback): move the data to 'cuda'")
+        with torch.cuda.device(images.device):
+            return self._forward_raw(images, want_prob, want_desc, want_logits, out, workspace, is_optical)
+
+    def _forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
+                     is_optical=None):
         """images (N,1,H,W) float32 on the GPU -> dict of NHWC device tensors (no layout exports):
         prob (N,H,W), desc_nhwc (N,Hc,Wc,D), enc_nhwc (N,Hc,Wc,E/2), logits_nhwc (N,Hc,Wc,65).
         out: a dict returned by an earlier call with the same shapes -> its tensors are overwritten instead of
@@ -376,15 +393,16 @@ class XPoint(torch.nn.Module):
         # (host-synchronous) enqueue, then back to the default.  Not safe against OTHER host threads enqueueing dense kernels at the
         # same time: one enqueueing thread per process (the reference's scripts are single-threaded; multi-GPU = one process per GPU)
         nprod = _DENSE_PRODUCTS[self.gemm_mode]
-        if nprod != 6:
+        prev = int(lib.xp_get_dense_products())          # whatever XP_DENSE_PRODUCTS / an earlier caller left: restored afterwards
+        if nprod != prev:
             _lib.call("xp_set_dense_products", nprod)
         try:
             _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                              ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
                                              _lib.current_stream()), "xp_xpoint_forward")
         finally:
-            if nprod != 6:
-                _lib.call("xp_set_dense_products", 6)
+            if nprod != prev:
+                _lib.call("xp_set_dense_products", prev)
         return out
 
     @staticmethod

@@ -43,10 +43,9 @@ def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_
     thr = pred['detection_threshold']
     H, W = data['optical']['image'].shape[2:]
     for out, spec in ((out_o, 'optical'), (out_t, 'thermal')):
-        p = out['prob'] * data[spec]['valid_mask']
-        if pred['nms'] > 0:
-            p = utils.box_nms(p, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'])
-        out['prob'] = p
+        if pred['nms'] > 0:          # the mask is applied only on the NMS branch (predict_align_image_pair.py:194-205)
+            out['prob'] = utils.box_nms(out['prob'] * data[spec]['valid_mask'], pred['nms'], thr, keep_top_k=pred['topk'],
+                                        on_cpu=pred['cpu_nms'])
     results = []
     for i in range(out_o['prob'].shape[0]):
         ko = torch.nonzero((out_o['prob'][i].squeeze() > thr).float())
@@ -110,7 +109,8 @@ class PairPipeline:
         self.pred = _cfg(cfg_prediction)
         self.mode = match_mode
         self.sweeps = int(nms_sweeps)
-        dev = torch.device("cuda")
+        dev = net._device if getattr(net, "_device", None) is not None and net._device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
         n = 2 * self.B
         lib = _lib.load()
         nbuf = 2 if self.overlap else 1
@@ -154,6 +154,12 @@ class PairPipeline:
         self.raw = None
 
     def run(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        if (mask_optical is None) != (mask_thermal is None):
+            raise ValueError("PairPipeline.run: pass both valid masks or neither")
+        with torch.cuda.device(self.device):
+            return self._run(optical, thermal, mask_optical, mask_thermal)
+
+    def _run(self, optical, thermal, mask_optical, mask_thermal):
         if not self.overlap:
             self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
             self._encode(0, None, None)

@@ -170,10 +170,12 @@ def get_matches(desc_1, desc_2, method='bfmatcher', knn_matches=False, mode="str
         raise NotImplementedError("knn_matches (Lowe ratio) is out of scope (configs/cipdp.yaml: knn_matches False)")
     if desc_1.shape[0] == 0 or desc_2.shape[0] == 0:
         return []
-    dev = torch.device("cuda")
+    # device tensors are matched where they live; host arrays (what the reference passes) go to the current device
+    dev = desc_1.device if (torch.is_tensor(desc_1) and desc_1.is_cuda) else torch.device("cuda", torch.cuda.current_device())
     t1 = torch.as_tensor(np.ascontiguousarray(desc_1) if isinstance(desc_1, np.ndarray) else desc_1).to(dev).float()
     t2 = torch.as_tensor(np.ascontiguousarray(desc_2) if isinstance(desc_2, np.ndarray) else desc_2).to(dev).float()
-    res = match_descriptors(t1.unsqueeze(0), t2.unsqueeze(0), None, mode)
+    with torch.cuda.device(dev):
+        res = match_descriptors(t1.unsqueeze(0), t2.unsqueeze(0), None, mode)
     if method == 'bfmatcher' and not kwargs.get('crossCheck', False):
         # BFMatcher default (crossCheck False): the nearest train descriptor of every query
         t = res["idx12"][0].cpu().numpy(); d = res["dist12"][0].cpu().numpy(); q = np.arange(len(t))
