@@ -36,8 +36,8 @@ X3_PRODUCTS = 6                # bf16 MFMA partial products per f32-accurate mul
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # 100 steps = 0.7 s timed: run-to-run spread of a 20-step region was +-5 %
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (roofline events are then taken in a separate eager pass)")
@@ -118,6 +118,8 @@ def main():
     import torch.distributed as dist
     rccl = {}
     try:
+        if world == 1 and os.environ.get("XP_BENCH_NO_RCCL"):       # A/B knob: the timed region without a live communicator
+            raise RuntimeError("XP_BENCH_NO_RCCL set")
         if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
             dist.init_process_group("nccl", device_id=dev)
         else:

@@ -122,6 +122,40 @@ def gen_g14():
     np.savez_compressed(os.path.join(OUT, "g14_multispectral.npz"), **out)
 
 
+def gen_g15(n_pairs=8):
+    """G15 — BASELINE config C2 end to end through the REAL reference: the 8 synthetic 480x640 pairs of bench.py's step
+    (pairs 0..7 = one PairPipeline batch), reference forward -> prob * mask -> box_nms(8, 0.015) -> nonzero ->
+    interpolate_descriptors -> NNMatcher (strict mutual NN, the matcher the repo itself holds; threshold 10 = never cuts).
+    Flow of predict_align_image_pair.py:185-260.  Stored: keypoints (y, x), the reference's score at each keypoint,
+    match index pairs and distances.  int16 / float32, ~0.7 MB."""
+    torch.set_num_threads(1)
+    stubs.install()
+    import xpoint.utils as ref_utils
+    H, W = 480, 640
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = build_ref.build_reference_xpoint(cfg, synth.make_state_dict(cfg))
+    thr, nms = 0.015, 8
+    g = {"meta": np.array([n_pairs, H, W], dtype=np.int32)}
+    for i in range(n_pairs):
+        data = synth.to_torch(synth.make_pair_batch(i, 1, H, W))
+        with torch.no_grad():
+            o, t, _ = net(data)
+        kps, descs = [], []
+        for spec, r in (("optical", o), ("thermal", t)):
+            raw = r["prob"][0, 0].clone()
+            pn = ref_utils.box_nms(r["prob"] * data[spec]["valid_mask"], nms, thr, keep_top_k=0, on_cpu=True)
+            kp = torch.nonzero((pn[0].squeeze() > thr).float())
+            kps.append(kp)
+            descs.append(ref_utils.interpolate_descriptors(kp, r["desc"][0], H, W))
+            g[f"p{i}/kp_{spec}"] = kp.numpy().astype(np.int16)
+            g[f"p{i}/score_{spec}"] = raw[kp[:, 0], kp[:, 1]].numpy()
+        ms = ref_utils.get_matches(descs[0].numpy(), descs[1].numpy(), "nnmatcher", False, threshold=10.0)
+        g[f"p{i}/matches"] = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int16).reshape(-1, 2)
+        g[f"p{i}/match_dist"] = np.array([m.distance for m in ms], dtype=np.float32)
+        print("g15 pair", i, "kpts", len(kps[0]), len(kps[1]), "matches", len(ms), flush=True)
+    np.savez_compressed(os.path.join(OUT, "g15_c2_batch8.npz"), **g)
+
+
 def main():
     torch.set_num_threads(1)
     stubs.install()
@@ -287,8 +321,9 @@ def main():
         print("480x640", spec, "candidates", int((r["prob"] > 0.015).sum()), "kpts", len(kp), "pmax", float(p.max()))
     np.savez_compressed(os.path.join(OUT, "g10_full480x640.npz"), **g10)
 
-    gen_g12(); gen_g13(); gen_g14()
-    manifest["generators"] = {"g1..g11": "main()", "g12_conv_xpoint.npz": "gen_g12()",
+    gen_g12(); gen_g13(); gen_g14(); gen_g15()
+    manifest["generators"] = {"g15_c2_batch8.npz": "gen_g15() (BASELINE config C2: 8 pairs 480x640 end to end)",
+                              "g1..g11": "main()", "g12_conv_xpoint.npz": "gen_g12()",
                               "g13_eval_metrics.npz": "gen_g13() (reference benchmark_evaluation.py functions; cv2 stand-ins in stubs.py)",
                               "g14_multispectral.npz": "gen_g14()"}
     for f in sorted(os.listdir(OUT)):

@@ -1,0 +1,81 @@
+"""CPU: the near-tie attribution helpers (tests/parity.py) and the oracle against the reference's C2 end-to-end
+fixture (tests/golden/g15_c2_batch8.npz: the real reference's keypoints and NNMatcher index pairs at 480x640)."""
+import numpy as np
+import torch
+
+from oracle import xpoint_oracle as xo
+from xpoint_amd import synth
+from tests import parity
+
+
+def _kp(prob, thr=0.3, size=8):
+    p = torch.from_numpy(prob)[None, None]
+    out = xo.box_nms(p, size, thr)
+    return torch.nonzero((out[0, 0] > thr).float()).numpy()
+
+
+def test_keypoint_attribution_explains_budget_noise_and_flags_real_errors():
+    rng = np.random.default_rng(3)
+    prob = rng.random((96, 128)).astype(np.float32)
+    prob = (np.floor(prob * 4096) / 4096).astype(np.float32)          # many exact and near ties
+    noisy = (prob + rng.uniform(-4e-5, 4e-5, prob.shape)).astype(np.float32)
+    a, b = _kp(prob), _kp(noisy)
+    rep, bad = parity.explain_keypoint_diff(b, a, noisy, 0.3, 8, tol=1e-4)
+    assert len(rep) > 0, "the perturbation was meant to flip some decisions"
+    assert not bad, parity.format_report("unexplained", bad)
+    # a keypoint that is simply wrong (far from every tie) must NOT be explained
+    smooth = np.zeros((64, 64), np.float32); smooth[10, 10] = 0.9; smooth[40, 40] = 0.8
+    rep, bad = parity.explain_keypoint_diff(np.array([[10, 10]]), np.array([[10, 10], [40, 40]]), smooth, 0.3, 8)
+    assert len(bad) == 1 and bad[0]["kp"] == (40, 40) and bad[0]["side"] == "reference only"
+    assert parity.explain_keypoint_diff(a, a, prob, 0.3) == ([], [])
+
+
+def test_match_attribution():
+    rng = np.random.default_rng(5)
+    n1, n2, D = 60, 70, 32
+    kpo = np.stack([np.arange(n1), np.arange(n1)], 1); kpt = np.stack([np.arange(n2), 2 * np.arange(n2)], 1)
+    d1 = rng.standard_normal((n1, D)); d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    d2 = rng.standard_normal((n2, D)); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    d2[7] = d1[3]; d2[9] = d1[3] + 1e-7 * rng.standard_normal(D)         # planted near-tie: query 3 -> 7 or 9
+    table = {"optical": {tuple(p): d for p, d in zip(kpo.tolist(), d1)}, "thermal": {tuple(p): d for p, d in zip(kpt.tolist(), d2)}}
+    desc_of = lambda side, pts: np.array([table[side][tuple(p)] for p in pts.tolist()])
+    ms = np.array([[m.queryIdx, m.trainIdx] for m in xo.get_matches(d1.astype(np.float32), d2.astype(np.float32))])
+    assert any(q == 3 for q, _ in ms)
+    flipped = ms.copy(); i = int(np.nonzero(ms[:, 0] == 3)[0][0]); flipped[i, 1] = 16 - ms[i, 1]     # 7 <-> 9
+    rep, bad = parity.explain_match_diff(kpo, kpt, kpo, kpt, flipped, ms, desc_of)
+    assert len(rep) == 2 and not bad, parity.format_report("m", rep)
+    wrong = ms.copy(); j = int(np.nonzero(ms[:, 0] != 3)[0][0]); wrong[j, 1] = (ms[j, 1] + 1) % n2            # a plain error
+    rep, bad = parity.explain_match_diff(kpo, kpt, kpo, kpt, wrong, ms, desc_of)
+    assert bad, "a wrong match with a clear distance gap must be flagged"
+    # a keypoint present on one side only explains the matches it takes part in
+    rep, bad = parity.explain_match_diff(kpo, kpt, kpo, kpt[:-1], ms, ms[ms[:, 1] != n2 - 1], desc_of)
+    assert all("one side only" in r["why"] or "differs between" in r["why"] for r in rep) and not bad
+
+
+def test_oracle_c2_indices_vs_reference_fixture(golden):
+    """The CPU oracle reproduces the REAL reference's 480x640 keypoints and NNMatcher index pairs (pair 0 of the C2 batch);
+    differences, if any, must be attributed (the oracle's forward equals the reference's bit for bit at one thread, but
+    this test runs at the host's thread count)."""
+    g = golden("g15_c2_batch8.npz")
+    H, W = 480, 640
+    cfg = synth.xpoint_exp1_config(H, W)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}
+    data = synth.to_torch(synth.make_pair_batch(0, 1, H, W))
+    with torch.no_grad():
+        res, (o, t, _), _ = xo.predict_align_image_pair(data, sd)
+    r = res[0]
+    for spec, out in (("optical", o), ("thermal", t)):
+        rep, bad = parity.explain_keypoint_diff(r[f"kp_{spec}"].numpy(), g[f"p0/kp_{spec}"], out["prob"][0, 0].numpy(), 0.015, 8, tol=1e-5)
+        assert not bad, parity.format_report(spec, rep)
+    ms = xo.nnmatcher(r["desc_optical"].numpy(), r["desc_thermal"].numpy(), threshold=10.0)
+    mine = np.array([[m.queryIdx, m.trainIdx] for m in ms])
+    if np.array_equal(r["kp_optical"].numpy(), g["p0/kp_optical"]) and np.array_equal(r["kp_thermal"].numpy(), g["p0/kp_thermal"]):
+        same = np.array_equal(mine, g["p0/matches"])
+    else:
+        same = False
+    if not same:
+        do, dt = o["desc"][0], t["desc"][0]
+        desc_of = lambda side, pts: xo.interpolate_descriptors(torch.from_numpy(pts), do if side == "optical" else dt, H, W).numpy()
+        rep, bad = parity.explain_match_diff(r["kp_optical"].numpy(), r["kp_thermal"].numpy(), g["p0/kp_optical"], g["p0/kp_thermal"],
+                                             mine, g["p0/matches"], desc_of, tol=1e-5)
+        assert not bad, parity.format_report("matches", rep)
