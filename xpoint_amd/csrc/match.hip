@@ -2,239 +2,351 @@
 // (cross-check) test.  Replaces cv2.BFMatcher(NORM_L2, crossCheck=True).match as called from
 // reference xpoint/utils/matching.py:4-36 (and the in-repo NNMatcher, matching.py:38-75).
 //
-// CDNA4 mapping.  d2[q,t] = |a_q|^2 + |b_t|^2 - 2 a_q.b_t : the N1 x 256 . 256 x N2 contraction runs on
-// the split-bf16 tile engine (gemm_x3_core.h: fp32-accurate products on the bf16 matrix pipe, 128x128
-// tiles; the prepare kernel writes both descriptor sets as bf16 planes once per image, so the tile
-// kernel stages both operands with straight 16-byte copies), the row/column minima are reduced with wave
-// shuffles inside the tile and merged across tiles with one 64-bit atomicMin per row/column and tile
-// (key = float bits of d2 << 32 | index, so equal distances resolve to the smallest index = first
-// minimum, independent of scheduling).
+// CDNA4 mapping (round 2).  The index result must be that of EXACT arithmetic, so the matrix pipe only has to NOMINATE:
+// every (q, t) whose approximate score is within a proven error bound of its row (column) optimum becomes a candidate,
+// and a second kernel re-evaluates the candidates in direct form with fp64 accumulation (first index wins ties).
+// That freedom is spent on the cheapest matrix arithmetic whose error can still be bounded: ONE fp16 product per
+// multiply (v_mfma_f32_32x32x16_f16, exact products, f32 accumulate) on descriptors rounded once to fp16.
+//   score e(q,t) = a.b - |a|^2/2 - |b|^2/2  (= -d^2/2; maximised).  The two norm terms ride in the contraction itself: every
+//   descriptor image carries one extra 16-wide k slab, [ -|a|^2/2 as hi+lo fp16, 1, 1, 0.. ] on the query side and
+//   [ 1, 1, -|b|^2/2 as hi+lo, 0.. ] on the target side, so the accumulator IS the score and the epilogue is a max.
+//   Descriptors are pre-multiplied by one power of two S per call (largest norm in [1, 2): exact, keeps fp16 in range).
+//   Rows past a pair's count are written as zero descriptors with score -30000: they never win and never qualify, so
+//   the kernels carry no bounds masks at all.
+// Two passes of the same Gram loop (the matrix work is cheap now: 2 x 1 product instead of 3 bf16 products + a heavy
+// epilogue): pass 1 leaves the approximate row / column maxima (running row maxima live in registers across the whole
+// column range of a workgroup, one atomicMax per row and workgroup; column maxima by one coalesced atomicMax per 32
+// columns and wave); pass 2 recomputes the tile and nominates everything within the error bound of those FINAL maxima.
+// A workgroup = 4 waves x 64 query rows; its A operand (64 x 272 fp16 per wave) stays in REGISTERS for the whole
+// kernel, so LDS only carries the target tiles (64 descriptors, LDS-DMA, double buffered, row stride 560 B = conflict-
+// free ds_read_b128), each fragment read feeding two MFMAs.  Grid = (column splits, 256-row strips, pairs), sized by
+// the capacity; strips / splits past the device-side counts exit at once.
 //
-// Index exactness.  fp32 Gram-form distances carry ~1e-7 cancellation noise, which is larger than the
-// smallest best/second-best gaps seen on real data (3e-6).  So the MFMA pass only
-// NOMINATES: every (q,t) whose approximate d2 is within EPS of the running row (column) minimum is
-// appended to that row's (column's) candidate list — a superset of the candidates near the final
-// minimum, because the running minimum only decreases.  A second kernel re-evaluates the nominated
-// pairs in direct form with fp64 accumulation and picks the exact first minimum.  The result is the
-// exact-arithmetic mutual nearest neighbour; it does not depend on fp32 rounding or tile order.
-#include "gemm_x3_core.h"
+// Error bound (scaled units, |a^|, |b^| <= 2): fp16 rounding 2^-12 relative per operand (absolute 2^-25 in the subnormal
+// range) -> |dot error| <= 2^-12 (|a^|^2 + |b^|^2) + 2e-6; norm terms as hi + lo: 2^-22 relative; f32 accumulation over 272
+// terms <= 8.5e-6 (|a^|^2 + |b^|^2).  So |e~ - e| <= E(q,t) / 2 with E = 5.1e-4 (|a^|^2 + |b^|^2) + 4e-6, and the true optimum of
+// row q satisfies e~ >= rowmax~ - E_q,  E_q = 5.1e-4 (|a^_q|^2 + M) + 4e-6,  M = the largest scaled squared norm of the call.
+// Only the number of candidates depends on the bound (measured on 480x640 pairs: 1.2 per row), never the result.
+#include "xp_common.h"
+#include "../../include/xpoint_hip.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* mt_lds_ptr_t;
+
+#ifndef XP_MT_DBG
+#define XP_MT_DBG 0   /* timing experiments only (wrong results): 1 no MFMA, 2 no target-tile DMA after the first, 4 no epilogue, 8 no barrier, 16 no fragment reads */
+#endif
 
 namespace {
 
 constexpr int CAND_CAP = 16;
-// The Gram pass runs THREE of the six split-bf16 partial products (a0 b0 + a0 b1 + a1 b0: half the matrix work).  Error of an
-// approximate d2 = |a|^2 + |b|^2 - 2 a.b, relative to (|a|^2 + |b|^2):
-//   dropped products   2 * 3 * 2^-16 * sum|a_k||b_k| <= 2 * 4.6e-5 * |a||b| <= 4.6e-5 (|a|^2 + |b|^2)      (Cauchy-Schwarz, AM-GM)
-//   f32 accumulation   <= 1e-5 (|a|^2 + |b|^2)                                                               (K = 256, as before)
-// EPS must cover the error of BOTH values it compares (the candidate's and the running minimum's): 2 * 5.6e-5 -> 1.2e-4.
-// Only the number of nominated candidates depends on it (a few per cent of the rows get a second one), never the result.
-constexpr int MATCH_NPROD = 3;
-constexpr float MATCH_EPS = MATCH_NPROD == 3 ? 1.2e-4f : 2e-5f;   // relative to (|a|^2 + |b|^2)
+constexpr float MT_EPS_REL = 5.1e-4f, MT_EPS_ABS = 4e-6f;
+constexpr float MT_DEAD = -30000.f;          // score term of rows past the count (finite in fp16)
+constexpr int MT_STRIP = 256, MT_TILE = 64;  // query rows per workgroup, target descriptors per LDS tile
+constexpr int MT_QCAP = 1020;                // pass 2: entries of the workgroup's LDS hit queue (4 KB with its count word)
 
-struct MatchParams {
-    const float* d1; const float* d2;            // (cap, D) per pair
-    const int* n1p; const int* n2p;               // device counts per pair (may be null -> n1max/n2max)
-    int which1, which2;                           // index into counts for this pair layout (see host)
-    int cap1, cap2, D;
-    const uint4* p1; const uint4* p2;             // descriptors as bf16 planes: [pair][slab][row][plane][16] (xp_split_weights_x3 layout)
-    int nslab;                                    // 16-wide slabs per descriptor (D padded to a multiple of 32)
-    float* na; float* nb;                         // norms^2 (pairs, cap)
-    unsigned long long* rowkey; unsigned long long* colkey;   // (pairs, cap)
-    int* rcnt; int* ccnt; int* rcand; int* ccand; // candidate lists (pairs, cap[, CAND_CAP])
-};
+__host__ __device__ constexpr int mt_rowb(int ksd) { return (ksd * 16 + 16) * 2 + 16; }   // fp16 image row: D values, ext slab, 16 B pad
 
 __device__ __forceinline__ int count_of(const int* p, int idx, int cap) { int n = p ? p[idx] : cap; return n < cap ? n : cap; }
-
-__global__ __launch_bounds__(256) void match_prepare_kernel(const float* __restrict__ d, const int* __restrict__ cnt, int cnt_stride,
-                                                            int cnt_off, int cap, int D, float* __restrict__ nrm,
-                                                            unsigned long long* __restrict__ key, int* __restrict__ ccount,
-                                                            uint2* __restrict__ planes, int nslab) {
-    const int pair = blockIdx.y;
-    const int n = count_of(cnt, pair * cnt_stride + cnt_off, cap);
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= cap) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t o = (int64_t)pair * cap + i;
-    if (i < n) {
-        const float* r = d + o * D;
-        float s = 0.f;
-        for (int c = lane; c < D; c += 64) s = fmaf(r[c], r[c], s);
-        s = xp_wave_sum(s);
-        if (lane == 0) nrm[o] = s;
-        // the row as three bf16 planes (exact split), slab-major so that a tile's slab is one contiguous run
-        for (int q = lane; q < nslab * 4; q += 64) {
-            const int k = q * 4;
-            const float4 v = k < D ? *reinterpret_cast<const float4*>(r + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            uint2 p0, p1, p2;
-            xp_split4(v, p0, p1, p2);
-            uint2* dst = planes + ((((int64_t)pair * nslab + (q >> 2)) * cap + i) * X3_SLAB_UNITS) * 2 + (q & 3);   // 8-byte units
-            dst[0] = p0; dst[4] = p1; dst[8] = p2;
-        }
-    }
-    if (lane == 0) { key[o] = ~0ull; ccount[o] = 0; }
-}
-
+// order-preserving float <-> uint map (atomicMax on scores of either sign)
+__device__ __forceinline__ unsigned mt_ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float mt_unord(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 __device__ __forceinline__ unsigned long long pack_key(float d2, int idx) {
     return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)idx;
 }
+__device__ __forceinline__ float mt_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float mt_max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
-// One 128x128 tile of the distance matrix of one pair.
-__global__ __launch_bounds__(256) void match_tile_kernel(MatchParams p, int cnt_stride) {
-    using T = GemmTileX3<2, 2, 2, 2>;
-    extern __shared__ __align__(16) float lds[];
-    __shared__ unsigned long long s_col[T::BN];
-    const int pair = blockIdx.z;
-    const int n1 = count_of(p.n1p, pair * cnt_stride + p.which1, p.cap1);
-    const int n2 = count_of(p.n2p, pair * cnt_stride + p.which2, p.cap2);
-    const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
-    if (m0 >= n1 || n0 >= n2) return;
-    // rows past n1 / n2 are clamped to row 0: they only feed distances that are overwritten with +inf below
-    const uint4* a_unit[T::AU_LD]; const uint4* b_unit[T::B_LD];
-#pragma unroll
-    for (int s = 0; s < T::AU_LD; ++s) {
-        const int m = m0 + T::au_row(s);
-        a_unit[s] = p.p1 + ((int64_t)pair * p.nslab * p.cap1 + (m < n1 ? m : 0)) * X3_SLAB_UNITS + T::au_unit(s);
-    }
-#pragma unroll
-    for (int s = 0; s < T::B_LD; ++s) {
-        const int n = n0 + T::b_row(s);
-        b_unit[s] = p.p2 + ((int64_t)pair * p.nslab * p.cap2 + (n < n2 ? n : 0)) * X3_SLAB_UNITS + T::b_unit(s);
-    }
-    const int64_t a_slab = (int64_t)p.cap1 * X3_SLAB_UNITS, b_slab = (int64_t)p.cap2 * X3_SLAB_UNITS;
-    const int last = p.nslab - 1;
-    auto ldA = [&](int s, int t) -> uint4 { return a_unit[s][(t < last ? t : last) * a_slab]; };
-    auto ldB = [&](int s, int t) -> uint4 { return b_unit[s][(t < last ? t : last) * b_slab]; };
-    // squared norms of the tile's rows / columns (0 for rows past the counts) and their maxima, staged once: the
-    // nomination passes below test 2 x 64 values per thread against thresholds that depend on them
-    __shared__ float s_na[T::BM], s_nb[T::BN];
-    __shared__ float s_max[2];
-    const float* na = p.na + (int64_t)pair * p.cap1;
-    const float* nb = p.nb + (int64_t)pair * p.cap2;
-    if (threadIdx.x < 2) s_max[threadIdx.x] = 0.f;
-    for (int i = threadIdx.x; i < T::BN; i += 256) s_col[i] = ~0ull;
-    __syncthreads();
-    if (threadIdx.x < T::BM) {
-        const int row = m0 + threadIdx.x;
-        const float v = row < n1 ? na[row] : 0.f;
-        s_na[threadIdx.x] = v;
-        const float mx = xp_wave_max(v);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(&s_max[0]), __float_as_int(mx));   // norms are >= 0: int order = float order
-    } else {
-        const int cl = threadIdx.x - T::BM, col = n0 + cl;
-        const float v = col < n2 ? nb[col] : 0.f;
-        s_nb[cl] = v;
-        const float mx = xp_wave_max(v);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(&s_max[1]), __float_as_int(mx));
-    }
-    f32x16 acc[2][2];
-    T::template run_presplit<MATCH_NPROD>(reinterpret_cast<unsigned char*>(lds), p.nslab * X3_BK, ldA, ldB, acc);   // ends with a barrier, so the s_col init is visible
-
+// ---- pass 0a: squared norms of both descriptor sets and the largest one of the call ----
+__global__ __launch_bounds__(256) void match_norms_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ cnt,
+                                                          int cnt_stride, int which1, int which2, int cap1, int cap2, int D,
+                                                          float* __restrict__ na, float* __restrict__ nb, unsigned* __restrict__ maxbits) {
+    __shared__ float s_m[4];
+    const int pair = blockIdx.y, side = blockIdx.z;
+    const int cap = side ? cap2 : cap1;
+    const int n = count_of(cnt, pair * cnt_stride + (side ? which2 : which1), cap);
+    if (blockIdx.x * 16 >= n) return;
     const int lane = threadIdx.x & 63;
-    const float na_max = s_max[0], nb_max = s_max[1];
-    float nbv[2]; int colg[2];
+    const int i0 = blockIdx.x * 16 + (threadIdx.x >> 6) * 4;       // four rows per wave: four independent 16-byte loads in flight per lane
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { colg[j] = n0 + T::col_of(j); nbv[j] = s_nb[T::col_of(j)]; }
-    // distances in place; invalid entries -> +inf.  The K-loop's LDS is free now: the tile is also written there
-    // ([128][TS] floats) so that ROW minima become in-lane scans (the MFMA layout keeps a row spread over 32 lanes,
-    // a column in one lane's registers).
-    constexpr int TS = 136;   // row stride: conflict-free for the b128 row scans below
-    float* tile = lds;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = T::row_of(i, r), row = m0 + rl;
-            const float nav = s_na[rl];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float d = fmaxf(nav + nbv[j] - 2.f * acc[i][j][r], 0.f);
-                if (row >= n1 || colg[j] >= n2) d = INFINITY;
-                acc[i][j][r] = d;
-                tile[rl * TS + T::col_of(j)] = d;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j < n ? i0 + j : n - 1;
+            v[j] = *reinterpret_cast<const float4*>((side ? d2 : d1) + ((int64_t)pair * cap + i) * D + c);
         }
-    // column minima: in-lane over the 32 rows a lane holds, then the other lane half, then LDS across the two wave rows
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float best = INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {   // rows ascend with (i, r>>2, lane half, r&3): strict < keeps the first minimum
-                const float d = acc[i][j][r];
-                const int rg = m0 + T::row_of(i, r);
-                if (d < best || (d == best && rg < bi)) { best = d; bi = rg; }
-            }
-        unsigned long long k = pack_key(best, bi);
-        const unsigned long long t = __shfl_xor(k, 32, 64);
-        k = t < k ? t : k;
-        if (lane < 32) atomicMin(&s_col[T::col_of(j)], k);
+        for (int j = 0; j < 4; ++j) { acc4[j] = fmaf(v[j].x, v[j].x, acc4[j]); acc4[j] = fmaf(v[j].y, v[j].y, acc4[j]); acc4[j] = fmaf(v[j].z, v[j].z, acc4[j]); acc4[j] = fmaf(v[j].w, v[j].w, acc4[j]); }
     }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t = xp_wave_sum(acc4[j]);
+        if (i0 + j < n) { if (lane == 0) (side ? nb : na)[(int64_t)pair * cap + i0 + j] = t; s = fmaxf(s, t); }
+    }
+    if (lane == 0) s_m[threadIdx.x >> 6] = s;
     __syncthreads();
-    // row minima: thread t scans 64 columns (interleaved 4-wide) of row t/2
-    unsigned long long* rk = p.rowkey + (int64_t)pair * p.cap1;
-    unsigned long long* ck = p.colkey + (int64_t)pair * p.cap2;
+    if (threadIdx.x == 0) {
+        // one atomic per workgroup at most, and only when it can raise the maximum: tens of thousands of atomics on ONE word
+        // serialise (0.7 ms for 65 k rows); the relaxed agent-scope load may lag, which only costs a redundant atomic
+        const float m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        const unsigned cur = __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__float_as_uint(m) > cur) atomicMax(maxbits, __float_as_uint(m));          // m >= 0: uint order = float order
+    }
+}
+
+// ---- pass 0b: fp16 images (scaled by the call's power of two), extension slab, dead rows; resets keys and counters ----
+template <int KSD>
+__global__ __launch_bounds__(256) void match_convert_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ cnt,
+                                                            int cnt_stride, int which1, int which2, int cap1, int cap2, int rows1P, int rows2P, int D,
+                                                            const float* __restrict__ na, const float* __restrict__ nb, const unsigned* __restrict__ maxbits,
+                                                            unsigned char* __restrict__ imgA, unsigned char* __restrict__ imgB,
+                                                            unsigned* __restrict__ rowkey, unsigned* __restrict__ colkey, int* __restrict__ rcnt, int* __restrict__ ccnt) {
+    constexpr int ROWB = mt_rowb(KSD);
+    const int pair = blockIdx.y, side = blockIdx.z;
+    const int cap = side ? cap2 : cap1, rowsP = side ? rows2P : rows1P;
+    const int n = count_of(cnt, pair * cnt_stride + (side ? which2 : which1), cap);
+    const int pad = side ? MT_TILE : MT_STRIP;
+    const int nP = (n + pad - 1) / pad * pad;            // rows the Gram kernels may touch
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nP || i >= rowsP) return;
+    const int lane = threadIdx.x & 63;
+    // S = 2^-floor(log2(sqrt(max norm^2))): the largest scaled norm lies in [1, 2)
+    const float mx = __uint_as_float(*maxbits);
+    int ex = 0;
+    if (mx > 0.f) { (void)frexpf(sqrtf(mx), &ex); ex -= 1; }
+    const float S = ldexpf(1.f, -ex), S2 = S * S;
+    unsigned char* row = (side ? imgB : imgA) + ((int64_t)pair * rowsP + i) * ROWB;
+    const bool live = i < n;
+    const float* r = (side ? d2 : d1) + ((int64_t)pair * cap + (live ? i : 0)) * D;
+    for (int c = lane * 4; c < KSD * 16; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && c < D) v = *reinterpret_cast<const float4*>(r + c);
+        union { _Float16 h[4]; uint2 u; } o;
+        o.h[0] = (_Float16)(v.x * S); o.h[1] = (_Float16)(v.y * S); o.h[2] = (_Float16)(v.z * S); o.h[3] = (_Float16)(v.w * S);
+        *reinterpret_cast<uint2*>(row + c * 2) = o.u;
+    }
+    if (lane == 0) {
+        const float hn = live ? -0.5f * S2 * (side ? nb : na)[(int64_t)pair * cap + i] : MT_DEAD;
+        const _Float16 hi = (_Float16)hn, lo = (_Float16)(hn - (float)hi), one = (_Float16)1.f, z = (_Float16)0.f;
+        union { _Float16 h[24]; uint4 u[3]; } e;
+        for (int k = 0; k < 24; ++k) e.h[k] = z;
+        if (side == 0) { e.h[0] = hi; e.h[1] = lo; e.h[2] = one; e.h[3] = one; }
+        else           { e.h[0] = one; e.h[1] = one; e.h[2] = hi; e.h[3] = lo; }
+        uint4* dst = reinterpret_cast<uint4*>(row + KSD * 32);
+        dst[0] = e.u[0]; dst[1] = e.u[1]; dst[2] = e.u[2];
+        if (side == 0) { rowkey[(int64_t)pair * rows1P + i] = 0u; if (i < cap1) rcnt[(int64_t)pair * cap1 + i] = 0; }
+        else           { colkey[(int64_t)pair * rows2P + i] = 0u; if (i < cap2) ccnt[(int64_t)pair * cap2 + i] = 0; }
+    }
+}
+
+struct GramParams {
+    const unsigned char* A; const unsigned char* B;      // fp16 images [pair][rowsP][ROWB]
+    int rows1P, rows2P;
+    const int* counts; int cnt_stride, which1, which2, cap1, cap2;
+    unsigned* rowkey; unsigned* colkey;                   // ordered-uint approximate maxima, [pair][rowsP]
+    const float* na; const float* nb; const unsigned* maxbits;
+    int* rcnt; int* ccnt; int* rcand; int* ccand;        // candidate lists (pairs, cap[, CAND_CAP])
+    int csplit;
+};
+
+// ---- passes 1 and 2: the Gram loop ----
+template <int KSD, int PASS>
+__global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
+    constexpr int KS = KSD + 1, ROWB = mt_rowb(KSD), TILEB = MT_TILE * ROWB, NPIECE = TILEB / 1024;
+    static_assert(TILEB % 1024 == 0, "a tile must be whole LDS-DMA pieces");
+    extern __shared__ __align__(16) unsigned char lds[];          // two target tiles | pass 2: hit queue (count word + MT_QCAP entries)
+    unsigned* const q_count = reinterpret_cast<unsigned*>(lds + 2 * TILEB);
+    unsigned* const q_entry = q_count + 4;
+    float* const row_thr = reinterpret_cast<float*>(lds + 2 * TILEB + 16 + 4 * MT_QCAP);     // pass 2: [MT_STRIP]
+    if (PASS == 2 && threadIdx.x == 0) *q_count = 0u;             // visible to everybody after the first tile's barrier
+    const int pair = blockIdx.z, strip = blockIdx.y, split = blockIdx.x;
+    const int n1 = count_of(p.counts, pair * p.cnt_stride + p.which1, p.cap1);
+    const int n2 = count_of(p.counts, pair * p.cnt_stride + p.which2, p.cap2);
+    const int r0 = strip * MT_STRIP;
+    if (r0 >= n1 || n2 <= 0) return;
+    const int per = ((n2 + p.csplit - 1) / p.csplit + MT_TILE - 1) / MT_TILE * MT_TILE;
+    const int c_begin = split * per;
+    if (c_begin >= n2) return;
+    const int c_end = min(c_begin + per, (n2 + MT_TILE - 1) / MT_TILE * MT_TILE);
+    const int ntiles = (c_end - c_begin) / MT_TILE;
+    const int lane = threadIdx.x & 63, fr = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr0 = r0 + wave * 64;                               // this wave's first query row
+
+    const unsigned char* Bb = p.B + ((int64_t)pair * p.rows2P + c_begin) * ROWB;
+    auto issue_tile = [&](int t, int buf) {
+        const unsigned char* src = Bb + (int64_t)t * TILEB + lane * 16;
+        unsigned char* dst = lds + buf * TILEB;
+#pragma unroll
+        for (int i = 0; i < (NPIECE + 3) / 4; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < NPIECE) __builtin_amdgcn_global_load_lds(src + piece * 1024, (mt_lds_ptr_t)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue_tile(0, 0);
+
+    // the wave's 64 query rows as MFMA A fragments, resident for the whole kernel
+    f16x8 af[KS][2];
+    {
+        const unsigned char* Ab = p.A + ((int64_t)pair * p.rows1P + wr0 + fr) * ROWB + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) af[ks][rb] = *reinterpret_cast<const f16x8*>(Ab + (int64_t)rb * 32 * ROWB + ks * 32);
+    }
+    // row of register r of row block rb (wave-relative): 32 rb + (r & 3) + 8 (r >> 2) + 4 h
+    float rowv[2][16];     // pass 1 only: running row maxima over this workgroup's columns
+    float Mx = 0.f, S2 = 1.f;
+    if (PASS == 1) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rowv[rb][r] = -INFINITY;
+    } else {
+        // pass 2: the 256 row thresholds of the strip live in LDS (a broadcast ds_read_b128 per four accumulator registers): as
+        // 32 more resident registers they pushed the kernel past the 256 of two waves per SIMD
+        const float mxn = __uint_as_float(*p.maxbits);
+        int ex = 0;
+        if (mxn > 0.f) { (void)frexpf(sqrtf(mxn), &ex); ex -= 1; }
+        S2 = ldexpf(1.f, -2 * ex);
+        Mx = mxn * S2;
+        const int row = r0 + (int)threadIdx.x;
+        const float thr = mt_unord(p.rowkey[(int64_t)pair * p.rows1P + row]) -
+                          (MT_EPS_REL * (p.na[(int64_t)pair * p.cap1 + (row < n1 ? row : n1 - 1)] * S2 + Mx) + MT_EPS_ABS);
+        row_thr[threadIdx.x] = row < n1 ? thr : INFINITY;                 // rows past the count never nominate
+    }
+    unsigned* ck = p.colkey + (int64_t)pair * p.rows2P + c_begin;
     int* rcnt = p.rcnt + (int64_t)pair * p.cap1; int* rcand = p.rcand + (int64_t)pair * p.cap1 * CAND_CAP;
     int* ccnt = p.ccnt + (int64_t)pair * p.cap2; int* ccand = p.ccand + (int64_t)pair * p.cap2 * CAND_CAP;
-    {
-        const int rl = threadIdx.x >> 1, hf = threadIdx.x & 1, row = m0 + rl;
-        const float* trow = tile + rl * TS + 4 * hf;
-        float best = INFINITY; int bi = 0x7fffffff;
+
+    // column thresholds (pass 2) of a tile's two 32-column blocks; loaded one tile ahead and BEFORE that tile's DMA is issued, so
+    // that the wait for them never includes the DMA behind them (vmcnt retires in order)
+    auto col_thresholds = [&](int t, float (&out)[2]) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float4 v = *reinterpret_cast<const float4*>(trow + 8 * m);
-            const int c0 = n0 + 8 * m + 4 * hf;
-            if (v.x < best) { best = v.x; bi = c0; }
-            if (v.y < best) { best = v.y; bi = c0 + 1; }
-            if (v.z < best) { best = v.z; bi = c0 + 2; }
-            if (v.w < best) { best = v.w; bi = c0 + 3; }
+        for (int cb = 0; cb < 2; ++cb) {
+            const int cl = t * MT_TILE + cb * 32 + fr, col = c_begin + cl;
+            const int cc = col < n2 ? col : n2 - 1;               // unconditional loads, clamped (see the row thresholds)
+            const float thr = mt_unord(ck[cc - c_begin]) - (MT_EPS_REL * (p.nb[(int64_t)pair * p.cap2 + cc] * S2 + Mx) + MT_EPS_ABS);
+            out[cb] = col < n2 ? thr : INFINITY;
         }
-        unsigned long long k = pack_key(best, bi);
-        const unsigned long long t = __shfl_xor(k, 1, 64);
-        k = t < k ? t : k;
-        unsigned long long run = k;
-        if (hf == 0 && row < n1) { const unsigned long long old = atomicMin(&rk[row], k); run = old < k ? old : k; }
-        run = __shfl(run, lane & ~1, 64);
-        if (row < n1) {
-            const float rmin = __uint_as_float((unsigned int)(run >> 32));
-            const float nav = s_na[rl];
-            const float loose = rmin + MATCH_EPS * (nav + nb_max + 1e-30f);     // >= every per-column threshold of this tile
+    };
+    float cthr[2] = {INFINITY, INFINITY}, cnext[2] = {INFINITY, INFINITY};
+    if (PASS == 2) col_thresholds(0, cnext);
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        // This wave's pieces of tile t have landed.  Pass 1 leaves its two column-maximum atomics of the previous tile in flight
+        // (issued after the DMA, so "all but the 2 youngest" covers the DMA): an atomic stays counted for thousands of cycles.
+        if (PASS == 1 && t > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(XP_MT_DBG & 8)) __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is done reading tile t - 1
+        if (PASS == 2) { cthr[0] = cnext[0]; cthr[1] = cnext[1]; col_thresholds(t + 1, cnext); }
+        if (t + 1 < ntiles && !(XP_MT_DBG & 2)) issue_tile(t + 1, buf ^ 1);
+        const unsigned char* tb = lds + buf * TILEB + fr * ROWB + h * 16;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const float4 v = *reinterpret_cast<const float4*>(trow + 8 * m);
-                if (!(v.x <= loose || v.y <= loose || v.z <= loose || v.w <= loose)) continue;   // almost always
-                const float dv[4] = {v.x, v.y, v.z, v.w};
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x16_t acc[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cl = 8 * m + 4 * hf + e, c = n0 + cl;
-                    if (c < n2 && dv[e] <= rmin + MATCH_EPS * (nav + s_nb[cl] + 1e-30f)) {
-                        const int pos = atomicAdd(&rcnt[row], 1);
-                        if (pos < CAND_CAP) rcand[(int64_t)row * CAND_CAP + pos] = c;
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+            // target fragments are read two k-steps ahead of the MFMAs that consume them (LDS latency behind the matrix pipe)
+            const unsigned char* tc = tb + cb * 32 * ROWB;
+            f16x8 bq[2] = {*reinterpret_cast<const f16x8*>(tc), *reinterpret_cast<const f16x8*>(tc + 32)};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 bf = bq[ks & 1];
+                if (ks + 2 < KS && !(XP_MT_DBG & 16)) bq[ks & 1] = *reinterpret_cast<const f16x8*>(tc + (ks + 2) * 32);
+                if (XP_MT_DBG & 1) { asm volatile("" :: "v"(bf), "v"(af[ks][0]), "v"(af[ks][1])); continue; }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][0], bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][1], bf, acc[1], 0, 0, 0);
+            }
+            if (XP_MT_DBG & 4) { asm volatile("" :: "v"(acc[0]), "v"(acc[1])); continue; }
+            // The epilogue reads the accumulators from inline asm (v_max_f32 / v_max3_f32 without the canonicalising moves hipcc puts in
+            // front of fmaxf on MFMA results).  hipcc pads no hazards for an asm statement, so the MFMA -> VALU-read wait states
+            // (up to 18 for a 16-pass XDL write) are spent here, once per block, in a statement that owns both accumulators.
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+            if (PASS == 1) {
+                float cm = acc[0][0];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        rowv[rb][r] = mt_max(rowv[rb][r], acc[rb][r]);
+                        rowv[rb][r + 1] = mt_max(rowv[rb][r + 1], acc[rb][r + 1]);
+                        cm = mt_max3(cm, acc[rb][r], acc[rb][r + 1]);
+                    }
+                cm = mt_max(cm, __shfl_xor(cm, 32, 64));
+                if (h == 0) atomicMax(&ck[t * MT_TILE + cb * 32 + fr], mt_ord(cm));
+            } else {
+                // Nomination: one compare pair per element, merged into a wave-wide scalar mask; only when some lane hits (about one
+                // element in 3000) do the hit lanes push (row, column, kind) into the workgroup's LDS queue.  The global candidate
+                // lists are appended to after the column range, all entries in parallel: a returning global atomic per hit inside
+                // this loop would stall the wave for microseconds each time.
+                const int cl = t * MT_TILE + cb * 32 + fr;                   // column, relative to c_begin
+                // One bit per accumulator register and lane, branch-free and without lane masks in scalar registers (64 compare masks
+                // overflow them and get spilled lane by lane; a scalar branch per register drains the instruction buffer 32 times per
+                // block): acc >= thr  <=>  sign bit of (acc - thr) clear, and v_alignbit shifts that sign bit into the mask.
+                // Element i = 16 rb + r ends up, inverted, in bit 31 - i.
+                unsigned rneg = 0u, cneg = 0u;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 rt = *reinterpret_cast<const float4*>(row_thr + wave * 64 + 32 * rb + 8 * g4 + 4 * h);   // rows of registers 4 g4 .. + 3
+                        const float rtv[4] = {rt.x, rt.y, rt.z, rt.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float v = acc[rb][4 * g4 + q];
+                            rneg = __builtin_amdgcn_alignbit(rneg, __float_as_uint(v - rtv[q]), 31);
+                            cneg = __builtin_amdgcn_alignbit(cneg, __float_as_uint(v - cthr[cb]), 31);
+                        }
+                    }
+                const unsigned rbits = ~rneg, cbits = ~cneg;
+                if (__builtin_amdgcn_ballot_w64((rbits | cbits) != 0u)) {          // about 70 % of the blocks hold one or two hits
+                    unsigned bits = rbits | cbits;
+                    while (bits) {
+                        const int bp = __ffs(bits) - 1;
+                        bits &= bits - 1u;
+                        const bool hr = (rbits >> bp) & 1u, hc = (cbits >> bp) & 1u;
+                        const int b = 31 - bp;                               // accumulator register 16 rb + r
+                        const unsigned rl = wave * 64 + 32 * (b >> 4) + (b & 3) + 8 * ((b & 15) >> 2) + 4 * h;     // row, relative to r0
+                        const unsigned e = (unsigned)cl | (rl << 16) | (hr ? 0x40000000u : 0u) | (hc ? 0x80000000u : 0u);
+                        const unsigned pos = atomicAdd(q_count, 1u);
+                        if (pos < MT_QCAP) q_entry[pos] = e;
+                        else {       // queue full (degenerate inputs, e.g. thousands of identical descriptors): mark the lists as
+                                     // overflowed, which sends that row / column to the refine kernel's scan of every target
+                            if (hr) atomicAdd(&rcnt[r0 + (int)rl], CAND_CAP + 1);
+                            if (hc) atomicAdd(&ccnt[c_begin + cl], CAND_CAP + 1);
+                        }
                     }
                 }
             }
         }
     }
-    // merge column minima with the other tiles, then nominate column candidates from the registers
-    for (int i = threadIdx.x; i < T::BN; i += 256)
-        if (n0 + i < n2) { const unsigned long long mine = s_col[i]; const unsigned long long old = atomicMin(&ck[n0 + i], mine); s_col[i] = old < mine ? old : mine; }
-    __syncthreads();
+    if (PASS == 2) {
+        __syncthreads();
+        const unsigned nq = min(*q_count, (unsigned)MT_QCAP);
+        for (unsigned i = threadIdx.x; i < nq; i += 256) {
+            const unsigned e = q_entry[i];
+            const int row = r0 + (int)((e >> 16) & 0x3fffu), col = c_begin + (int)(e & 0xffffu);
+            if (e & 0x40000000u) { const int k = atomicAdd(&rcnt[row], 1); if (k < CAND_CAP) rcand[(int64_t)row * CAND_CAP + k] = col; }
+            if (e & 0x80000000u) { const int k = atomicAdd(&ccnt[col], 1); if (k < CAND_CAP) ccand[(int64_t)col * CAND_CAP + k] = row; }
+        }
+    }
+    if (PASS == 1) {
+        // row maxima: reduce each register over the 32 lanes (columns) of its half, one atomicMax per row and workgroup
+        unsigned* rk = p.rowkey + (int64_t)pair * p.rows1P + wr0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (colg[j] >= n2) continue;
-        const float cmin = __uint_as_float((unsigned int)(s_col[T::col_of(j)] >> 32));
-        const float loose = cmin + MATCH_EPS * (na_max + nbv[j] + 1e-30f);      // >= every per-row threshold of this tile
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (!(acc[i][j][r] <= loose)) continue;                          // almost always (invalid rows hold +inf)
-                const int rl = T::row_of(i, r), row = m0 + rl;
-                if (row >= n1) continue;
-                if (acc[i][j][r] <= cmin + MATCH_EPS * (s_na[rl] + nbv[j] + 1e-30f)) {
-                    const int pos = atomicAdd(&ccnt[colg[j]], 1);
-                    if (pos < CAND_CAP) ccand[(int64_t)colg[j] * CAND_CAP + pos] = row;
-                }
+                float v = xp_row16_max(rowv[rb][r]);
+                v = mt_max(v, __shfl_xor(v, 16, 64));
+                if (fr == 0) atomicMax(&rk[32 * rb + (r & 3) + 8 * (r >> 2) + 4 * h], mt_ord(v));
             }
     }
 }
@@ -318,13 +430,34 @@ __global__ __launch_bounds__(1024) void match_mutual_kernel(const int* __restric
 
 }  // namespace
 
-static int match_nslab(int D) { return ((D + X3_BK - 1) / X3_BK + 1) & ~1; }   // even number of 16-wide slabs
+static int mt_ksd(int D) { return D <= 64 ? 4 : (D <= 128 ? 8 : 16); }
+static size_t mt_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
 extern "C" size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2, int D) {
     const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
-    // rowkey, colkey, scratch (u64) | na, nb (f32) | rcnt, ccnt | rcand, ccand | bf16 planes of both descriptor sets
-    return 8 * (a + b + a) + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 512 +
-           (a + b) * (size_t)match_nslab(D) * X3_SLAB_UNITS * 16;
+    const size_t aP = (size_t)pairs * mt_up(cap1, MT_STRIP), bP = (size_t)pairs * mt_up(cap2, MT_TILE);
+    const size_t rowb = mt_rowb(mt_ksd(D));
+    // rowkey, colkey (u32, padded rows) | scratch (u64) | na, nb | rcnt, ccnt | rcand, ccand | max-norm word | fp16 images of both sets
+    return 4 * (aP + bP) + 8 * a + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 1024 + (aP + bP) * rowb;
+}
+
+template <int KSD>
+static void mt_launch(const GramParams& g, const float* d1, const float* d2, int D, int pairs, hipStream_t s) {
+    constexpr int ROWB = mt_rowb(KSD);
+    constexpr size_t kLds = 2 * (size_t)MT_TILE * ROWB + 16 + 4 * MT_QCAP + 4 * MT_STRIP;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        attr_set = true;
+    }
+    const int rowsmax = g.rows1P > g.rows2P ? g.rows1P : g.rows2P;
+    hipLaunchKernelGGL(match_convert_kernel<KSD>, dim3(xp_cdiv(rowsmax, 4), pairs, 2), dim3(256), 0, s, d1, d2, g.counts, g.cnt_stride, g.which1, g.which2,
+                       g.cap1, g.cap2, g.rows1P, g.rows2P, D, g.na, g.nb, g.maxbits, const_cast<unsigned char*>(g.A), const_cast<unsigned char*>(g.B),
+                       g.rowkey, g.colkey, g.rcnt, g.ccnt);
+    const dim3 grid(g.csplit, g.rows1P / MT_STRIP, pairs);
+    hipLaunchKernelGGL((match_gram_kernel<KSD, 1>), grid, dim3(256), kLds, s, g);
+    hipLaunchKernelGGL((match_gram_kernel<KSD, 2>), grid, dim3(256), kLds, s, g);
 }
 
 // d1 (pairs, cap1, D), d2 (pairs, cap2, D); counts: device int array, n1 of pair i at counts[i*cnt_stride + which1]
@@ -337,45 +470,52 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     XP_CHECK_ARG(d1 && d2 && idx12 && dist12 && idx21 && dist21 && match_q && match_t && match_d && match_count && workspace,
                  "xp_match_mnn: null pointer");
     XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D % 4 == 0, "xp_match_mnn: bad shape (D must be a multiple of 4)");
+    XP_CHECK_ARG(cap1 <= 65536 && cap2 <= 65536, "xp_match_mnn: at most 65536 descriptors per image");
+    XP_CHECK_ARG(D <= 256, "xp_match_mnn: descriptor size %d > 256 (the query strip is register resident; the reference's models use 64 and 256)", D);
     XP_CHECK_ARG(mode == 0 || mode == 1, "xp_match_mnn: mode 0 (strict_mnn) or 1 (legacy_crosscheck)");
     XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2, D), "xp_match_mnn: workspace too small");
     XP_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "xp_match_mnn: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
+    const int rows1P = (int)mt_up(cap1, MT_STRIP), rows2P = (int)mt_up(cap2, MT_TILE);
+    const size_t aP = (size_t)pairs * rows1P, bP = (size_t)pairs * rows2P;
+    const int ksd = mt_ksd(D);
     char* w = (char*)workspace;
-    MatchParams p{};
-    p.d1 = d1; p.d2 = d2; p.n1p = counts; p.n2p = counts; p.which1 = which1; p.which2 = which2;
-    p.cap1 = cap1; p.cap2 = cap2; p.D = D;
-    p.rowkey = (unsigned long long*)w; w += 8 * a;
-    p.colkey = (unsigned long long*)w; w += 8 * b;
+    GramParams g{};
+    g.rows1P = rows1P; g.rows2P = rows2P; g.counts = counts; g.cnt_stride = cnt_stride; g.which1 = which1; g.which2 = which2;
+    g.cap1 = cap1; g.cap2 = cap2;
     unsigned long long* scratch = (unsigned long long*)w; w += 8 * a;
-    p.na = (float*)w; w += 4 * a;
-    p.nb = (float*)w; w += 4 * b;
-    p.rcnt = (int*)w; w += 4 * a;
-    p.ccnt = (int*)w; w += 4 * b;
-    p.rcand = (int*)w; w += 4 * CAND_CAP * a;
-    p.ccand = (int*)w; w += 4 * CAND_CAP * b;
+    g.rowkey = (unsigned*)w; w += 4 * aP;
+    g.colkey = (unsigned*)w; w += 4 * bP;
+    float* na = (float*)w; w += 4 * a;
+    float* nb = (float*)w; w += 4 * b;
+    g.na = na; g.nb = nb;
+    g.rcnt = (int*)w; w += 4 * a;
+    g.ccnt = (int*)w; w += 4 * b;
+    g.rcand = (int*)w; w += 4 * CAND_CAP * a;
+    g.ccand = (int*)w; w += 4 * CAND_CAP * b;
     w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
-    p.nslab = match_nslab(D);
-    uint4* planes1 = (uint4*)w; w += a * (size_t)p.nslab * X3_SLAB_UNITS * 16;
-    uint4* planes2 = (uint4*)w;
-    p.p1 = planes1; p.p2 = planes2;
+    unsigned* maxbits = (unsigned*)w; w += 256;
+    g.maxbits = maxbits;
+    g.A = (const unsigned char*)w; w += aP * mt_rowb(ksd);
+    g.B = (const unsigned char*)w;
+    // enough workgroups to fill the chip twice when the lists are half full; at least one 64-wide tile per split
+    int csplit = xp_cdiv(1024, (int64_t)(rows1P / MT_STRIP) * pairs);
+    csplit = csplit < 1 ? 1 : (csplit > 16 ? 16 : csplit);
+    if (csplit > rows2P / MT_TILE) csplit = rows2P / MT_TILE;
+    g.csplit = csplit;
     XpProfScope prof("match_mnn", s, 0.0, 0.0);   // work depends on device-side counts: bench.py prices it from the fetched counts
-    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, counts, cnt_stride, which1, cap1, D, p.na, p.rowkey, p.rcnt, (uint2*)planes1, p.nslab);
-    hipLaunchKernelGGL(match_prepare_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, counts, cnt_stride, which2, cap2, D, p.nb, p.colkey, p.ccnt, (uint2*)planes2, p.nslab);
-    using T = GemmTileX3<2, 2, 2, 2>;
-    constexpr size_t kTileLds = T::kLdsBytes > sizeof(float) * T::BM * 136 ? T::kLdsBytes : sizeof(float) * T::BM * 136;   // K-loop buffers, then the [128][136] distance tile
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
-        attr_set = true;
-    }
-    dim3 grid(xp_cdiv(cap2, T::BN), xp_cdiv(cap1, T::BM), pairs);
-    hipLaunchKernelGGL(match_tile_kernel, grid, dim3(256), kTileLds, s, p, cnt_stride);
+    XP_HIP(hipMemsetAsync(maxbits, 0, 16, s));
+    const int capmax = cap1 > cap2 ? cap1 : cap2;
+    hipLaunchKernelGGL(match_norms_kernel, dim3(xp_cdiv(capmax, 16), pairs, 2), dim3(256), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D,
+                       na, nb, maxbits);
+    if (ksd == 4) mt_launch<4>(g, d1, d2, D, pairs, s);
+    else if (ksd == 8) mt_launch<8>(g, d1, d2, D, pairs, s);
+    else mt_launch<16>(g, d1, d2, D, pairs, s);
     hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
-                       cap1, cap2, D, p.rcnt, p.rcand, idx12, dist12);
+                       cap1, cap2, D, g.rcnt, g.rcand, idx12, dist12);
     hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, d1, counts, counts, cnt_stride, which2, which1,
-                       cap2, cap1, D, p.ccnt, p.ccand, idx21, dist21);
+                       cap2, cap1, D, g.ccnt, g.ccand, idx21, dist21);
     hipLaunchKernelGGL(match_mutual_kernel, dim3(pairs), dim3(1024), 0, s, idx12, dist12, idx21, dist21, counts, counts, cnt_stride, which1,
                        which2, cap1, cap2, mode, match_q, match_t, match_d, match_count, scratch);
     XP_LAUNCH_CHECK();
