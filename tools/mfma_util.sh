@@ -2,7 +2,7 @@
 # MFMA utilisation per kernel of one single-stream bench step: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/mfma_util; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap > $OUT/p1.log 2>&1 || echo "pass failed: $(tail -2 $OUT/p1.log)"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d > $OUT/p1.log 2>&1 || echo "pass failed: $(tail -2 $OUT/p1.log)"
 python3 - "$OUT" > $R/gpurun_out/mfma_utilisation.txt <<'PY'
 import collections, csv, glob, os, re, sys
 d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
