@@ -48,8 +48,8 @@ def parse():
     ap.add_argument("--register", action="store_true", help="also run the registration step (robust homography per pair) inside every step; not part of the headline metric's definition")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: no overlap of step i's detection / matching kernels with step i+1's encoder")
     ap.add_argument("--no-other-backend", action="store_true", help="skip the extra timing passes (other dense-layer back end, single-stream rate): keeps profiler output to the headline configuration")
-    ap.add_argument("--gemm", choices=["x3", "f32"], default=os.environ.get("XP_GEMM_MODE", "x3"),
-                    help="dense-layer back end: x3 = f32-accurate split-bf16 on the bf16 matrix pipe (default), f32 = exact-f32 MFMA "
+    ap.add_argument("--gemm", choices=["h2", "x3", "f32"], default=os.environ.get("XP_GEMM_MODE", "h2"),
+                    help="dense-layer back end: h2 = f32-grade split-fp16 on the f16 matrix pipe (default), x3 = f32-grade split-bf16, f32 = exact-f32 MFMA "
                          "(the reduced-precision classes x2 / bf16 are timed as extra, labelled passes only: never the headline)")
     return ap.parse_args()
 

@@ -87,6 +87,22 @@ int xp_gemm_nt_x3(const float* A, const void* Wx3, float* C, const float* bias, 
 int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* bias, const float* scale,
                        const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
                        int act, void* stream);
+/* fp32-grade variants on the f16 matrix pipe ("h2": every f32 operand is written as the sum of two fp16 values, which
+ * reproduces it to 2^-24 relative — half an f32 ulp; three fp16 MFMA partial products per multiply, f32 accumulate: per
+ * product about one f32 rounding, i.e. the error class of the f32 FMA chain the reference computes (csrc/gemm_h2_core.h,
+ * DESIGN.md §3c) at half the matrix work of the "x3" kernels).  Same semantics, epilogue and reference call sites as
+ * xp_gemm_nt / xp_conv3x3_nhwc (VMamba.py:649,663 in/out_proj; :110-128 Mlp; :605 x_proj; :1405-1440 convs;
+ * XPoint.py:112-138 head convs).  The weight matrix is passed pre-split: xp_split_weights_h2 converts a row-major (N, K) f32
+ * matrix into xp_split_weights_h2_bytes(N, K) bytes — slab-major fp16 planes of the rows scaled by a power of two each
+ * (largest element in [2^13, 2^14): keeps the low plane out of fp16's subnormal range) followed by the N inverse scales,
+ * which the epilogue applies exactly.  Activations are split unscaled: |A| must stay below 65504 (fp16 range; LayerNorm /
+ * GELU / SiLU outputs are O(1)); elements below 2^-3 carry an absolute error <= 2^-25. */
+size_t xp_split_weights_h2_bytes(int N, int K);
+int xp_split_weights_h2(const float* W, void* out, int N, int K, void* stream);
+int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const float* bias, const float* scale, const float* shift,
+                  const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
+int xp_conv3x3_nhwc_h2(const float* x, const void* Wh2, float* y, const float* bias, const float* scale, const float* shift,
+                       int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
 /* Precision class of the "x3" kernels (xp_gemm_nt_x3, xp_conv3x3_nhwc_x3, xp_mlp_fused_x3 and every dense layer of
  * xp_xpoint_forward with wsplit != NULL), process-wide, read at launch time:
  *   6 (default)  all six partial products of weight >= 2^-16: f32-grade (the class pinned against the reference, 1e-4 bar)
@@ -96,6 +112,13 @@ int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* b
  * The same weight buffers serve all three. */
 int xp_set_dense_products(int n);
 int xp_get_dense_products(void);
+/* Engine of the dense layers of xp_xpoint_forward (wsplit != NULL), process-wide, read at launch time:
+ *   1 (default)  "h2": xp_gemm_nt_h2 / xp_conv3x3_nhwc_h2 — operands as two fp16 planes, three partial products (f32-grade)
+ *   0            "x3": xp_gemm_nt_x3 / xp_conv3x3_nhwc_x3 — three bf16 planes, xp_set_dense_products partial products
+ * The fused block kernels (xp_mlp_fused_x3, xp_ln_proj_x3) use the x3 planes under both; the buffer prepared by
+ * xp_prepare_split_weights holds both formats. */
+int xp_set_dense_engine(int engine);
+int xp_get_dense_engine(void);
 
 /* Fused VSS-block MLP branch, in place:  X <- X + fc2(GELU(fc1(LayerNorm(X)) + b1)) + b2   (reference
  * VMamba.py:1230-1234 VSSBlock.forward second residual, :110-128 Mlp; LayerNorm over C, biased variance, eps;

@@ -29,10 +29,11 @@ def _data(first, B, H, W):
     return synth.to_torch(synth.make_pair_batch(first, B, H, W), "cuda")
 
 
-@pytest.mark.parametrize("gemm_mode", ["x3", "f32"])
+@pytest.mark.parametrize("gemm_mode", ["h2", "x3", "f32"])
 @pytest.mark.parametrize("tag,H,W,B,vssm", [("tiny32_64x96", 64, 96, 1, {"EMBED_DIM": 32}), ("full_64x96", 64, 96, 2, None)])
 def test_forward_vs_reference_golden(gpu_lib, golden, tag, H, W, B, vssm, gemm_mode):
-    """Both dense-layer back ends (split-bf16 on the bf16 matrix pipe = default, exact-f32 MFMA) against the reference."""
+    """All three f32-grade dense-layer back ends (split-fp16 on the f16 matrix pipe = default, split-bf16, exact-f32 MFMA)
+    against the reference."""
     g = golden("g345_model.npz")
     cfg = synth.xpoint_exp1_config(H, W, vssm=vssm)
     net = _net(cfg)
@@ -56,14 +57,15 @@ def test_gemm_modes_agree_480x640(gpu_lib):
     net = _net(synth.xpoint_exp1_config(H, W))
     img = _data(0, 1, H, W)["optical"]["image"]
     with torch.no_grad():
-        net.gemm_mode = "x3"
-        a = net.forward_raw(img, want_logits=True)
-        a = {k: v.clone() for k, v in a.items() if v is not None}
         net.gemm_mode = "f32"
         b = net.forward_raw(img, want_logits=True)
-    for k in ("prob", "desc_nhwc", "enc_nhwc", "logits_nhwc"):
-        err = float((a[k] - b[k]).abs().max())
-        assert err < 2e-5 * max(1.0, float(b[k].abs().max())), (k, err)
+        b = {k: v.clone() for k, v in b.items() if v is not None}
+        for mode in ("h2", "x3"):
+            net.gemm_mode = mode
+            a = net.forward_raw(img, want_logits=True)
+            for k in ("prob", "desc_nhwc", "enc_nhwc", "logits_nhwc"):
+                err = float((a[k] - b[k]).abs().max())
+                assert err < 2e-5 * max(1.0, float(b[k].abs().max())), (mode, k, err)
 
 
 def test_forward_224x320_and_end_to_end(gpu_lib, golden):

@@ -21,13 +21,21 @@ for (M, N, K, act, res) in shapes:
     C = torch.empty(M, N, device="cuda"); R = torch.randn(M, N, device="cuda") if res else None
     st = L.current_stream()
     X3 = os.environ.get("GB_X3", "0") == "1"
-    if X3:
+    H2 = os.environ.get("GB_H2", "0") == "1"
+    if H2:
+        import ctypes
+        Wx = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device="cuda")
+        L.call("xp_split_weights_h2", L.ptr(W), ctypes.c_void_p(Wx.data_ptr()), N, K, st)
+        wxp = ctypes.c_void_p(Wx.data_ptr())
+    elif X3:
         import ctypes
         Wx = torch.empty(L.load().xp_split_weights_x3_bytes(N, K), dtype=torch.uint8, device="cuda")
         L.call("xp_split_weights_x3", L.ptr(W), ctypes.c_void_p(Wx.data_ptr()), N, K, st)
         wxp = ctypes.c_void_p(Wx.data_ptr())
     def run():
-        if X3:
+        if H2:
+            L.call("xp_gemm_nt_h2", L.ptr(A), wxp, L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
+        elif X3:
             L.call("xp_gemm_nt_x3", L.ptr(A), wxp, L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
         else:
             L.call("xp_gemm_nt", L.ptr(A), L.ptr(W), L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)

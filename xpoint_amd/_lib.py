@@ -29,11 +29,15 @@ _SIGNATURES = {
     "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
     "xp_ss2d_core_set_mode": [c_i],
     "xp_set_dense_products": [c_i],
+    "xp_set_dense_engine": [c_i],
     "xp_gemm_nt": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc": [c_p] * 6 + [c_i] * 8 + [c_p],
     "xp_split_weights_x3": [c_p, c_p, c_i, c_i, c_p],
     "xp_gemm_nt_x3": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc_x3": [c_p] * 6 + [c_i] * 8 + [c_p],
+    "xp_split_weights_h2": [c_p, c_p, c_i, c_i, c_p],
+    "xp_gemm_nt_h2": [c_p] * 7 + [c_i] * 7 + [c_p],
+    "xp_conv3x3_nhwc_h2": [c_p] * 6 + [c_i] * 8 + [c_p],
     "xp_mlp_fused_x3": [c_p] * 7 + [c_i] * 3 + [c_f, c_p],
     "xp_mlp_fused_x3_pack": [c_p] * 4 + [c_i] * 2 + [c_p],
     "xp_ln_proj_x3_pack": [c_p] * 2 + [c_i] * 2 + [c_p],
@@ -76,9 +80,11 @@ _SIZE_QUERIES = {
     "xp_forward_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "xp_ss2d_core_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_split_weights_x3_bytes": (c_sz, [c_i] * 2),
+    "xp_split_weights_h2_bytes": (c_sz, [c_i] * 2),
     "xp_split_weights_bytes": (c_sz, [c_p]),
     "xp_mlp_fused_x3_supported": (c_i, [c_i, c_i]),
     "xp_get_dense_products": (c_i, []),
+    "xp_get_dense_engine": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_ln_proj_x3_pack_bytes": (c_sz, [c_i, c_i]),
     "xp_find_homography_workspace_bytes": (c_sz, [c_i]),

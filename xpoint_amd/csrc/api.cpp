@@ -101,6 +101,17 @@ extern "C" int xp_prof_get(int index, char* tag, int tag_len, double* total_ms, 
 static std::atomic<int> g_dense_products{[] { const char* e = getenv("XP_DENSE_PRODUCTS"); const int v = e ? atoi(e) : 6; return (v == 1 || v == 3) ? v : 6; }()};
 int xp_dense_products_value() { return g_dense_products.load(); }
 extern "C" int xp_get_dense_products(void) { return g_dense_products.load(); }
+// Dense-layer engine of xp_xpoint_forward with wsplit != NULL: 1 = "h2" (two fp16 planes, three products; gemm_h2_core.h),
+// 0 = "x3" (three bf16 planes, xp_set_dense_products products; gemm_x3_core.h).  The fused block kernels (xp_mlp_fused_x3,
+// xp_ln_proj_x3) are x3 in both.  XP_DENSE_ENGINE=x3|h2 sets the initial value.
+static std::atomic<int> g_dense_engine{[] { const char* e = getenv("XP_DENSE_ENGINE"); return (e && std::string(e) == "x3") ? 0 : 1; }()};
+int xp_dense_engine_value() { return g_dense_engine.load(); }
+extern "C" int xp_get_dense_engine(void) { return g_dense_engine.load(); }
+extern "C" int xp_set_dense_engine(int engine) {
+    XP_CHECK_ARG(engine == 0 || engine == 1, "xp_set_dense_engine: 0 (x3: split bf16) or 1 (h2: split fp16); got %d", engine);
+    g_dense_engine.store(engine);
+    return XP_OK;
+}
 extern "C" int xp_set_dense_products(int n) {
     XP_CHECK_ARG(n == 6 || n == 3 || n == 1, "xp_set_dense_products: 6 (f32-grade, default), 3 (two-plane operands) or 1 (plain bf16 operands); got %d", n);
     g_dense_products.store(n);

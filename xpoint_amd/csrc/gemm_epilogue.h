@@ -18,6 +18,8 @@ struct GemmParams {
     const float* scale;   // (N) or null   (applied after the activation; eval-mode BatchNorm)
     const float* shift;
     const float* res;     // (M, ldres) or null
+    const float* wscale;  // (N) or null: per-output-column factor applied to the accumulator before the bias (split-fp16 engine: undoes the
+                          // power-of-two row scale of the offline weight split, exactly)
     int M, N, K;
     int lda, ldc, ldres;
     int act;              // 0 none, 1 GELU(erf), 2 ReLU (before scale/shift), 3 ReLU after scale/shift
@@ -27,6 +29,10 @@ struct GemmParams {
     unsigned long long* stamps;   // debug (XP_GEMM_STAMPS): 4 s_memtime stamps per workgroup, else null
 };
 
+
+// tile engines whose accumulators carry a per-column power-of-two factor declare `static constexpr bool kRowScale = true`
+template <class T, class = void> struct tile_has_row_scale : std::false_type {};
+template <class T> struct tile_has_row_scale<T, std::enable_if_t<T::kRowScale>> : std::true_type {};
 
 // T: tile engine providing BM, BN, row_of(i, r), col_of(j).  acc[i][j] are the lane's 32x32 accumulator tiles.
 template <class T, int TM, int TN>
@@ -50,6 +56,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int m0, int n
                 const bool cok = INTERIOR || col < p.N;
                 const int clc = cok ? cl : 0;
                 const float bi = p.bias ? p.bias[n0 + clc] : 0.f;
+                const float ws = tile_has_row_scale<T>::value ? p.wscale[n0 + clc] : 1.f;
                 const float sc = p.scale ? p.scale[n0 + clc] : 1.f;
                 const float sh = p.shift ? p.shift[n0 + clc] : 0.f;
                 const float* resb = p.res ? p.res + (int64_t)m0 * p.ldres + n0 : nullptr;
@@ -63,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int m0, int n
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bi;
+                    float v = tile_has_row_scale<T>::value ? acc[i][j][r] * ws + bi : acc[i][j][r] + bi;    // ws is a power of two: the product is exact
                     if (ACT == 1) v = xp_gelu_fast(v);
                     if (ACT == 2) v = fmaxf(v, 0.f);
                     v = v * sc + sh;

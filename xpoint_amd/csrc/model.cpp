@@ -14,7 +14,7 @@
 namespace {
 
 struct Param { std::string name; size_t offset; size_t numel; };
-struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset; };   // a GEMM weight and its split-bf16 copy
+struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset, h2_offset; };   // a GEMM weight and its split-bf16 / split-fp16 copies
 struct MlpPack { std::string block; int C, H4; size_t byte_offset, in_offset; };          // weight streams of one VSS block's fused tail (out_proj + MLP) and head (in_proj)
 
 struct Ctx {
@@ -24,7 +24,7 @@ struct Ctx {
     std::vector<Param> params;
     std::vector<SplitW> split;
     std::vector<MlpPack> packs;
-    size_t total, split_bytes;
+    size_t total, split_bytes, h2_bytes;    // split_bytes: the x3 region (planes + fused-kernel packs); the h2 region follows it
     size_t add(const std::string& n, size_t numel) {
         size_t off = total;
         params.push_back({n, off, numel});
@@ -34,8 +34,9 @@ struct Ctx {
     // a (N, K) matrix consumed by a GEMM / 3x3 conv: also gets a slot in the split-weights buffer
     size_t add_gemm(const std::string& n, int N, int K) {
         const size_t off = add(n, (size_t)N * K);
-        split.push_back({n, off, N, K, split_bytes});
+        split.push_back({n, off, N, K, split_bytes, h2_bytes});
         split_bytes += (xp_split_weights_x3_bytes(N, K) + 255) / 256 * 256;
+        h2_bytes += (xp_split_weights_h2_bytes(N, K) + 255) / 256 * 256;
         return off;
     }
     size_t off(const std::string& n) const {
@@ -44,6 +45,10 @@ struct Ctx {
     }
     size_t split_off(const std::string& n) const {
         for (auto& p : split) if (p.name == n) return p.byte_offset;
+        return (size_t)-1;
+    }
+    size_t h2_off(const std::string& n) const {       // offset inside the whole buffer (the h2 region starts at split_bytes)
+        for (auto& p : split) if (p.name == n) return split_bytes + p.h2_offset;
         return (size_t)-1;
     }
     size_t pack_off(const std::string& block) const {
@@ -64,7 +69,7 @@ int enc_channels_of(const Ctx& c) { return c.dims[c.nstages - 1] / 16; }
 
 void build_layout(Ctx& c) {
     const int E = c.cfg.embed_dim, N = c.cfg.d_state;
-    c.total = 0; c.split_bytes = 0; c.split.clear(); c.packs.clear();
+    c.total = 0; c.split_bytes = 0; c.h2_bytes = 0; c.split.clear(); c.packs.clear();
     c.add("stem.w", 9 * (E / 2)); c.add("stem.b", E / 2); c.add("stem.ln_w", E / 2); c.add("stem.ln_b", E / 2);
     c.add_gemm("pe2.w", E, 9 * (E / 2)); c.add("pe2.b", E); c.add("pe2.ln_w", E); c.add("pe2.ln_b", E);
     for (int s = 0; s < c.nstages; ++s) {
@@ -195,18 +200,19 @@ extern "C" size_t xp_forward_workspace_bytes(void* ctx, int batch, int H, int W)
     return plan_ws(*c, batch, s).total_floats * sizeof(float);
 }
 
-extern "C" size_t xp_split_weights_bytes(void* ctx) { return ctx ? ((Ctx*)ctx)->split_bytes : 0; }
+extern "C" size_t xp_split_weights_bytes(void* ctx) { return ctx ? ((Ctx*)ctx)->split_bytes + ((Ctx*)ctx)->h2_bytes : 0; }
 
 #define RUN(call) do { int rc__ = (call); if (rc__ != XP_OK) return rc__; } while (0)
 
 extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* wsplit, size_t wsplit_bytes, void* stream) {
     XP_CHECK_ARG(ctx && weights && wsplit, "xp_prepare_split_weights: null pointer");
     Ctx* c = (Ctx*)ctx;
-    XP_CHECK_ARG(wsplit_bytes >= c->split_bytes, "xp_prepare_split_weights: buffer too small");
+    XP_CHECK_ARG(wsplit_bytes >= c->split_bytes + c->h2_bytes, "xp_prepare_split_weights: buffer too small");
     XP_CHECK_ARG(((uintptr_t)wsplit & 15) == 0, "xp_prepare_split_weights: buffer must be 16-byte aligned");
     for (auto& e : c->split) {
         XP_CHECK_ARG(e.K % 4 == 0, "xp_prepare_split_weights: %s has K = %d, not a multiple of 4", e.name.c_str(), e.K);
         RUN(xp_split_weights_x3(weights + e.src_offset, (char*)wsplit + e.byte_offset, e.N, e.K, stream));
+        RUN(xp_split_weights_h2(weights + e.src_offset, (char*)wsplit + c->split_bytes + e.h2_offset, e.N, e.K, stream));
     }
     for (auto& e : c->packs)
         RUN(xp_mlp_fused_x3_pack((char*)wsplit + c->split_off(e.block + "fc1_w"), (char*)wsplit + c->split_off(e.block + "fc2_w"),
@@ -231,14 +237,17 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     float* ws = (float*)workspace;
     float *X = ws + wp.X, *T1 = ws + wp.T1, *T2 = ws + wp.T2, *T3 = ws + wp.T3, *HB = ws + wp.HB, *XD = ws + wp.XD, *SS = ws + wp.SS;
     auto P = [&](const std::string& n) -> const float* { return weights + c->off(n); };
+    const bool h2 = xp_dense_engine_value() == 1 && xp_dense_products_value() == 6;    // the reduced-product classes are x3 classes
     // dense layers: the split-bf16 kernels when the caller passed split weights, else the exact-f32 MFMA kernels
     auto gemm = [&](const float* A, const std::string& w, float* C, const float* bias, const float* scale, const float* shift,
                     const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act) -> int {
+        if (wsplit && h2) return xp_gemm_nt_h2(A, (const char*)wsplit + c->h2_off(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
         if (wsplit) return xp_gemm_nt_x3(A, (const char*)wsplit + c->split_off(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
         return xp_gemm_nt(A, P(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
     };
     auto conv = [&](const float* x, const std::string& w, float* y, const float* bias, const float* scale, const float* shift,
                     int Hi, int Wi, int Ci, int Co, int stride, int reflect, int act) -> int {
+        if (wsplit && h2) return xp_conv3x3_nhwc_h2(x, (const char*)wsplit + c->h2_off(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
         if (wsplit) return xp_conv3x3_nhwc_x3(x, (const char*)wsplit + c->split_off(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
         return xp_conv3x3_nhwc(x, P(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
     };

@@ -54,6 +54,8 @@ static inline int xp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 
 // Partial products per multiply of the split-bf16 dense kernels (xp_set_dense_products): 6 (default), 3 or 1.
 int xp_dense_products_value();
+// Dense-layer engine of the fused encoder (xp_set_dense_engine): 0 = x3 (split bf16), 1 = h2 (split fp16, three products).
+int xp_dense_engine_value();
 
 #ifdef __HIPCC__
 // softplus with torch semantics (beta 1, threshold 20): reference csms6s.py:49-50 /

@@ -31,7 +31,8 @@ class _ModelCfg(ctypes.Structure):
 _LoadResult = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 _DIR_ORDER = [0, 2, 1, 3]   # device order of the four scan routes (row pair, then column pair)
-_DENSE_PRODUCTS = {"x3": 6, "x2": 3, "bf16": 1, "f32": 6}   # gemm_mode -> partial products of the split-bf16 kernels
+_DENSE_PRODUCTS = {"h2": 6, "x3": 6, "x2": 3, "bf16": 1, "f32": 6}   # gemm_mode -> partial products of the split-bf16 kernels
+_DENSE_ENGINE = {"h2": 1}                                             # gemm_mode -> xp_set_dense_engine (default 0 = x3)
 
 
 class XPoint(torch.nn.Module):
@@ -70,10 +71,11 @@ class XPoint(torch.nn.Module):
         self._wsplit: Optional[torch.Tensor] = None      # split-bf16 copies of the GEMM weights, derived from _blob on the device
         self._blob_t: Optional[torch.Tensor] = None      # multispectral only: the THERMAL encoder + the same heads
         self._wsplit_t: Optional[torch.Tensor] = None
-        # "x3": dense layers on the bf16 matrix pipe with split operands, 6 partial products (fp32-accurate; the default and the
-        # class pinned against the reference); "f32": exact-f32 MFMA kernels; "x2": 3 partial products (operands to 16 bits);
+        # "h2" (default): dense layers on the f16 matrix pipe, f32 operands as two fp16 planes, 3 partial products (f32-grade: an
+        # operand error of 2^-24, csrc/gemm_h2_core.h); "x3": bf16 matrix pipe, three planes, 6 partial products (f32-grade);
+        # both are pinned against the reference.  "f32": exact-f32 MFMA kernels; "x2": 3 bf16 partial products (operands to 16 bits);
         # "bf16": 1 product = bf16 operands, f32 accumulate — the class of the reference's mixed_precision autocast (XPoint.py:182)
-        self.gemm_mode = os.environ.get("XP_GEMM_MODE", "x3")
+        self.gemm_mode = os.environ.get("XP_GEMM_MODE", "h2")
         self._device = torch.device("cpu")
         self._ws: Dict[str, torch.Tensor] = {}
         self._conv_impl = None
@@ -393,9 +395,13 @@ class XPoint(torch.nn.Module):
         # (host-synchronous) enqueue, then back to the default.  Not safe against OTHER host threads enqueueing dense kernels at the
         # same time: one enqueueing thread per process (the reference's scripts are single-threaded; multi-GPU = one process per GPU)
         nprod = _DENSE_PRODUCTS[self.gemm_mode]
+        engine = _DENSE_ENGINE.get(self.gemm_mode, 0)
         prev = int(lib.xp_get_dense_products())          # whatever XP_DENSE_PRODUCTS / an earlier caller left: restored afterwards
+        prev_engine = int(lib.xp_get_dense_engine())
         if nprod != prev:
             _lib.call("xp_set_dense_products", nprod)
+        if engine != prev_engine:
+            _lib.call("xp_set_dense_engine", engine)
         try:
             _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                              ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
@@ -403,6 +409,8 @@ class XPoint(torch.nn.Module):
         finally:
             if nprod != prev:
                 _lib.call("xp_set_dense_products", prev)
+            if engine != prev_engine:
+                _lib.call("xp_set_dense_engine", prev_engine)
         return out
 
     @staticmethod
