@@ -26,11 +26,23 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, W, PAIRS = 480, 640, 8
+H, W, PAIRS = 480, 640, 8          # config c2 (the headline); c4 / c5 override them in main()
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "c2": dict(H=480, W=640, pairs=8, cap=8192, topk=0, label="C2: XPoint VMamba encoder, 480x640 optical-thermal, batch=8 pairs/GPU"),
+    # configs[3]: 1024x1024, keep_top_k 4096 -> a dense 4k x 4k x 256 descriptor match per pair
+    "c4": dict(H=1024, W=1024, pairs=4, cap=16384, topk=4096, nms_sweeps=12, label="C4: XPoint 1024x1024 VIS-SAR pairs, keep_top_k 4096 (4k x 4k x 256 match)"),
+    # configs[4]: streaming (images from pinned host memory every step, result lists back to the host), hipGraph-replayed step,
+    # homography-regression head.  The reference's RegNet head is only defined for 256x256 inputs (its FC layer is sized for a
+    # 32x32 encoder map: RegNet.py:38-52), so the head runs on the 256x256 top-left crop of every pair, in the step.
+    "c5": dict(H=480, W=640, pairs=8, cap=8192, topk=0, label="C5: XPoint + RegNet head (on 256x256 crops), 480x640 optical-NIR, streaming 8-pair steps "
+                                                                  "from pinned host memory, hipGraph-replayed step"),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 X3_PRODUCTS = 6                # bf16 MFMA partial products per f32-accurate multiply in the split-bf16 GEMM (csrc/gemm_x3_core.h)
+H2_PRODUCTS = 3                # fp16 MFMA partial products per f32-grade multiply in the split-fp16 GEMM (csrc/gemm_h2_core.h)
 
 
 def parse():
@@ -38,7 +50,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)     # 100 steps = 0.7 s timed: run-to-run spread of a 20-step region was +-5 %
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (c2 = the headline; c4, c5: see CONFIGS)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (roofline events are then taken in a separate eager pass)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra PCIe-inclusive pass (pcie_inclusive_pairs_per_s: images uploaded from pinned host memory and "
@@ -103,7 +116,14 @@ def self_launch(args):
 
 
 def main():
+    global H, W
     args = parse()
+    conf = CONFIGS[args.config]
+    H, W = conf["H"], conf["W"]
+    if args.pairs <= 0:
+        args.pairs = conf["pairs"]
+    if args.config == "c5":
+        args.graph = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -149,11 +169,30 @@ def main():
     data = synth.to_torch(synth.make_pair_batch(first, B, H, W), dev)
     opt, thr = data["optical"]["image"], data["thermal"]["image"]
     mo, mt = data["optical"]["valid_mask"], data["thermal"]["valid_mask"]
-    overlap = not args.no_overlap and not args.graph
-    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=overlap, split_encoder=args.split_encoder, estimate_homography=args.register)
+    overlap = not args.no_overlap
+    CAP = conf["cap"]
+    pred = dict(topk=conf["topk"])
+    sweeps = conf.get("nms_sweeps", 6)       # sweeps past the fixed point exit at once; 1024x1024 needs more than 480x640 (longer suppression chains)
+    pipe = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, overlap=overlap, split_encoder=args.split_encoder,
+                        estimate_homography=args.register)
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
-    pipe1 = PairPipeline(net, B, H, W, cap=8192, estimate_homography=args.register) if overlap else pipe
+    pipe1 = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, estimate_homography=args.register) if overlap else pipe
+    # config c5: the homography-regression head on the 256x256 crops (a second, small forward through the same encoder weights)
+    hm_step = None
+    if args.config == "c5":
+        cfg_hm = synth.xpoint_exp1_config(256, 256, hm_head=True)
+        net_hm = models.XPoint(cfg_hm).eval()
+        net_hm.gemm_mode = args.gemm
+        net_hm.load_state_dict(synth.make_torch_state_dict(cfg_hm), strict=True)
+        net_hm.to(dev)
+        hm_out = {}
+
+        def hm_step(o_img, t_img):
+            crop = {"optical": {"image": o_img[:, :, :256, :256].contiguous()}, "thermal": {"image": t_img[:, :, :256, :256].contiguous()}}
+            hm_out["hm"] = net_hm(crop)[2]
+        pin_o, pin_t = opt.cpu().pin_memory(), thr.cpu().pin_memory()
+        dev_o, dev_t = torch.empty_like(opt), torch.empty_like(thr)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -187,11 +226,25 @@ def main():
         breakdown = sorted(prof_table(), key=lambda r: -r["ms"])
         dominant = breakdown[0]["tag"]
         if args.graph:
-            step = pipe.capture(opt, thr, mo, mt)
+            # HIP events cannot be recorded inside a replayed graph: the dominant kernel is timed in eager single-stream passes first
             lib.xp_prof_reset(); lib.xp_prof_filter(dominant.encode()); lib.xp_prof_enable(1)
             for _ in range(3):
-                pipe.run(opt, thr, mo, mt)          # eager passes: HIP events cannot be recorded inside a replayed graph
+                pipe1.run(opt, thr, mo, mt)
             torch.cuda.synchronize(); lib.xp_prof_enable(0)
+            replay = pipe.capture(opt, thr, mo, mt)
+            if args.config == "c5":
+                def step():
+                    # streaming step: images arrive from pinned host memory, the step's result lists go back to the host
+                    dev_o.copy_(pin_o, non_blocking=True); dev_t.copy_(pin_t, non_blocking=True)
+                    replay(dev_o, dev_t, mo, mt)
+                    hm_step(dev_o, dev_t)
+                    pipe.wait()
+                    _ = (pipe.counts.cpu(), pipe.m["match_count"].cpu(), pipe.m["match_q"].cpu(), pipe.m["match_t"].cpu(), pipe.kp.cpu(), hm_out["hm"].cpu())
+            else:
+                step = lambda: replay(opt, thr, mo, mt)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
         elif overlap:
             step = lambda: pipe.run(opt, thr, mo, mt)
             # the dominant kernel's launches are timed in single-stream passes right here (same data, same kernels);
@@ -227,9 +280,12 @@ def main():
             single_rate = world * B * args.steps / (time.perf_counter() - t3)
             pipe1.verify()
         # the same step on the other dense-layer back end, for the record (never the headline value)
-        other = "f32" if args.gemm == "x3" else "x3"
+        other = "x3" if args.gemm == "h2" else "h2"
         other_rate = None
         class_rates = {}
+        f32_rate = None
+        if args.config != "c2":
+            args.no_other_backend = True
         if not args.graph and not args.no_other_backend:
             net.gemm_mode = other
             for _ in range(2):
@@ -241,6 +297,15 @@ def main():
             sync_all()
             other_rate = world * B * args.steps / (time.perf_counter() - t2)
             pipe.verify()
+            net.gemm_mode = "f32"
+            for _ in range(2):
+                pipe.run(opt, thr, mo, mt)
+            sync_all()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.run(opt, thr, mo, mt)
+            sync_all()
+            f32_rate = world * B * args.steps / (time.perf_counter() - t2)
             # reduced-precision classes of the same kernels: NOT within the 1e-4 bar, reported beside the headline
             class_rates = {}
             for cls in ("x2", "bf16"):
@@ -257,7 +322,7 @@ def main():
             pipe.run(opt, thr, mo, mt)          # leave the buffers holding the headline back end's results
             torch.cuda.synchronize()
     pcie = None
-    if not args.no_h2d:
+    if not args.no_h2d and args.config == "c2":
         ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
         do, dth = torch.empty_like(opt), torch.empty_like(thr)
         with torch.no_grad():
@@ -285,15 +350,16 @@ def main():
         avg_s = dom["ms"] / max(dom["launches"], 1) * 1e-3
         if dom["flops"] > 0 and dominant.startswith(("gemm", "conv3x3", "mlp_fused", "proj_mlp_fused")):
             ach = dom["flops"] / dom["launches"] / avg_s / 1e12
-            x3 = "_x3" in dominant
-            # split-bf16 kernels: algorithmic (f32-equivalent) 2MNK flops against the bf16 dense peak / 6 products per multiply
-            peak = MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS if x3 else MFMA_F32_PEAK_TFLOPS
+            x3 = "_x3" in dominant or "_h2" in dominant
+            nprod = H2_PRODUCTS if "_h2" in dominant else X3_PRODUCTS
+            # split kernels: algorithmic (f32-equivalent) 2MNK flops against the 16-bit dense MFMA peak / partial products per multiply
+            peak = MFMA_BF16_PEAK_TFLOPS / nprod if x3 else MFMA_F32_PEAK_TFLOPS
             roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
                     "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
             if x3:
-                roof["peak_note"] = (f"f32-equivalent: bf16 dense MFMA peak {MFMA_BF16_PEAK_TFLOPS:.0f} TFLOP/s / {X3_PRODUCTS} bf16 products per "
-                                     f"f32-accurate multiply; executed bf16 MFMA rate = {ach * X3_PRODUCTS:.0f} TFLOP/s")
+                roof["peak_note"] = (f"f32-equivalent: bf16 / fp16 dense MFMA peak {MFMA_BF16_PEAK_TFLOPS:.0f} TFLOP/s / {nprod} partial products per "
+                                     f"f32-grade multiply; executed 16-bit MFMA rate = {ach * nprod:.0f} TFLOP/s = {ach * nprod / MFMA_BF16_PEAK_TFLOPS:.3f} of peak")
         else:
             ach = dom["bytes"] / dom["launches"] / avg_s / 1e9
             roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -309,8 +375,8 @@ def main():
                 tiles = dominant.rsplit("_", 1)[1].split("x")
                 cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2",
                         ("128", "32"): "4, 1, 1, 1"}
-                kname = (f"{'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, {1 if dominant.startswith('conv3x3') else 0}"
-                         + (", 6>" if "_x3_" in dominant else ">"))
+                kname = (f"{'gemm_h2_kernel' if '_h2_' in dominant else 'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, "
+                         f"{1 if dominant.startswith('conv3x3') else 0}" + (", 6>" if "_x3_" in dominant else ">"))
                 roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
         except Exception:
@@ -337,10 +403,13 @@ def main():
             "value": round(world * B * args.steps / dt, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (dense layers: f32 operands split exactly into 3 bf16 terms, 6 bf16-MFMA partial products, f32 accumulate; "
+            "dtype": ("f32 (dense layers: f32 operands as 2 fp16 terms = 2^-24 operand error, 3 fp16-MFMA partial products, f32 accumulate; fused block tails: "
+                      "3 bf16 terms, 6 products; all other kernels f32)") if args.gemm == "h2" else
+                     ("f32 (dense layers: f32 operands split exactly into 3 bf16 terms, 6 bf16-MFMA partial products, f32 accumulate; "
                       "all other kernels f32)") if args.gemm == "x3" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"XPoint VMamba encoder, 480x640 optical-thermal, batch={B} pairs/GPU, encode+detect(NMS 8, thr 0.015)+describe+match(strict mutual NN)",
+            "config": {"workload": conf["label"] + f" (pairs/GPU/step = {B}): encode+detect(NMS 8, thr 0.015" + (f", keep_top_k {conf['topk']}" if conf["topk"] else "") +
+                                   ")+describe+match(strict mutual NN)" + (", step replayed from hipGraphs" if args.graph else ""),
                        "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}, RCCL weight bcast",
                        "stream_overlap": (f"{1 + max(pipe.split_encoder, 1)} HIP streams: step i+1's encoder ({max(pipe.split_encoder, 1)} image group(s)) overlaps "
                                           "step i's detection / matching kernels; all K steps complete inside the timed region") if overlap else "none (one stream)",
@@ -358,8 +427,8 @@ def main():
                 continue
             mfma = r["flops"] > 0 and r["tag"].startswith(("gemm", "conv3x3", "mlp_fused", "proj_mlp_fused", "ln_proj"))
             if mfma:
-                x3k = "_x3" in r["tag"]
-                pk = MFMA_BF16_PEAK_TFLOPS / X3_PRODUCTS if x3k else MFMA_F32_PEAK_TFLOPS
+                x3k = "_x3" in r["tag"] or "_h2" in r["tag"]
+                pk = MFMA_BF16_PEAK_TFLOPS / (H2_PRODUCTS if "_h2" in r["tag"] else X3_PRODUCTS) if x3k else MFMA_F32_PEAK_TFLOPS
                 a = r["flops"] / r["ms"] / 1e9
                 top.append({"kernel": r["tag"], "bound": "mfma", "achieved": round(a, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
                             "frac": round(a / pk, 4), "share_of_single_stream_step": round(r["ms"] / tot_ms, 4), "launches": r["launches"]})
@@ -371,8 +440,9 @@ def main():
         if single_rate is not None:
             out["single_stream"] = {"pairs_per_s": round(single_rate, 2), "note": "same steps enqueued on one HIP stream (bench.py --no-overlap)"}
         if other_rate is not None:
-            out["other_gemm_backend"] = {"gemm": other, "pairs_per_s": round(other_rate, 2),
-                                         "note": "same step with the dense layers on the " + ("exact-f32 MFMA kernels" if other == "f32" else "split-bf16 kernels")}
+            out["other_gemm_backends"] = {"note": "same step with the dense layers on the other f32-grade back ends: x3 = split-bf16 (6 products), "
+                                                  "h2 = split-fp16 (3 products), f32 = exact-f32 MFMA kernels",
+                                          "pairs_per_s": {other: round(other_rate, 2), "f32": round(f32_rate, 2)}}
         if class_rates:
             out["reduced_precision_classes"] = {
                 "note": "same step, dense layers with fewer split-bf16 partial products (xp_set_dense_products): outside the 1e-4 parity bar, "

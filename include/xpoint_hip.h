@@ -44,6 +44,18 @@ int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, co
                           int batch, int dim, int delta_dim, int seqlen, int dstate, int ngroups,
                           int delta_softplus, void* stream);
 
+/* The same operator with the reference's other input_t instantiations (cusoflex/selective_scan_core_fwd.cu:6-10) and its
+ * second output (selective_scan_oflex.cpp:206-208, kernel selective_scan_fwd_kernel_oflex.cuh:154-162):
+ *   itype 0 / 1 / 2: u, delta, B, C are f32 / f16 / bf16 (A, D, delta_bias always f32; the state is always f32);
+ *   out_float != 0: out is f32 (the "oflex" form the Python caller uses, csms6s.py:80), else out has the input type;
+ *   x_chunks (batch, dim, ceil(seqlen / 2048), 2 * dstate) f32 or NULL: per 2048-element chunk and state n the running
+ *   prefix of the scan, x[.., 2n] = prod exp(delta A_n) since the start of the row, x[.., 2n + 1] = h_n at the end of the
+ *   chunk (last state = x[:, :, -1, 1::2]).  The 16-bit instantiations evaluate exp(delta A) as exp2 on the hardware unit like
+ *   the reference's kernel (reference tolerances f16 rtol 3e-3 / atol 5e-3, bf16 3e-2 / 5e-2: test_selective_scan.py:401-403). */
+int xp_selective_scan_fwd_typed(const void* u, const void* delta, const float* A, const void* B, const void* C, const float* D,
+                                const float* delta_bias, void* out, float* x_chunks, int itype, int out_float, int batch, int dim,
+                                int delta_dim, int seqlen, int dstate, int ngroups, int delta_softplus, void* stream);
+
 /* Fused SS2D core in pixel layout = cross_scan + dt_proj + selective_scan + cross_merge + out_norm of
  * xpoint/models/vmamba_src/VMamba.py:601-646 (forward_corev2) with csm_triton.py:22-85 (cross scan/merge).
  *   u (batch, H, W, C) = SiLU(dwconv(in_proj(x)));  xdbl (batch*H*W, 4*(R+2)) = u @ x_proj^T with the four

@@ -156,6 +156,37 @@ def gen_g15(n_pairs=8):
     np.savez_compressed(os.path.join(OUT, "g15_c2_batch8.npz"), **g)
 
 
+def gen_g16():
+    """G16 — BASELINE config C4 through the REAL reference: one synthetic 1024x1024 pair, box_nms(8, 0.015, keep_top_k=4096),
+    nonzero, interpolate_descriptors, NNMatcher (strict mutual NN): the 4k x 4k x 256 match.  Keypoints, their scores, match
+    index pairs; plus every 32nd prob row and a strided descriptor volume for the forward check."""
+    torch.set_num_threads(1)
+    stubs.install()
+    import xpoint.utils as ref_utils
+    H = W = 1024
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = build_ref.build_reference_xpoint(cfg, synth.make_state_dict(cfg))
+    data = synth.to_torch(synth.make_pair_batch(0, 1, H, W))
+    with torch.no_grad():
+        o, t, _ = net(data)
+    g = {"meta": np.array([1, H, W, 4096], dtype=np.int32)}
+    kps, descs = [], []
+    for spec, r in (("optical", o), ("thermal", t)):
+        raw = r["prob"][0, 0].clone()
+        pn = ref_utils.box_nms(r["prob"] * data[spec]["valid_mask"], 8, 0.015, keep_top_k=4096, on_cpu=True)
+        kp = torch.nonzero((pn[0].squeeze() > 0.015).float())
+        kps.append(kp)
+        descs.append(ref_utils.interpolate_descriptors(kp, r["desc"][0], H, W))
+        g[f"kp_{spec}"] = kp.numpy().astype(np.int16)
+        g[f"score_{spec}"] = raw[kp[:, 0], kp[:, 1]].numpy()
+        g[f"prob_rows_{spec}"] = raw[::32].numpy()
+        g[f"desc_cols_{spec}"] = r["desc"][0, :, ::16, ::16].numpy()
+    ms = ref_utils.get_matches(descs[0].numpy(), descs[1].numpy(), "nnmatcher", False, threshold=10.0)
+    g["matches"] = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int16).reshape(-1, 2)
+    print("g16 kpts", len(kps[0]), len(kps[1]), "matches", len(ms), flush=True)
+    np.savez_compressed(os.path.join(OUT, "g16_c4_1024.npz"), **g)
+
+
 def main():
     torch.set_num_threads(1)
     stubs.install()
@@ -321,8 +352,9 @@ def main():
         print("480x640", spec, "candidates", int((r["prob"] > 0.015).sum()), "kpts", len(kp), "pmax", float(p.max()))
     np.savez_compressed(os.path.join(OUT, "g10_full480x640.npz"), **g10)
 
-    gen_g12(); gen_g13(); gen_g14(); gen_g15()
+    gen_g12(); gen_g13(); gen_g14(); gen_g15(); gen_g16()
     manifest["generators"] = {"g15_c2_batch8.npz": "gen_g15() (BASELINE config C2: 8 pairs 480x640 end to end)",
+                              "g16_c4_1024.npz": "gen_g16() (BASELINE config C4: one 1024x1024 pair, keep_top_k 4096, end to end)",
                               "g1..g11": "main()", "g12_conv_xpoint.npz": "gen_g12()",
                               "g13_eval_metrics.npz": "gen_g13() (reference benchmark_evaluation.py functions; cv2 stand-ins in stubs.py)",
                               "g14_multispectral.npz": "gen_g14()"}

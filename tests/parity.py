@@ -20,9 +20,10 @@ def _overlaps(dy, dx, size):
     return inter / (2.0 * size * size - inter) > 0.1
 
 
-def explain_keypoint_diff(kp_mine, kp_ref, prob_mine, thr, size=8, tol=1e-4):
+def explain_keypoint_diff(kp_mine, kp_ref, prob_mine, thr, size=8, tol=1e-4, topk_cut=None):
     """kp_* (N,2) integer (y,x); prob_mine (H,W) float: the map MY keypoints came from (before NMS).
-    Returns (report, unexplained): report = list of dicts for every keypoint in the symmetric difference."""
+    topk_cut: with keep_top_k, the score of the last survivor kept (a survivor whose score is within tol of it may fall on either side of
+    the cut).  Returns (report, unexplained): report = list of dicts for every keypoint in the symmetric difference."""
     mine = {tuple(int(v) for v in p) for p in np.asarray(kp_mine).reshape(-1, 2)}
     ref = {tuple(int(v) for v in p) for p in np.asarray(kp_ref).reshape(-1, 2)}
     diff = sorted(mine ^ ref)
@@ -36,6 +37,8 @@ def explain_keypoint_diff(kp_mine, kp_ref, prob_mine, thr, size=8, tol=1e-4):
         why = None
         if abs(s - thr) <= tol:
             why = f"score {s:.7f} within {tol:g} of the threshold {thr}"
+        elif topk_cut is not None and abs(s - topk_cut) <= 2 * tol:
+            why = f"score {s:.7f} within {2 * tol:g} of the top-k cut score {topk_cut:.7f}"
         else:
             # a competing overlapping candidate whose score is within 2 tol (each side carries up to tol), or whose own
             # candidacy is within tol of the threshold

@@ -474,3 +474,43 @@ def test_cli_flows_end_to_end(gpu_lib, tmp_path):
     assert out["1/matches"].tolist() == [[m.queryIdx, m.trainIdx] for m in res[0]["matches"]]
     outk = cli.main(["keypoints", "-y", str(tmp_path / "cfg.yaml"), "-m", str(tmp_path / "model"), "-i", "1"])
     assert outk["1/kp_thermal"].shape[1] == 2
+
+
+def test_c4_1024_topk4096_end_to_end_vs_reference(gpu_lib, golden, capsys):
+    """BASELINE config C4 on the GPU against the REAL reference (tests/golden/g16_c4_1024.npz): one 1024x1024 pair, box NMS with
+    keep_top_k 4096, 4096 x 4096 x 256 mutual-NN match.  Forward within 1e-4 (strided samples); keypoints and index pairs identical to
+    the reference's up to attributed near-ties (incl. the top-k cut)."""
+    from tests import parity
+    from xpoint_amd import utils
+    from xpoint_amd.predict import PairPipeline
+    g = golden("g16_c4_1024.npz")
+    _, H, W, K = [int(v) for v in g["meta"]]
+    net = _net(synth.xpoint_exp1_config(H, W))
+    data = _data(0, 1, H, W)
+    pipe = PairPipeline(net, 1, H, W, cap=16384, cfg_prediction=dict(topk=K), nms_sweeps=12, overlap=True, split_encoder=2)
+    with torch.no_grad():
+        for _ in range(2):
+            pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
+        out = pipe.fetch()[0]
+    prob = pipe.raw["prob"].cpu().numpy()
+    desc = pipe.raw["desc_nhwc"].permute(0, 3, 1, 2).cpu().numpy()
+    lines, kp_m = [], {}
+    for j, spec in enumerate(("optical", "thermal")):
+        assert float(np.abs(prob[j][::32] - g[f"prob_rows_{spec}"]).max()) < TOL
+        assert float(np.abs(desc[j][:, ::16, ::16] - g[f"desc_cols_{spec}"]).max()) < TOL
+        kp_m[spec] = out[f"kp_{spec}"].numpy()
+        ref = g[f"kp_{spec}"].astype(np.int64)
+        assert len(kp_m[spec]) == K == len(ref)
+        cut = float(np.sort(prob[j][kp_m[spec][:, 0], kp_m[spec][:, 1]])[0])          # score of the last survivor kept
+        rep, bad = parity.explain_keypoint_diff(kp_m[spec], ref, prob[j], 0.015, 8, tol=TOL, topk_cut=cut)
+        lines.append(parity.format_report(f"1024x1024 {spec} keypoints (top-k {K})", rep))
+        assert not bad, parity.format_report(spec, bad)
+    mine = np.stack([out["match_q"], out["match_t"]], 1).astype(np.int64)
+    vol = {"optical": pipe.raw["desc_nhwc"][0], "thermal": pipe.raw["desc_nhwc"][1]}
+    desc_of = lambda side, pts: utils.interpolate_descriptors_nhwc(torch.from_numpy(pts), vol[side], H, W).cpu().numpy()
+    rep, bad = parity.explain_match_diff(kp_m["optical"], kp_m["thermal"], g["kp_optical"], g["kp_thermal"], mine, g["matches"].astype(np.int64), desc_of, tol=TOL)
+    lines.append(parity.format_report(f"1024x1024 mutual-NN pairs ({len(mine)} mine, {len(g['matches'])} reference)", rep))
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+    assert not bad, parity.format_report("matches", bad)
+    assert len(rep) <= max(4, len(mine) // 50)

@@ -83,3 +83,66 @@ def test_scan_errors(gpu_lib):
                           torch.zeros(1, 3, 1, 8, device="cuda"))           # dim % ngroups != 0
     with pytest.raises(RuntimeError):
         selective_scan_fn(u.cpu(), u, torch.zeros(4, 1), torch.zeros(1, 1, 1, 8), torch.zeros(1, 1, 1, 8))
+
+
+# ------------------------------------------------------------------------------------------------ f16 / bf16 instantiations, x output
+def _chunk_states(u, delta, A, Bm, Cm, Dv, bias, softplus=True, chunk=2048):
+    """fp64 restatement of the op's second output (selective_scan_oflex.cpp:206-208; kernel :154-162): per 2048-element chunk and state
+    the running prefix (product of exp(delta A) since the row start, h at the chunk end)."""
+    u, delta, A, Bm, Cm = [t.double() for t in (u, delta, A, Bm, Cm)]
+    Bsz, D, L = u.shape
+    G, N = Bm.shape[1], Bm.shape[2]
+    dl = delta.repeat_interleave(D // delta.shape[1], dim=1) + (bias.double().repeat_interleave(D // bias.shape[0])[None, :, None] if bias is not None else 0.0)
+    if softplus:
+        dl = torch.where(dl <= 20.0, torch.log1p(torch.exp(dl)), dl)
+    Bf = Bm.repeat_interleave(D // G, dim=1); Cf = Cm.repeat_interleave(D // G, dim=1)          # (B, D, N, L)
+    h = torch.zeros(Bsz, D, N, dtype=torch.float64); pa = torch.ones(Bsz, D, N, dtype=torch.float64)
+    nch = (L + chunk - 1) // chunk
+    x = torch.zeros(Bsz, D, nch, 2 * N, dtype=torch.float64)
+    out = torch.zeros(Bsz, D, L, dtype=torch.float64)
+    for l in range(L):
+        a = torch.exp(dl[:, :, l, None] * A[None])
+        h = a * h + dl[:, :, l, None] * Bf[:, :, :, l] * u[:, :, l, None]
+        pa = pa * a
+        out[:, :, l] = (h * Cf[:, :, :, l]).sum(-1) + (Dv.double()[None] * u[:, :, l] if Dv is not None else 0.0)
+        if (l + 1) % chunk == 0 or l == L - 1:
+            x[:, :, l // chunk, 0::2] = pa; x[:, :, l // chunk, 1::2] = h
+    return out, x
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", [(torch.float32, 2e-5, 2e-5), (torch.float16, 3e-3, 5e-3), (torch.bfloat16, 3e-2, 5e-2)])
+@pytest.mark.parametrize("case", [(2, 4, 24, 1, 64), (1, 2, 16, 1, 2049), (1, 1, 4, 8, 512), (2, 2, 8, 16, 4500), (1, 4, 6, 3, 301)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_scan_typed_inputs_and_chunk_states(gpu_lib, case, dtype, rtol, atol):
+    """The reference's half-input / float-output instantiations (cusoflex/selective_scan_core_fwd.cu:6-10) with the reference's own
+    tolerances (test_selective_scan.py:401-403: f16 rtol 3e-3 / atol 5e-3, bf16 3e-2 / 5e-2; the inputs are rounded to the 16-bit type
+    first, as its test does), the per-chunk state output x, and last state = x[:, :, -1, 1::2]."""
+    from xpoint_amd.kernels import selective_scan_fwd, selective_scan_fn
+    name = "scan/typed_%d_%d_%d_%d_%d" % case
+    u, delta, A, Bm, Cm, Dv, bias = [torch.from_numpy(x) for x in scan_inputs(name, *case)]
+    u, delta, Bm, Cm = [t.to(dtype) for t in (u, delta, Bm, Cm)]
+    ref_out, ref_x = _chunk_states(u.float(), delta.float(), A, Bm.float(), Cm.float(), Dv, bias)
+    out, x = selective_scan_fwd(u.cuda(), delta.cuda(), A.cuda(), Bm.cuda(), Cm.cuda(), Dv.cuda(), bias.cuda(), True, 1, True)
+    assert out.dtype == torch.float32 and x.shape == ref_x.shape
+    if dtype == torch.float32:          # f32: the build's own bar, scaled by the output magnitude like the tests above (sums of up to 16 states)
+        rtol, atol = 0.0, 2e-5 * max(1.0, float(ref_out.abs().max()))
+    np.testing.assert_allclose(out.cpu().numpy(), ref_out.numpy(), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(x.cpu().numpy(), ref_x.numpy(), rtol=rtol, atol=atol)
+    o2, last = selective_scan_fn(u.cuda(), delta.cuda(), A.cuda(), Bm.cuda(), Cm.cuda(), Dv.cuda(), bias.cuda(), True, return_last_state=True)
+    np.testing.assert_allclose(last.cpu().numpy(), ref_x[:, :, -1, 1::2].numpy(), rtol=rtol, atol=atol)
+    if dtype != torch.float32:                # output in the input type (out_float False)
+        o3, _ = selective_scan_fwd(u.cuda(), delta.cuda(), A.cuda(), Bm.cuda(), Cm.cuda(), Dv.cuda(), bias.cuda(), True, 1, False)
+        assert o3.dtype == dtype
+        np.testing.assert_allclose(o3.float().cpu().numpy(), ref_out.numpy(), rtol=4 * rtol, atol=4 * atol)
+
+
+def test_scan_typed_errors(gpu_lib):
+    from xpoint_amd.kernels import selective_scan_fwd
+    u = torch.zeros(1, 4, 8, device="cuda", dtype=torch.float16)
+    A = torch.zeros(4, 1, device="cuda"); B = torch.zeros(1, 1, 1, 8, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        selective_scan_fwd(u, u.float(), A, B, B)                       # mixed input dtypes (selective_scan_oflex.cpp:163-166)
+    with pytest.raises(RuntimeError):
+        selective_scan_fwd(u, u, A.half(), B, B)                        # A must be float32
+    with pytest.raises(RuntimeError):
+        selective_scan_fwd(u.to(torch.int32), u, A, B, B)

@@ -26,6 +26,7 @@ c_sz = ctypes.c_size_t
 _SIGNATURES = {
     "xp_device_info": [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
     "xp_selective_scan_fwd": [c_p] * 9 + [c_i] * 7 + [c_p],
+    "xp_selective_scan_fwd_typed": [c_p] * 9 + [c_i] * 9 + [c_p],
     "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
     "xp_ss2d_core_set_mode": [c_i],
     "xp_set_dense_products": [c_i],

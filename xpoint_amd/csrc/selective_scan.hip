@@ -295,6 +295,136 @@ __global__ __launch_bounds__(256) void selective_scan_fwd_n1v2_kernel(
     if (last_state && lane == 0) last_state[row] = h;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// General form: any d_state <= 256, inputs u / delta / B / C in f32, f16 or bf16 (the reference's input_t instantiations,
+// cusoflex/selective_scan_core_fwd.cu:6-10; A, D, delta_bias stay f32 and the state is always f32), output f32 ("oflex",
+// out_float) or the input type, and the per-chunk scan state x (batch, dim, ceil(L / 2048), 2 N) of selective_scan_oflex.cpp:206-208:
+// x[.., c, 2n] = product of exp(delta A_n) from the start of the row to the end of 2048-element chunk c, x[.., c, 2n + 1] = h_n there
+// (the running prefix of the reference's block scan, selective_scan_fwd_kernel_oflex.cuh:154-162; last state = x[:, :, -1, 1::2]).
+// One wave per (batch, channel) row, 512-element steps (8 items per lane: one 16-byte load per operand for the 16-bit types,
+// two for f32), the (a, b) scan across the wave on DPP moves, the per-state carries (h, running product) in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <class T> struct ScanIO;
+template <> struct ScanIO<float> {
+    __device__ static __forceinline__ void load8(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ static __forceinline__ float get(const float* p) { return *p; }
+    __device__ static __forceinline__ void store8(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    __device__ static __forceinline__ void put(float* p, float v) { *p = v; }
+};
+template <class H> struct ScanIO16 {
+    typedef H hvec8 __attribute__((ext_vector_type(8)));
+    __device__ static __forceinline__ void load8(const H* p, float (&v)[8]) {
+        const hvec8 a = *reinterpret_cast<const hvec8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+    __device__ static __forceinline__ float get(const H* p) { return (float)*p; }
+    __device__ static __forceinline__ void store8(H* p, const float (&v)[8]) {
+        hvec8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (H)v[i];
+        *reinterpret_cast<hvec8*>(p) = a;
+    }
+    __device__ static __forceinline__ void put(H* p, float v) { *p = (H)v; }
+};
+template <> struct ScanIO<_Float16> : ScanIO16<_Float16> {};
+template <> struct ScanIO<__bf16> : ScanIO16<__bf16> {};
+
+constexpr int kXChunk = 2048;      // the reference's chunk of the x output (selective_scan_oflex.cpp:206)
+
+template <class T, class OT, bool EXACT_EXP>
+__global__ __launch_bounds__(256) void selective_scan_fwd_gen_kernel(
+    const T* __restrict__ u, const T* __restrict__ delta, const float* __restrict__ A, const T* __restrict__ Bm, const T* __restrict__ Cm,
+    const float* __restrict__ Dv, const float* __restrict__ delta_bias, OT* __restrict__ out, float* __restrict__ last_state,
+    float* __restrict__ xchunks, int batch, int dim, int delta_dim, int L, int N, int G, int softplus, int vec) {
+    __shared__ float carry_h[4][256], carry_a[4][256];      // per wave and state: h and the running product of a (reference MAX_DSTATE 256)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)batch * dim) return;
+    const int b = (int)(row / dim), d = (int)(row % dim);
+    const int g = d / (dim / G), dd = d / (dim / delta_dim);
+    const T* up = u + row * L;
+    const T* dp = delta + ((int64_t)b * delta_dim + dd) * L;
+    const T* Bp = Bm + ((int64_t)b * G + g) * N * L;
+    const T* Cp = Cm + ((int64_t)b * G + g) * N * L;
+    OT* op = out + row * L;
+    const float Dval = Dv ? Dv[d] : 0.f, bias = delta_bias ? delta_bias[dd] : 0.f;
+    const int nxc = (L + kXChunk - 1) / kXChunk;
+    for (int n = lane; n < N; n += 64) { carry_h[wave][n] = 0.f; carry_a[wave][n] = 1.f; }
+    auto ld = [&](const T* p, int off, int rem, float (&v)[8]) {
+        if (vec && rem >= 8) ScanIO<T>::load8(p + off, v);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = i < rem ? ScanIO<T>::get(p + off + i) : 0.f;
+        }
+    };
+    for (int c0 = 0; c0 < L; c0 += kChunk8) {
+        const int off = c0 + lane * 8, rem = L - off;       // rem may be <= 0
+        float uv[8], dl[8], du[8], ov[8];
+        ld(up, off, rem, uv); ld(dp, off, rem, dl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = dl[i] + bias;
+            dl[i] = softplus ? (EXACT_EXP ? xp_softplus_fast(t) : (t <= 20.f ? xp_log1p_fast(__builtin_amdgcn_exp2f(t * 1.44269504088896340736f)) : t)) : t;
+            du[i] = dl[i] * uv[i];
+            ov[i] = Dval * uv[i];
+        }
+        const bool xc_end = ((c0 + kChunk8) % kXChunk == 0) || (c0 + kChunk8 >= L);     // this step closes a 2048-element chunk of x
+        for (int n = 0; n < N; ++n) {
+            const float An = A[(int64_t)d * N + n];
+            float bv[8], cv[8], la[8], lb[8];
+            ld(Bp + (int64_t)n * L, off, rem, bv); ld(Cp + (int64_t)n * L, off, rem, cv);
+            float pa = 1.f, pb = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float a = EXACT_EXP ? xp_exp_fast(dl[i] * An) : __builtin_amdgcn_exp2f(dl[i] * (An * 1.44269504088896340736f));
+                float bb = bv[i] * du[i];
+                if (i >= rem) { a = 1.f; bb = 0.f; }              // identity past the end keeps the carried state right
+                pb = a * pb + bb; pa = a * pa;
+                la[i] = pa; lb[i] = pb;
+            }
+            float ta = pa, tb = pb;
+            xp_wave_scan_ab(ta, tb);
+            const float ea = xp_dpp<0x138, 0xf>(1.f, ta), eb = xp_dpp<0x138, 0xf>(0.f, tb);      // prefix of the lanes before this one
+            const float hprev = carry_h[wave][n], aprev = carry_a[wave][n];
+            const float hin = ea * hprev + eb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] += cv[i] * (la[i] * hin + lb[i]);
+            const float tot_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ta), 63));
+            const float hend = tot_a * hprev + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb), 63));
+            if (lane == 0) {
+                carry_h[wave][n] = hend; carry_a[wave][n] = aprev * tot_a;
+                if (xchunks && xc_end) {
+                    float* xp = xchunks + ((row * nxc + c0 / kXChunk) * N + n) * 2;
+                    xp[0] = aprev * tot_a; xp[1] = hend;
+                }
+            }
+        }
+        if (vec && rem >= 8) ScanIO<OT>::store8(op + off, ov);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < rem) ScanIO<OT>::put(op + off + i, ov[i]);
+        }
+    }
+    if (last_state) for (int n = lane; n < N; n += 64) last_state[row * N + n] = carry_h[wave][n];
+}
+
+template <class T, class OT, bool EXACT>
+static void launch_gen(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm, const float* Dv, const float* delta_bias,
+                       void* out, float* last_state, float* xchunks, int batch, int dim, int delta_dim, int L, int N, int G, int softplus, hipStream_t s) {
+    const int64_t rows = (int64_t)batch * dim;
+    const size_t al = 8 * sizeof(T) - 1;
+    const int vec = (L % 8 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)Bm | (uintptr_t)Cm) & al) == 0) && (((uintptr_t)out & (8 * sizeof(OT) - 1)) == 0);
+    hipLaunchKernelGGL((selective_scan_fwd_gen_kernel<T, OT, EXACT>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const T*)u, (const T*)delta, A,
+                       (const T*)Bm, (const T*)Cm, Dv, delta_bias, (OT*)out, last_state, xchunks, batch, dim, delta_dim, L, N, G, softplus, vec);
+}
+
 }  // namespace
 
 extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
@@ -327,12 +457,41 @@ extern "C" int xp_selective_scan_fwd(const float* u, const float* delta, const f
         else
             hipLaunchKernelGGL(selective_scan_fwd_n1_kernel<false>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out, last_state,
                                batch, dim, delta_dim, seqlen, ngroups, delta_softplus);
-    } else if (vec)
-        hipLaunchKernelGGL(selective_scan_fwd_kernel<true>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
-                           last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
-    else
-        hipLaunchKernelGGL(selective_scan_fwd_kernel<false>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
-                           last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
+    } else {
+        // d_state > 1: the 8-item DPP-scan kernel (the 4-item shuffle-scan kernel above ran at 0.08 of HBM at N = 16)
+        static const bool old_gen = getenv("XP_SCAN_OLD_GEN") != nullptr;
+        if (!old_gen) launch_gen<float, float, true>(u, delta, A, Bm, Cm, Dv, delta_bias, out, last_state, nullptr, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus, s);
+        else if (vec)
+            hipLaunchKernelGGL(selective_scan_fwd_kernel<true>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
+                               last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
+        else
+            hipLaunchKernelGGL(selective_scan_fwd_kernel<false>, grid, block, 0, s, u, delta, A, Bm, Cm, Dv, delta_bias, out,
+                               last_state, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus);
+    }
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+// itype: 0 f32, 1 f16, 2 bf16 (u, delta, B, C); out_float != 0: out is f32 ("oflex"), else out has the input type.
+extern "C" int xp_selective_scan_fwd_typed(const void* u, const void* delta, const float* A, const void* Bm, const void* Cm, const float* Dv,
+                                           const float* delta_bias, void* out, float* x_chunks, int itype, int out_float, int batch, int dim,
+                                           int delta_dim, int seqlen, int dstate, int ngroups, int delta_softplus, void* stream) {
+    XP_CHECK_ARG(u && delta && A && Bm && Cm && out, "xp_selective_scan_fwd_typed: null tensor pointer");
+    XP_CHECK_ARG(itype >= 0 && itype <= 2, "xp_selective_scan_fwd_typed: itype 0 (f32), 1 (f16) or 2 (bf16)");
+    XP_CHECK_ARG(batch > 0 && dim > 0 && seqlen > 0, "xp_selective_scan_fwd_typed: batch/dim/seqlen must be positive");
+    XP_CHECK_ARG(dstate > 0 && dstate <= 256, "xp_selective_scan_fwd_typed: dstate must be in [1,256] (got %d)", dstate);
+    XP_CHECK_ARG(ngroups > 0 && dim % ngroups == 0, "xp_selective_scan_fwd_typed: dim %% ngroups != 0");
+    XP_CHECK_ARG(delta_dim > 0 && dim % delta_dim == 0, "xp_selective_scan_fwd_typed: dim %% delta_dim != 0");
+    hipStream_t s = (hipStream_t)stream;
+    const double isz = itype == 0 ? 4.0 : 2.0, osz = (out_float || itype == 0) ? 4.0 : 2.0;
+    XpProfScope prof(itype == 0 ? "selective_scan_fwd_gen_f32" : (itype == 1 ? "selective_scan_fwd_gen_f16" : "selective_scan_fwd_gen_bf16"), s,
+                     (9.0 * dstate + 1.0) * batch * dim * (double)seqlen,
+                     (2.0 * isz + osz) * batch * dim * (double)seqlen + 2.0 * isz * batch * ngroups * dstate * (double)seqlen);
+#define XP_GEN(T, OT, EX) launch_gen<T, OT, EX>(u, delta, A, Bm, Cm, Dv, delta_bias, out, nullptr, x_chunks, batch, dim, delta_dim, seqlen, dstate, ngroups, delta_softplus, s)
+    if (itype == 0) XP_GEN(float, float, true);
+    else if (itype == 1) { if (out_float) XP_GEN(_Float16, float, false); else XP_GEN(_Float16, _Float16, false); }
+    else { if (out_float) XP_GEN(__bf16, float, false); else XP_GEN(__bf16, __bf16, false); }
+#undef XP_GEN
     XP_LAUNCH_CHECK();
     return XP_OK;
 }

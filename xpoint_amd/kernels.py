@@ -22,10 +22,52 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+_ITYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def selective_scan_fwd(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True, nrows=1, out_float=True):
+    """The pybind op of the reference, `selective_scan_cuda_oflex.fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows,
+    out_float) -> [out, x]` (selective_scan_oflex.cpp:143-231): u, delta, B, C of one dtype in {float32, float16, bfloat16}; A, D,
+    delta_bias float32; out float32 if out_float else the input dtype; x (B, D, ceil(L / 2048), 2 N) float32, last state =
+    x[:, :, -1, 1::2].  nrows is a CUDA launch-shape hint there and is ignored here."""
+    for t, n in ((u, "u"), (delta, "delta"), (A, "A"), (B, "B"), (C, "C"), (D, "D"), (delta_bias, "delta_bias")):
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"{n} must be a CUDA(HIP) tensor")                     # selective_scan_oflex.cpp:152-160
+    if u.dtype not in _ITYPE:
+        raise RuntimeError(f"u: dtype must be float32, float16 or bfloat16 (got {u.dtype})")
+    for t, n in ((delta, "delta"), (B, "B"), (C, "C")):
+        if t.dtype != u.dtype:
+            raise RuntimeError(f"{n} must have u's dtype {u.dtype} (got {t.dtype})")
+    for t, n in ((A, "A"), (D, "D"), (delta_bias, "delta_bias")):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"{n} must be float32 (got {t.dtype})")
+    if u.dim() != 3 or B.dim() != 4:
+        raise RuntimeError("selective_scan_fwd: u must be (B, D, L) and B/C (B, G, N, L)")
+    u, delta, A, B, C = u.contiguous(), delta.contiguous(), A.contiguous(), B.contiguous(), C.contiguous()
+    D = D.contiguous() if D is not None else None
+    delta_bias = delta_bias.contiguous() if delta_bias is not None else None
+    batch, dim, L = u.shape
+    _, G, N, L2 = B.shape
+    if L2 != L or C.shape != B.shape or A.shape != (dim, N) or delta.shape[0] != batch or delta.shape[2] != L:
+        raise RuntimeError("selective_scan_fwd: shape mismatch")
+    if N > 256:
+        raise RuntimeError("selective_scan_fwd: dstate must be <= 256")                # MAX_DSTATE, selective_scan_oflex.cpp:11
+    out = torch.empty((batch, dim, L), device=u.device, dtype=torch.float32 if out_float else u.dtype)
+    x = torch.empty((batch, dim, (L + 2047) // 2048, 2 * N), device=u.device, dtype=torch.float32)
+    _lib.call("xp_selective_scan_fwd_typed", ptr(u), ptr(delta), ptr(A), ptr(B), ptr(C), ptr(D), ptr(delta_bias), ptr(out), ptr(x),
+              c_i(_ITYPE[u.dtype]), c_i(int(bool(out_float))), c_i(batch), c_i(dim), c_i(delta.shape[1]), c_i(L), c_i(N), c_i(G),
+              c_i(int(bool(delta_softplus))), _lib.current_stream(u))
+    return [out, x]
+
+
 def selective_scan_fn(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=True, oflex=True, backend=None,
                       return_last_state=False):
     """u (B, K*C, L); delta (B, Dd, L) with K*C % Dd == 0; A (K*C, N); B, C (B, K, N, L); D, delta_bias
-    (K*C)/(Dd).  Returns out (B, K*C, L) float32 (oflex: float output)."""
+    (K*C)/(Dd).  Returns out (B, K*C, L) float32 (oflex: float output).  float16 / bfloat16 inputs go through
+    selective_scan_fwd (the reference's half-input / float-output instantiations)."""
+    if u.dtype in (torch.float16, torch.bfloat16):
+        out, x = selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, 1, oflex)
+        return (out, x[:, :, -1, 1::2].contiguous()) if return_last_state else out
     u, delta, A, B, C = (_f32c(t, n) for t, n in ((u, "u"), (delta, "delta"), (A, "A"), (B, "B"), (C, "C")))
     D = _f32c(D, "D"); delta_bias = _f32c(delta_bias, "delta_bias")
     if u.dim() != 3 or B.dim() != 4:

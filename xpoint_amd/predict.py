@@ -266,18 +266,75 @@ class PairPipeline:
         return self
 
     def capture(self, optical, thermal, mask_optical=None, mask_thermal=None):
-        """Capture run() into a hipGraph (fixed shapes, preallocated buffers) and return a replay callable.  The inputs
-        are copied into the pipeline's own image buffer by the graph itself, so refill `optical` / `thermal` in place
-        (same storage) between replays."""
-        if self.overlap:
-            raise RuntimeError("PairPipeline.capture: build the pipeline with overlap=False (a captured graph is one stream)")
-        self.run(optical, thermal, mask_optical, mask_thermal)          # warm-up outside capture (one-time attribute calls)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run(optical, thermal, mask_optical, mask_thermal)
-        self._graph = g
-        return g.replay
+        """Capture the step into hipGraphs (fixed shapes, preallocated buffers) and return a replay callable that takes the same
+        arguments as run().  The input copies stay outside the graphs (so the caller may pass different tensors, e.g. pinned
+        host memory, at every replay).
+        One stream: one graph of encoder + detection + matching.  Overlapped pipeline: per output buffer (two of them), one
+        graph per encoder image group and one for the detection / matching kernels, each replayed on its own stream and
+        chained by the same events as the eager schedule — the cross-step overlap survives capture."""
+        with torch.cuda.device(self.device):
+            for _ in range(2 if self.overlap else 1):           # warm-up outside capture: one-time allocations, both buffers
+                self._run(optical, thermal, mask_optical, mask_thermal)
+            torch.cuda.synchronize()
+            masked = mask_optical is not None
+            if not self.overlap:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._encode(0, None, None)
+                    self._post(0, masked, None)
+                self._graphs = g
+
+                def replay(optical, thermal, mask_optical=None, mask_thermal=None):
+                    self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
+                    g.replay()
+                    return self
+                return replay
+            S = max(self.split_encoder, 1)
+            enc_streams = self.enc_streams if self.split_encoder else [self.enc_stream]
+            graphs = []
+            for k in range(2):
+                enc_g = []
+                gsz = 2 * self.B // S
+                for h, stream in enumerate(enc_streams):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        if self.split_encoder:
+                            sl = slice(h * gsz, (h + 1) * gsz)
+                            view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
+                            fl = self._flags()
+                            self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
+                                                 is_optical=None if fl is None else fl[sl])
+                        else:
+                            self._encode(k, None, None)
+                    enc_g.append(g)
+                pg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(pg, stream=self.post_stream):
+                    self._post(k, masked, None)
+                graphs.append((enc_g, pg))
+            self._graphs = graphs
+            torch.cuda.synchronize()
+
+            def replay(optical, thermal, mask_optical=None, mask_thermal=None):
+                with torch.cuda.device(self.device):
+                    k = self._call & 1
+                    self._call += 1
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(self.post_done[k])
+                    self._stage_inputs(k, optical, thermal, mask_optical, mask_thermal)
+                    enc_g, pg = graphs[k]
+                    for h, stream in enumerate(enc_streams):
+                        stream.wait_stream(cur)
+                        with torch.cuda.stream(stream):
+                            enc_g[h].replay()
+                            self.encs_done[k][h].record() if self.split_encoder else self.enc_done[k].record()
+                        self.post_stream.wait_event(self.encs_done[k][h] if self.split_encoder else self.enc_done[k])
+                    with torch.cuda.stream(self.post_stream):
+                        pg.replay()
+                        self.post_done[k].record()
+                    self.raw = self.raw_b[k]
+                    self.images = self.images_b[k]
+                return self
+            return replay
 
     def verify(self):
         """After a synchronisation point: the async NMS must have reached its fixed point and no list may have
