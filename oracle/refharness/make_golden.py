@@ -187,6 +187,25 @@ def gen_g16():
     np.savez_compressed(os.path.join(OUT, "g16_c4_1024.npz"), **g)
 
 
+def gen_g17():
+    """G17 — 8-bit R, G, B -> gray vectors of the ingest path (ImagePairDataset.py:199-208): every grey level, the primaries and
+    secondaries, every triple where the 14-bit fixed point and round(0.299 R + 0.587 G + 0.114 B) disagree on a 32-step lattice, and
+    4096 seeded random triples; expected gray from the oracle's integer restatement of OpenCV's RGB2Gray<uchar> (needs no
+    reference import: cv2 is absent)."""
+    from oracle import xpoint_oracle as xo
+    rng = np.random.default_rng(17)
+    lat = np.arange(0, 256, 32).tolist() + [255]
+    grid = np.array([(r, g, b) for r in lat for g in lat for b in lat], dtype=np.uint8)
+    fx = ((grid[:, 2].astype(np.int64) * 1868 + grid[:, 1].astype(np.int64) * 9617 + grid[:, 0].astype(np.int64) * 4899 + 8192) >> 14)
+    fl = np.floor(0.299 * grid[:, 0] + 0.587 * grid[:, 1] + 0.114 * grid[:, 2] + 0.5).astype(np.int64)
+    rgb = np.concatenate([np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1),
+                          np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.uint8),
+                          grid[fx != fl], rng.integers(0, 256, (4096, 3), dtype=np.uint8)], 0)
+    gray = xo.bgr2gray_u8(rgb)
+    np.savez_compressed(os.path.join(OUT, "g17_gray.npz"), rgb=rgb, gray=gray, value=xo.gray_to_float(gray))
+    print("g17", rgb.shape, "fixed-point != float rounding on", int((fx != fl).sum()), "lattice triples")
+
+
 def main():
     torch.set_num_threads(1)
     stubs.install()
@@ -352,7 +371,7 @@ def main():
         print("480x640", spec, "candidates", int((r["prob"] > 0.015).sum()), "kpts", len(kp), "pmax", float(p.max()))
     np.savez_compressed(os.path.join(OUT, "g10_full480x640.npz"), **g10)
 
-    gen_g12(); gen_g13(); gen_g14(); gen_g15(); gen_g16()
+    gen_g12(); gen_g13(); gen_g14(); gen_g15(); gen_g16(); gen_g17()
     manifest["generators"] = {"g15_c2_batch8.npz": "gen_g15() (BASELINE config C2: 8 pairs 480x640 end to end)",
                               "g16_c4_1024.npz": "gen_g16() (BASELINE config C4: one 1024x1024 pair, keep_top_k 4096, end to end)",
                               "g1..g11": "main()", "g12_conv_xpoint.npz": "gen_g12()",

@@ -481,3 +481,29 @@ def predict_keypoints(data, sd, pred=DEFAULT_PREDICTION):
         out.append([extract_keypoints(p[i].squeeze(), pred["detection_threshold"], data[spec]["valid_mask"][i].squeeze())
                     for i in range(p.shape[0])])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Data ingest: reference datasets/ImagePairDataset.py:199-208 decodes with cv2.imread and converts with
+# cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) / 255.0.  OpenCV is absent from /root/reference and from the image ("parity unpinned" for
+# the cv2 call itself); this restates its 8-bit path from the published implementation — modules/imgproc/src/color_rgb.simd.hpp,
+# RGB2Gray<uchar>: fixed point with yuv_shift = 14 and the BT.601 coefficients R2Y = 4899, G2Y = 9617, B2Y = 1868 (= 0.299, 0.587,
+# 0.114 * 2^14, summing to 2^14), rounding offset 2^13, pinned opencv-python==4.10.0.82 (reference requirements.txt:2) — in exact
+# Python integers, independently of the package's host path (xpoint_amd/datasets.py) and of the HIP kernel (xp_ingest_u8).
+# ---------------------------------------------------------------------------------------------------------------------
+def bgr2gray_u8(rgb):
+    """rgb: (..., 3) uint8 in R, G, B order (the decoded pixel; cv2.imread stores the same pixel as B, G, R) -> (...) uint8."""
+    import numpy as np
+    a = np.asarray(rgb)
+    flat = a.reshape(-1, a.shape[-1])
+    out = np.empty(len(flat), dtype=np.uint8)
+    for i, px in enumerate(flat.tolist()):
+        r, g, b = px[0], px[1], px[2]
+        out[i] = (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14
+    return out.reshape(a.shape[:-1])
+
+
+def gray_to_float(gray_u8):
+    """numpy's `gray / 255.0` of the reference (float64 division) as the float32 the network receives."""
+    import numpy as np
+    return (np.asarray(gray_u8).astype(np.float64) / 255.0).astype(np.float32)

@@ -79,3 +79,37 @@ def test_oracle_c2_indices_vs_reference_fixture(golden):
         rep, bad = parity.explain_match_diff(r["kp_optical"].numpy(), r["kp_thermal"].numpy(), g["p0/kp_optical"], g["p0/kp_thermal"],
                                              mine, g["p0/matches"], desc_of, tol=1e-5)
         assert not bad, parity.format_report("matches", rep)
+
+
+def test_homography_oracle_selfcheck():
+    """oracle/homography_oracle.py (the CPU restatement of the shipped robust estimator; its GPU twin is compared with it in
+    tests/test_gpu_evaluation.py): recovers a known model under 40 % outliers, is deterministic, distinct samples, no model below 4."""
+    from oracle import homography_oracle as ho
+    rng = np.random.default_rng(11)
+    Ht = np.array([[1.05, 0.03, 12.0], [-0.02, 0.97, -7.0], [4e-5, -3e-5, 1.0]])
+    src = np.stack([rng.uniform(0, 640, 300), rng.uniform(0, 480, 300)], 1)
+    q = np.concatenate([src, np.ones((300, 1))], 1) @ Ht.T
+    dst = q[:, :2] / q[:, 2:] + rng.normal(0, 0.3, (300, 2))
+    out = rng.random(300) < 0.4
+    dst[out] = np.stack([rng.uniform(0, 640, out.sum()), rng.uniform(0, 480, out.sum())], 1)
+    H, mask, n, best = ho.find_homography(src.astype(np.float32), dst.astype(np.float32), 3.0, 1500, seed=3)
+    H2, mask2, n2, best2 = ho.find_homography(src.astype(np.float32), dst.astype(np.float32), 3.0, 1500, seed=3)
+    assert best == best2 and np.array_equal(H, H2) and n == n2
+    corners = np.array([[0, 0, 1], [640, 0, 1], [0, 480, 1], [640, 480, 1]], float)
+    pa = corners @ H.T; pb = corners @ Ht.T
+    assert np.abs(pa[:, :2] / pa[:, 2:] - pb[:, :2] / pb[:, 2:]).max() < 1.0 and abs(H[2, 2] - 1) < 1e-12
+    assert (mask.astype(bool) & ~out).sum() > 0.95 * (~out).sum() and n == int(mask.sum())
+    idx = ho.sample4(3, 0, np.arange(200), 7)
+    assert all(len(set(r)) == 4 for r in idx.tolist()) and idx.min() >= 0 and idx.max() < 7
+    assert ho.find_homography(src[:3].astype(np.float32), dst[:3].astype(np.float32))[2] == 0
+
+
+def test_gray_conversion_fixture(golden):
+    """tests/golden/g17_gray.npz (8-bit R, G, B -> gray, OpenCV's RGB2Gray<uchar> fixed point restated in exact integers by the oracle):
+    the oracle reproduces it, and so does the package's host path (xpoint_amd.datasets), which is a separate numpy implementation."""
+    from xpoint_amd.datasets import rgb_to_gray_u8, gray_lut
+    g = golden("g17_gray.npz")
+    assert np.array_equal(xo.bgr2gray_u8(g["rgb"]), g["gray"])
+    assert np.array_equal(rgb_to_gray_u8(g["rgb"][None])[0], g["gray"])
+    assert np.array_equal(gray_lut()[g["gray"]], g["value"]) and np.array_equal(xo.gray_to_float(g["gray"]), g["value"])
+    assert np.array_equal(g["gray"][:256], np.arange(256))                      # r = g = b -> the grey level itself

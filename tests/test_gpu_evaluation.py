@@ -140,6 +140,28 @@ def test_find_homography_recovers_model_under_outliers(gpu_lib):
         assert int(nb[b]) == int(mb[b].sum()) and int(mb[b, (600 if b == 0 else 450):].sum()) == 0
 
 
+@pytest.mark.parametrize("seed_case,n,inl,noise,thr,iters,hseed", [(1, 900, 0.55, 0.5, 3.0, 10000, 0), (5, 300, 0.8, 0.3, 2.0, 2000, 7), (6, 40, 0.7, 0.2, 3.0, 500, 123),
+                                                                  (2, 200, 1.0, 0.0, 1.0, 1000, 0)])
+def test_find_homography_equals_oracle(gpu_lib, seed_case, n, inl, noise, thr, iters, hseed):
+    """The shipped estimator against its independent numpy restatement (oracle/homography_oracle.py: same counter-hashed samples,
+    same normalised DLT, same f32 MSAC score in point order, same three least-squares rounds): SAME winning hypothesis,
+    identical inlier mask and count, H to 1e-9.  (cv2.findHomography itself stays unpinned: OpenCV is absent)"""
+    from oracle import homography_oracle as ho
+    from xpoint_amd import utils
+    _, src, dst, _ = _corr_case(seed_case, n, inl, noise)
+    H, mask, n_inl = utils.find_homography_batched(torch.from_numpy(src).cuda()[None], torch.from_numpy(dst).cuda()[None], None, thr, iters, hseed)
+    Ho, mo, no, best = ho.find_homography(src, dst, thr, iters, hseed, pair=0)
+    assert best >= 0 and int(n_inl[0]) == no
+    assert np.array_equal(mask[0].cpu().numpy(), mo)
+    np.testing.assert_allclose(H[0].cpu().numpy(), Ho, rtol=1e-9, atol=1e-9)
+    # second pair of a batch: the pair index enters the hypothesis hash
+    S = torch.from_numpy(np.stack([src, src])).cuda(); D = torch.from_numpy(np.stack([dst, dst])).cuda()
+    Hb, mb, nb = utils.find_homography_batched(S, D, None, thr, iters, hseed)
+    H1, m1, n1, _ = ho.find_homography(src, dst, thr, iters, hseed, pair=1)
+    assert int(nb[1]) == n1 and np.array_equal(mb[1].cpu().numpy(), m1)
+    np.testing.assert_allclose(Hb[1].cpu().numpy(), H1, rtol=1e-9, atol=1e-9)
+
+
 def test_predict_align_image_pair_with_registration(gpu_lib):
     """predict_align_image_pair.py:287-303 end to end: thermal = optical shifted by (dx, dy) pixels -> the estimated
     homography is that translation (keypoints are integer pixels, so to a fraction of a pixel)."""

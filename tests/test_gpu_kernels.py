@@ -588,6 +588,24 @@ def test_ingest_u8_exact(gpu_lib, ch):
         L.call("xp_ingest_u8", ctypes.c_void_p(d.data_ptr()), H0, W0, ch, top, left, h + 100, w, L.ptr(lut), L.ptr(out), L.current_stream())
 
 
+def test_ingest_u8_vs_gray_fixture(gpu_lib, golden):
+    """xp_ingest_u8 against the oracle's fixture (tests/golden/g17_gray.npz: OpenCV's 8-bit fixed-point BGR2GRAY restated in exact
+    integers, then / 255.0 in float64 -> float32), not against the package's own host path."""
+    L = _lib()
+    g = golden("g17_gray.npz")
+    H0, W0 = 89, 49
+    assert g["rgb"].shape == (H0 * W0, 3)
+    d = torch.from_numpy(g["rgb"].reshape(H0, W0, 3).copy()).cuda()
+    lut = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)).cuda()
+    out = torch.empty((H0, W0), device="cuda")
+    L.call("xp_ingest_u8", ctypes.c_void_p(d.data_ptr()), H0, W0, 3, 0, 0, H0, W0, L.ptr(lut), L.ptr(out), L.current_stream())
+    assert np.array_equal(out.cpu().numpy().reshape(-1), g["value"])
+    rgba = np.concatenate([g["rgb"], np.full((H0 * W0, 1), 200, np.uint8)], 1).reshape(H0, W0, 4)          # alpha is ignored
+    d4 = torch.from_numpy(rgba.copy()).cuda()
+    L.call("xp_ingest_u8", ctypes.c_void_p(d4.data_ptr()), H0, W0, 4, 0, 0, H0, W0, L.ptr(lut), L.ptr(out), L.current_stream())
+    assert np.array_equal(out.cpu().numpy().reshape(-1), g["value"])
+
+
 def test_image_pair_dataset_load_batch_equals_getitem(gpu_lib, tmp_path):
     """Device ingest (host decode -> u8 upload -> xp_ingest_u8) == the host path of ImagePairDataset.__getitem__, bit for bit,
     and the batch feeds XPoint.forward's input structure."""
