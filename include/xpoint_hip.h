@@ -150,6 +150,18 @@ size_t xp_mlp_fused_x3_pack_bytes(int C, int hidden, int with_proj);
 int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, const void* W0x3, void* out, int C, int hidden, void* stream);
 int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
                     const float* b2, int M, int C, int hidden, float eps, void* stream);
+/* The same fused kernels on the split-fp16 engine ("h2", csrc/gemm_h2_core.h: two fp16 planes, three products): weight
+ * streams packed from xp_split_weights_h2 buffers (W1h2 (hidden, C), W2h2 (C, hidden), W0h2 (C, C) or NULL), whose power-of-two
+ * row scales the kernel undoes exactly (fc1: before the GELU; fc2 and the projections: on the accumulators); the same buffers
+ * are passed again at launch for those scales.  Shapes as xp_mlp_fused_x3_supported. */
+size_t xp_mlp_fused_h2_pack_bytes(int C, int hidden, int with_proj);
+int xp_mlp_fused_h2_pack(const void* W1h2, const void* W2h2, const void* W0h2, void* out, int C, int hidden, void* stream);
+int xp_mlp_fused_h2(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const void* W1h2, const void* W2h2,
+                    const void* W0h2, const float* b1, const float* b2, int M, int C, int hidden, float eps, void* stream);
+size_t xp_ln_proj_h2_pack_bytes(int C, int N);
+int xp_ln_proj_h2_pack(const void* W0h2, void* out, int C, int N, void* stream);
+int xp_ln_proj_h2(const float* X, const float* ln_w, const float* ln_b, const void* Wpack, const void* W0h2, float* Out, int M, int C, int N,
+                  float eps, void* stream);
 /* The head of the block in the same row-stationary form:  Out (M, N) = LayerNorm(X) W0^T   (VMamba.py:1229 norm + :649
  * in_proj, bias-free), one launch instead of xp_layernorm + xp_gemm_nt_x3, the normalised rows never written to memory.
  * W0 (N, C) is passed as the packed stream built by xp_ln_proj_x3_pack from its xp_split_weights_x3 form

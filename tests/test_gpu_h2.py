@@ -116,3 +116,62 @@ def test_conv3x3_h2(gpu_lib, B, H, W, Ci, Co, stride, reflect):
            L.current_stream())
     err = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max())
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("proj", [False, True])
+@pytest.mark.parametrize("M,C,H4", [(128, 96, 384), (300, 96, 384), (1000, 32, 128), (517, 64, 256), (4480, 96, 384), (77, 96, 96),
+                                    (200, 64, 64), (130, 32, 512), (300, 192, 768), (129, 128, 512), (2400, 192, 768)])
+def test_mlp_fused_h2(gpu_lib, M, C, H4, proj):
+    """x + fc2(GELU(fc1(LN(x)))) in one launch (VMamba.py:1230-1234, :110-128), optionally preceded by x += t W0^T (SS2D out_proj +
+    first residual, VMamba.py:663, :1229) on the split-fp16 engine, vs fp64 torch and vs the separate h2 launches it replaces."""
+    L = _lib()
+    X = _u(f"mx{M}{C}", (M, C), -2.0, 2.0); lw = _u(f"mlw{C}", (C,), 0.5, 1.5); lb = _u(f"mlb{C}", (C,), -0.5, 0.5)
+    W1 = _u(f"mw1{C}{H4}", (H4, C), -0.2, 0.2); b1 = _u(f"mb1{H4}", (H4,), -0.5, 0.5)
+    W2 = _u(f"mw2{C}{H4}", (C, H4), -0.1, 0.1); b2 = _u(f"mb2{C}", (C,), -0.5, 0.5)
+    T1 = _u(f"mt{M}{C}", (M, C), -1.0, 1.0); W0 = _u(f"mw0{C}", (C, C), -0.2, 0.2)
+    W1[3] *= 1e-3; W2[:, 5] *= 30.0; W0[1] *= 1e-2                      # rows of very different magnitude: the per-row scales matter
+    Xd = X.double()
+    if proj:
+        Xd = Xd + F.linear(T1.double(), W0.double())
+    ref = Xd + F.linear(F.gelu(F.linear(F.layer_norm(Xd, (C,), lw.double(), lb.double(), 1e-5), W1.double(), b1.double())), W2.double(), b2.double())
+    Xg = X.cuda(); lwd, lbd, b1d, b2d, T1d = lw.cuda(), lb.cuda(), b1.cuda(), b2.cuda(), T1.cuda()
+    W1x, W2x, W0x = _split_h2(L, W1.cuda()), _split_h2(L, W2.cuda()), _split_h2(L, W0.cuda())
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = L.current_stream()
+    pack = torch.empty(L.load().xp_mlp_fused_h2_pack_bytes(C, H4, int(proj)), dtype=torch.uint8, device="cuda")
+    L.call("xp_mlp_fused_h2_pack", vp(W1x), vp(W2x), vp(W0x) if proj else None, vp(pack), C, H4, st)
+    L.call("xp_mlp_fused_h2", L.ptr(Xg), L.ptr(T1d) if proj else None, L.ptr(lwd), L.ptr(lbd), vp(pack), vp(W1x), vp(W2x), vp(W0x) if proj else None,
+           L.ptr(b1d), L.ptr(b2d), M, C, H4, 1e-5, st)
+    err = float((Xg.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    X3 = X.cuda(); T = torch.empty((M, C), device="cuda"); Hb = torch.empty((M, H4), device="cuda")
+    if proj:
+        L.call("xp_gemm_nt_h2", L.ptr(T1d), vp(W0x), L.ptr(X3), None, None, None, L.ptr(X3), M, C, C, C, C, C, 0, st)
+    L.call("xp_layernorm", L.ptr(X3), L.ptr(T), L.ptr(lwd), L.ptr(lbd), M, C, 1e-5, 0, st)
+    L.call("xp_gemm_nt_h2", L.ptr(T), vp(W1x), L.ptr(Hb), L.ptr(b1d), None, None, None, M, H4, C, C, H4, 0, 1, st)
+    L.call("xp_gemm_nt_h2", L.ptr(Hb), vp(W2x), L.ptr(X3), L.ptr(b2d), None, None, L.ptr(X3), M, C, H4, H4, C, C, 0, st)
+    err3 = float((X3.cpu().double() - ref).abs().max())
+    assert err <= 2.0 * err3 + 1e-6, (err, err3)
+    assert float((Xg - X3).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,C,N", [(300, 96, 96), (1000, 32, 64), (517, 64, 64), (4480, 96, 96), (77, 192, 192), (129, 128, 128), (260, 96, 32)])
+def test_ln_proj_h2(gpu_lib, M, C, N):
+    """LayerNorm + bias-free projection in one launch (VMamba.py:1229 norm + :649 in_proj) on the split-fp16 engine."""
+    L = _lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = L.current_stream()
+    X = _u(f"lpx{M}{C}", (M, C), -2.0, 2.0); lw = _u(f"lpw{C}", (C,), 0.5, 1.5); lb = _u(f"lpb{C}", (C,), -0.5, 0.5); W0 = _u(f"lpW{C}{N}", (N, C), -0.3, 0.3)
+    W0[2] *= 1e-3
+    ref = F.linear(F.layer_norm(X.double(), (C,), lw.double(), lb.double(), 1e-5), W0.double())
+    Xd, lwd, lbd = X.cuda(), lw.cuda(), lb.cuda()
+    W0x = _split_h2(L, W0.cuda())
+    nb = L.load().xp_ln_proj_h2_pack_bytes(C, N)
+    assert nb > 0
+    pack = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    L.call("xp_ln_proj_h2_pack", vp(W0x), vp(pack), C, N, st)
+    out = torch.empty((M, N), device="cuda")
+    L.call("xp_ln_proj_h2", L.ptr(Xd), L.ptr(lwd), L.ptr(lbd), vp(pack), vp(W0x), L.ptr(out), M, C, N, 1e-5, st)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    assert torch.equal(Xd.cpu(), X)                       # X is read-only

@@ -39,6 +39,10 @@ _SIGNATURES = {
     "xp_split_weights_h2": [c_p, c_p, c_i, c_i, c_p],
     "xp_gemm_nt_h2": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc_h2": [c_p] * 6 + [c_i] * 8 + [c_p],
+    "xp_mlp_fused_h2": [c_p] * 10 + [c_i] * 3 + [c_f, c_p],
+    "xp_mlp_fused_h2_pack": [c_p] * 4 + [c_i] * 2 + [c_p],
+    "xp_ln_proj_h2_pack": [c_p] * 2 + [c_i] * 2 + [c_p],
+    "xp_ln_proj_h2": [c_p] * 6 + [c_i] * 3 + [c_f, c_p],
     "xp_mlp_fused_x3": [c_p] * 7 + [c_i] * 3 + [c_f, c_p],
     "xp_mlp_fused_x3_pack": [c_p] * 4 + [c_i] * 2 + [c_p],
     "xp_ln_proj_x3_pack": [c_p] * 2 + [c_i] * 2 + [c_p],
@@ -87,6 +91,8 @@ _SIZE_QUERIES = {
     "xp_get_dense_products": (c_i, []),
     "xp_get_dense_engine": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
+    "xp_mlp_fused_h2_pack_bytes": (c_sz, [c_i, c_i, c_i]),
+    "xp_ln_proj_h2_pack_bytes": (c_sz, [c_i, c_i]),
     "xp_ln_proj_x3_pack_bytes": (c_sz, [c_i, c_i]),
     "xp_find_homography_workspace_bytes": (c_sz, [c_i]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),

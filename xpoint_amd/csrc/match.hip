@@ -58,6 +58,9 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, int idx) {
 __device__ __forceinline__ float mt_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float mt_max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
+// (a kernel, not hipMemsetAsync: see nms_reset_counters_kernel in postproc.hip)
+__global__ void match_reset_kernel(unsigned* __restrict__ maxbits) { if (threadIdx.x < 4) maxbits[threadIdx.x] = 0u; }
+
 // ---- pass 0a: squared norms of both descriptor sets and the largest one of the call ----
 __global__ __launch_bounds__(256) void match_norms_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ cnt,
                                                           int cnt_stride, int which1, int which2, int cap1, int cap2, int D,
@@ -505,7 +508,7 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     if (csplit > rows2P / MT_TILE) csplit = rows2P / MT_TILE;
     g.csplit = csplit;
     XpProfScope prof("match_mnn", s, 0.0, 0.0);   // work depends on device-side counts: bench.py prices it from the fetched counts
-    XP_HIP(hipMemsetAsync(maxbits, 0, 16, s));
+    hipLaunchKernelGGL(match_reset_kernel, dim3(1), dim3(64), 0, s, maxbits);
     const int capmax = cap1 > cap2 ? cap1 : cap2;
     hipLaunchKernelGGL(match_norms_kernel, dim3(xp_cdiv(capmax, 16), pairs, 2), dim3(256), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D,
                        na, nb, maxbits);

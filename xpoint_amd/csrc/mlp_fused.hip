@@ -37,6 +37,7 @@
 #include <string>
 
 #include "gemm_x3_core.h"
+#include "gemm_h2_core.h"
 
 #ifndef XP_MLP_DBG
 #define XP_MLP_DBG 0   /* timing experiments only (wrong results): 1 no GELU, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no bf16 split of the hidden values, 16 no MFMA */
@@ -55,16 +56,22 @@ struct MlpParams {
     const float* b2;
     int M, H4;
     float eps;
+    // split-fp16 ("h2") instances only: inverse power-of-two row scales of the offline weight split (gemm_h2_core.h) —
+    // s0 (rows of W0), s1 (H4 rows of fc1.weight), s2 (C rows of fc2.weight); null for the split-bf16 instances
+    const float* s0; const float* s1; const float* s2;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int C>
+template <int C, bool H2 = false>
 struct MlpTile {
     static constexpr int KS = C / 16;            // k slabs of fc1
     static constexpr int NT = C / 32;            // 32-wide output tiles of fc2
     static constexpr int ROWS = 2 * C;           // rows of a chunk image (W1: KS x 32, W2: 2 x C)
-    static constexpr int UNITS = ROWS * 7;       // 16-byte units per image incl. the pad unit of every row
+    static constexpr int NPL = H2 ? 2 : 3;       // operand planes (h2: two fp16 planes, x3: three bf16 planes), 32 B each per row and slab
+    static constexpr int UPR = 2 * NPL + 1;      // 16-byte units per image row incl. its pad unit
+    static constexpr int ROWB = UPR * 16;        // 112 B (x3) / 80 B (h2): both conflict-free for ds_read_b128 fragment reads
+    static constexpr int UNITS = ROWS * UPR;     // 16-byte units per image
     static constexpr int NI = (UNITS * 16 + 4095) / 4096;     // DMA instructions per wave and image (4 waves x 1 KiB each)
     static constexpr int IMGP = NI * 4096;       // image stride in the packed stream and in the LDS ring (>= UNITS * 16)
     static_assert(C % 32 == 0, "C must be a multiple of 32");
@@ -73,10 +80,18 @@ struct MlpTile {
 __device__ __forceinline__ int mlp_swap23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // One thread per 16-byte unit of the packed stream (see the header comment for the image order).
-template <int C>
+// source unit of (weight row n of N, 16-wide k slab s, unit k = plane * 2 + octet) in the offline split layouts
+template <bool H2>
+__device__ __forceinline__ uint4 mlp_src_unit(const uint4* __restrict__ W, int N, int n, int s, int k) {
+    if (H2) return W[((int64_t)(s >> 1) * N + n) * H2_SLAB_UNITS + (k >> 1) * 4 + (s & 1) * 2 + (k & 1)];       // [slab32][n][plane][4 octets]
+    return W[((int64_t)s * N + n) * X3_SLAB_UNITS + k];                                                         // [slab16][n][plane][2 octets]
+}
+
+template <int C, bool H2>
 __global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2, const uint4* __restrict__ W0, uint4* __restrict__ out, int H4,
                                 int n0) {      // n0 = rows of W0 (C for out_proj ahead of an MLP; any multiple of 32 for a projection-only stream)
-    using T = MlpTile<C>;
+    using T = MlpTile<C, H2>;
+    constexpr int UPR = T::UPR, KD = T::UPR - 1;
     const int NC = H4 / 32, NPRE = W0 ? n0 / 32 : 0;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int upi = T::IMGP / 16;
@@ -84,25 +99,25 @@ __global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __res
     int n = (int)(id / upi);
     const int u = (int)(id - (int64_t)n * upi);
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    const int row = u / 7, k = u - row * 7;
+    const int row = u / UPR, k = u - row * UPR;
     if (n < NPRE) {          // the (C, C) projection ahead of the MLP, as NT images in the W1 format (32 permuted output rows x all k slabs)
-        if (u < T::UNITS && k < 6) {
+        if (u < T::UNITS && k < KD) {
             const int s = row >> 5, h = 32 * n + mlp_swap23(row & 31);
-            v = W0[((int64_t)s * n0 + h) * X3_SLAB_UNITS + k];
+            v = mlp_src_unit<H2>(W0, n0, h, s, k);
         }
         out[id] = v;
         return;
     }
     n -= NPRE;
-    if (u < T::UNITS && k < 6) {
+    if (u < T::UNITS && k < KD) {
         // image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1); n = 2NC-1 -> W2(NC-1)
         const bool is_w1 = (n == 0) || ((n & 1) && n < 2 * NC - 1);
         if (is_w1) {
             const int c = (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
-            v = W1[((int64_t)s * H4 + h) * X3_SLAB_UNITS + k];
+            v = mlp_src_unit<H2>(W1, H4, h, s, k);
         } else {
             const int c = (n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1, j = row / C, nn = row - j * C;
-            v = W2[((int64_t)(2 * c + j) * C + nn) * X3_SLAB_UNITS + k];
+            v = mlp_src_unit<H2>(W2, C, nn, 2 * c + j, k);
         }
     }
     out[id] = v;
@@ -125,16 +140,49 @@ __device__ __forceinline__ float mlp_gelu(float x) {
 
 // MODE 0: MLP branch; 1: out_proj + first residual, then the MLP branch; 2: LayerNorm + one bias-free projection only
 // (Out = LN(X) W0^T: the block's norm + in_proj, VMamba.py:1229 / :649), the same row-stationary phases without the MLP.
-template <int C, int NW, int MODE, int NP>
-__global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_kernel(MlpParams p) {
+// 16-bit operand fragments of either engine travel as raw bits; the MFMA is chosen by the engine
+typedef unsigned frag_bits __attribute__((ext_vector_type(4)));
+template <bool H2>
+__device__ __forceinline__ f32x16 mlp_mfma(frag_bits a, frag_bits b, f32x16 c) {
+    if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// eight f32 -> operand planes (x3: three exact bf16 planes; h2: two fp16 planes, 2^-24 operand error)
+template <bool H2>
+__device__ __forceinline__ void mlp_split8(const float4& lo, const float4& hi, frag_bits (&pl)[3]) {
+    if constexpr (H2) {
+        uint2 a0, a1, b0, b1;
+        h2_split4(lo, a0, a1); h2_split4(hi, b0, b1);
+        pl[0] = frag_bits{a0.x, a0.y, b0.x, b0.y}; pl[1] = frag_bits{a1.x, a1.y, b1.x, b1.y}; pl[2] = pl[0];
+    } else {
+        uint4 c0, c1, c2;
+        xp_split8(lo, hi, c0, c1, c2);
+        pl[0] = frag_bits{c0.x, c0.y, c0.z, c0.w}; pl[1] = frag_bits{c1.x, c1.y, c1.z, c1.w}; pl[2] = frag_bits{c2.x, c2.y, c2.z, c2.w};
+    }
+}
+template <bool H2>
+__device__ __forceinline__ void mlp_split2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+    if constexpr (H2) {
+        union { f16x2_t h; unsigned u; } a, b;
+        a.h = f16x2_t{(_Float16)x, (_Float16)y};
+        b.h = f16x2_t{(_Float16)(x - (float)a.h[0]), (_Float16)(y - (float)a.h[1])};
+        p0 = a.u; p1 = b.u; p2 = a.u;
+    } else xp_split2(x, y, p0, p1, p2);
+}
+
+template <int C, int NW, int MODE, int NP, bool H2>
+__global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void mlp_fused_kernel(MlpParams p) {      // h2: two waves per SIMD at every C (two planes resident)
     static_assert(NP == 6 || NP == 3 || NP == 1, "partial products per multiply (gemm_x3_core.h)");
+    static_assert(!H2 || NP == 3, "the split-fp16 engine always forms its three products");
     constexpr bool PRE = MODE == 1, PROJ_ONLY = MODE == 2;
-    using T = MlpTile<C>;
+    using T = MlpTile<C, H2>;
+    constexpr int ROWB = T::ROWB;
     constexpr int KS = T::KS, NT = T::NT;
     constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
     static_assert(T::NI * 4 % NW == 0, "image pieces must divide among the waves");
-    extern __shared__ __align__(16) unsigned char lds[];       // [3 image slots][b1 (H4 floats)] — ONE array (LDS-DMA waits)
+    extern __shared__ __align__(16) unsigned char lds[];       // [3 image slots][b1 (H4 floats)][h2: 1 / row scale of fc1 (H4 floats)] — ONE array (LDS-DMA waits)
     unsigned char* const bias_lds = lds + 3 * T::IMGP;
+    unsigned char* const inv1_lds = bias_lds + (size_t)p.H4 * 4;
     const int lane = threadIdx.x & 63, fr = lane & 31, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * (NW * 32) + wave * 32;
@@ -174,9 +222,16 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         }
     }
     if (!PROJ_ONLY)
-        for (int i = threadIdx.x; i < p.H4 / 4; i += NW * 64)
-            reinterpret_cast<float4*>(bias_lds)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-    bf16x8 xp[KS][3];          // planes of the B operand of the fc1-type MFMAs: LN(x) of this wave's rows (PRE: first the T1 rows)
+        for (int i = threadIdx.x; i < p.H4 / 4; i += NW * 64) {
+            float4 bv = reinterpret_cast<const float4*>(p.b1)[i];
+            if constexpr (H2) {      // accumulators carry the row scale 2^k of fc1.weight: start them at b1 * 2^k, multiply by 2^-k before the GELU (both exact)
+                const float4 iv = reinterpret_cast<const float4*>(p.s1)[i];
+                reinterpret_cast<float4*>(inv1_lds)[i] = iv;
+                bv = make_float4(bv.x / iv.x, bv.y / iv.y, bv.z / iv.z, bv.w / iv.w);
+            }
+            reinterpret_cast<float4*>(bias_lds)[i] = bv;
+        }
+    frag_bits xp[KS][3];       // planes of the B operand of the fc1-type MFMAs: LN(x) of this wave's rows (PRE: first the T1 rows)
     auto layer_norm_split = [&]() {
         float sum = 0.f;
 #pragma unroll
@@ -203,9 +258,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
             lo.z = (xv[s][0].z - mean) * rstd * w0.z + c0.z; lo.w = (xv[s][0].w - mean) * rstd * w0.w + c0.w;
             hi.x = (xv[s][1].x - mean) * rstd * w1.x + c1.x; hi.y = (xv[s][1].y - mean) * rstd * w1.y + c1.y;
             hi.z = (xv[s][1].z - mean) * rstd * w1.z + c1.z; hi.w = (xv[s][1].w - mean) * rstd * w1.w + c1.w;
-            union { uint4 u; bf16x8 v; } c[3];
-            xp_split8(lo, hi, c[0].u, c[1].u, c[2].u);
-            xp[s][0] = c[0].v; xp[s][1] = c[1].v; xp[s][2] = c[2].v;
+            mlp_split8<H2>(lo, hi, xp[s]);
         }
     };
     if (PRE) {                 // rows of T1 in the same lane layout, split into planes
@@ -213,9 +266,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float4 lo = *reinterpret_cast<const float4*>(tr + 16 * s), hi = *reinterpret_cast<const float4*>(tr + 16 * s + 4);
-            union { uint4 u; bf16x8 v; } c[3];
-            xp_split8(lo, hi, c[0].u, c[1].u, c[2].u);
-            xp[s][0] = c[0].v; xp[s][1] = c[1].v; xp[s][2] = c[2].v;
+            mlp_split8<H2>(lo, hi, xp[s]);
         }
     } else {
         layer_norm_split();
@@ -232,8 +283,25 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};     // smallest partial products first
-    const int frag = fr * X3_ROWB + 16 * g;
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};     // smallest partial products first (h2 = the last three: a1 b0, a0 b1, a0 b0)
+    constexpr int NPLD = H2 ? 2 : 3;                                          // planes read from an image row
+    const int frag = fr * ROWB + 16 * g;
+    // h2: 1 / row scale of the hidden units held by this lane's accumulator registers (registers 8j .. 8j+7 = units 32c + 16j + 8g + 0..7)
+    auto load_inv1 = [&](int c, float (&iv)[16]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 lo = *reinterpret_cast<const float4*>(inv1_lds + (32 * c + 16 * j + 8 * g) * 4);
+            const float4 hi = *reinterpret_cast<const float4*>(inv1_lds + (32 * c + 16 * j + 8 * g + 4) * 4);
+            iv[8 * j + 0] = lo.x; iv[8 * j + 1] = lo.y; iv[8 * j + 2] = lo.z; iv[8 * j + 3] = lo.w;
+            iv[8 * j + 4] = hi.x; iv[8 * j + 5] = hi.y; iv[8 * j + 6] = hi.z; iv[8 * j + 7] = hi.w;
+        }
+    };
+    float inv_cur[16];                     // h2: scales of the chunk whose GELU is being evaluated
+    // 8 consecutive inverse row scales of a projection's output columns col0 .. col0 + 7 (h2; the x3 planes are unscaled)
+    auto load_inv8 = [&](const float* sc, int col0, float (&iv)[8]) {
+        const float4 lo = *reinterpret_cast<const float4*>(sc + col0), hi = *reinterpret_cast<const float4*>(sc + col0 + 4);
+        iv[0] = lo.x; iv[1] = lo.y; iv[2] = lo.z; iv[3] = lo.w; iv[4] = hi.x; iv[5] = hi.y; iv[6] = hi.z; iv[7] = hi.w;
+    };
 
     // accumulator start = b1 of the chunk: registers 8j .. 8j+7 = hidden units 32c + 16j + 8g + 0..7
     auto load_bias = [&](int c, f32x16& h) {
@@ -246,11 +314,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         }
     };
     unsigned hp[2][3][4];                  // GELU(hidden chunk) as planes (slab j, plane, 4 x 2 bf16): the A operand of fc2
-    auto hfrag = [&](int j, int pl) {
-        union { uint4 u; bf16x8 v; } c;
-        c.u = make_uint4(hp[j][pl][0], hp[j][pl][1], hp[j][pl][2], hp[j][pl][3]);
-        return c.v;
-    };
+    auto hfrag = [&](int j, int pl) { return frag_bits{hp[j][pl][0], hp[j][pl][1], hp[j][pl][2], hp[j][pl][3]}; };
     int n = 0, slot = 0;                   // image used by the current phase and its ring slot; image n + 2 goes to slot - 1 (mod 3)
     // The DMA pieces of image n + 2 are issued BETWEEN the MFMA groups of phase n (one piece per k slab / output step), not in one
     // burst at its start: a few per cent faster (363 vs 375 us at C = 192) — an LDS-DMA issued among MFMAs costs less than one issued
@@ -262,31 +326,31 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     };
     // VALU slices placed between MFMAs.  Slices 0..15: GELU of element r in place; 16..19 / 20..23: bf16 split of pair q of half 0 / 1.
     auto slice = [&](int k, f32x16& h) {
-        if (k < 16) { h[k] = mlp_gelu(h[k]); return; }
+        if (k < 16) { h[k] = mlp_gelu(H2 ? h[k] * inv_cur[k] : h[k]); return; }
         const int j = (k - 16) >> 2, q = (k - 16) & 3;
         if (XP_MLP_DBG & 8) { hp[j][0][q] = __float_as_uint(h[8 * j + 2 * q]); hp[j][1][q] = __float_as_uint(h[8 * j + 2 * q + 1]); hp[j][2][q] = hp[j][0][q]; }
-        else xp_split2(h[8 * j + 2 * q], h[8 * j + 2 * q + 1], hp[j][0][q], hp[j][1][q], hp[j][2][q]);
+        else mlp_split2<H2>(h[8 * j + 2 * q], h[8 * j + 2 * q + 1], hp[j][0][q], hp[j][1][q], hp[j][2][q]);
     };
     // fc1 of one chunk from the W1 image in `slot` into nxt (preloaded with the bias); between the MFMAs, slices [0, NSL) of the
     // previous chunk's accumulators `cur` (NSL = 0: none)
     auto fc1 = [&](int slot, f32x16& nxt, f32x16& cur, auto nsl_tag) {
         constexpr int NSL = decltype(nsl_tag)::value;
         const unsigned char* img = lds + slot * T::IMGP + frag;
-        bf16x8 a[2][3];
+        frag_bits a[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[0][pl] = *reinterpret_cast<const bf16x8*>(img + pl * 32);
+        for (int pl = 0; pl < NPLD; ++pl) a[0][pl] = *reinterpret_cast<const frag_bits*>(img + pl * 32);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) {      // fragments of slab s+1 are requested before the MFMAs of slab s
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[(s + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(img + (s + 1) * 32 * X3_ROWB + pl * 32);
+                for (int pl = 0; pl < NPLD; ++pl) a[(s + 1) & 1][pl] = *reinterpret_cast<const frag_bits*>(img + (s + 1) * 32 * ROWB + pl * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 6 - NP; pp < 6; ++pp) {
                 const int m = s * NP + pp - (6 - NP);
-                if (XP_MLP_DBG & 16) { if (pp == 5) nxt[0] += (float)a[s & 1][0][0] * (float)xp[s][0][0]; }
-                else nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][PA[pp]], xp[s][PB[pp]], nxt, 0, 0, 0);
+                if (XP_MLP_DBG & 16) { if (pp == 5) nxt[0] += __uint_as_float(a[s & 1][0][0]) * __uint_as_float(xp[s][0][0]); }
+                else nxt = mlp_mfma<H2>(a[s & 1][PA[pp]], xp[s][PB[pp]], nxt);
 #pragma unroll
                 for (int k = (m * NSL + NP * KS - 1) / (NP * KS); k < ((m + 1) * NSL + NP * KS - 1) / (NP * KS); ++k) slice(k, cur);
                 __builtin_amdgcn_sched_barrier(0);
@@ -298,22 +362,22 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     // (slices 20..23 of `cur`) between those MFMAs, then hidden slab 1
     auto fc2 = [&](int slot, f32x16& cur) {
         const unsigned char* img = lds + slot * T::IMGP + frag;
-        bf16x8 b[2][3];
+        frag_bits b[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const bf16x8*>(img + pl * 32);
+        for (int pl = 0; pl < NPLD; ++pl) b[0][pl] = *reinterpret_cast<const frag_bits*>(img + pl * 32);
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {          // step i = (hidden slab j = i / NT, output tile t = i % NT)
             const int j = i / NT, t = i % NT;
             if (i + 1 < 2 * NT) {
                 const int j1 = (i + 1) / NT, t1 = (i + 1) % NT;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) b[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(img + (j1 * C + t1 * 32) * X3_ROWB + pl * 32);
+                for (int pl = 0; pl < NPLD; ++pl) b[(i + 1) & 1][pl] = *reinterpret_cast<const frag_bits*>(img + (j1 * C + t1 * 32) * ROWB + pl * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 6 - NP; pp < 6; ++pp) {
-                if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * (float)b[i & 1][0][0]; }
-                else oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hfrag(j, PA[pp]), b[i & 1][PB[pp]], oacc[t], 0, 0, 0);
+                if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i & 1][0][0]); }
+                else oacc[t] = mlp_mfma<H2>(hfrag(j, PA[pp]), b[i & 1][PB[pp]], oacc[t]);
                 if (i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (NP >= 4 ? q == pp - (6 - NP) : true) slice(20 + q, cur);
@@ -340,6 +404,12 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
             if (rok) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
+                    if constexpr (H2) {      // undo the row scale of the projection weight (exact)
+                        float iv[8];
+                        load_inv8(p.s0, 32 * t + 16 * jj + 8 * g, iv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h0[8 * jj + e] *= iv[e];
+                    }
                     *reinterpret_cast<float4*>(ow + 32 * t + 16 * jj) = make_float4(h0[8 * jj + 0], h0[8 * jj + 1], h0[8 * jj + 2], h0[8 * jj + 3]);
                     *reinterpret_cast<float4*>(ow + 32 * t + 16 * jj + 4) = make_float4(h0[8 * jj + 4], h0[8 * jj + 5], h0[8 * jj + 6], h0[8 * jj + 7]);
                 }
@@ -360,6 +430,12 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
             end_phase();
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
+                if constexpr (H2) {          // undo the row scale of out_proj.weight (exact): channels 16 (2t + jj) + 8g + 0..7
+                    float iv[8];
+                    load_inv8(p.s0, 16 * (2 * t + jj) + 8 * g, iv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h0[8 * jj + e] *= iv[e];
+                }
                 float4& lo = xv[2 * t + jj][0]; float4& hi = xv[2 * t + jj][1];
                 lo.x = lo.x + h0[8 * jj + 0]; lo.y = lo.y + h0[8 * jj + 1]; lo.z = lo.z + h0[8 * jj + 2]; lo.w = lo.w + h0[8 * jj + 3];
                 hi.x = hi.x + h0[8 * jj + 4]; hi.y = hi.y + h0[8 * jj + 5]; hi.z = hi.z + h0[8 * jj + 6]; hi.w = hi.w + h0[8 * jj + 7];
@@ -386,6 +462,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
     //          phase B = fc2(c) (image 2 + 2c)
     auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
+        if constexpr (H2) load_inv1(c, inv_cur);
         load_bias(c + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         fc1(slot, nxt, cur, std::integral_constant<int, 20>{});
@@ -396,6 +473,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     int c = 0;
     for (; c + 2 < NC; c += 2) { iter(c, h0, h1); iter(c + 1, h1, h0); }
     auto tail = [&](f32x16& cur) {         // last chunk: nothing left to overlap the GELU with; image 2 NC - 1
+        if constexpr (H2) load_inv1(NC - 1, inv_cur);
 #pragma unroll
         for (int k = 0; k < 20; ++k) slice(k, cur);
         fc2(slot, cur);
@@ -411,6 +489,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
         for (int t = 0; t < NT; ++t) {
             const int col = t * 32 + fr;
             const float bi = p.b2[col];
+            const float ws = H2 ? p.s2[col] : 1.f;          // h2: 1 / row scale of fc2.weight (exact)
             float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -421,7 +500,7 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float v = oacc[t][r] + bi;
+                const float v = H2 ? oacc[t][r] * ws + bi : oacc[t][r] + bi;
                 if (INTERIOR || m0 + rl < p.M) xb[rl * C + col] = rv[r] + v;
             }
         }
@@ -429,30 +508,39 @@ __global__ __launch_bounds__(NW * 64, (C <= 96 ? 8 : 4) / NW) void mlp_fused_ker
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int C, int NW, int MODE, int NP>
+template <int C, int NW, int MODE, int NP, bool H2 = false>
 int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     constexpr bool PRE = MODE == 1;
-    using T = MlpTile<C>;
-    const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4;
+    using T = MlpTile<C, H2>;
+    const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4 * (H2 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T::IMGP + 4096 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * T::IMGP + 4096 * 4 * (H2 ? 2 : 1));
         attr_set = true;
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = std::string(MODE == 2 ? "ln_proj_x3_c" : PRE ? "proj_mlp_fused_x3_c" : "mlp_fused_x3_c") + std::to_string(C);      // one tag per kernel instance
-    if (NP != 6) tag += "_np" + std::to_string(NP);
+    const char* eng = H2 ? "_h2_c" : "_x3_c";
+    std::string tag = std::string(MODE == 2 ? "ln_proj" : PRE ? "proj_mlp_fused" : "mlp_fused") + eng + std::to_string(C);      // one tag per kernel instance
+    if (NP != 6 && !H2) tag += "_np" + std::to_string(NP);
     if (by_shape) tag += "_M" + std::to_string(p.M);
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
     XpProfScope prof(tag.c_str(), s, MODE == 2 ? 2.0 * p.M * C * (double)p.Nout : 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
                      MODE == 2 ? 4.0 * p.M * (C + (double)p.Nout) + 6.0 * C * (double)p.Nout : (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP, H2>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
 
 template <int C, int NW, int MODE>
 int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
+    // split-fp16 instances (scales present).  C = 192: one 8-wave workgroup per CU (its three 32 KB image slots leave no room for a
+    // second one) puts two waves on every SIMD; the narrower ones run two 4-wave workgroups per CU.
+    static const bool nw4 = getenv("XP_MLP_H2_NW4") != nullptr && atoi(getenv("XP_MLP_H2_NW4")) != 0;      // A/B: 0.716 (8 waves) vs 0.747 ms (4 waves) per two launches
+    if (p.s2 || (MODE == 2 && p.s0)) {
+        if (C == 192 && !nw4) return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(p, s);
+        return launch_mlp_np<C, 4, MODE, 3, true>(p, s);
+    }
     switch (xp_dense_products_value()) {      // precision class of the dense kernels (xp_set_dense_products)
         case 1: return launch_mlp_np<C, 4, MODE, 1>(p, s);
         case 3: return launch_mlp_np<C, 4, MODE, 3>(p, s);
@@ -466,8 +554,38 @@ int launch_mlp(const MlpParams& p, hipStream_t s) {
     return p.T1 ? launch_mlp_pre<C, NW, 1>(p, s) : launch_mlp_pre<C, NW, 0>(p, s);
 }
 
-template <int C>
-size_t pack_bytes(int H4, int with_proj) { return (size_t)(2 * (H4 / 32) + (with_proj ? MlpTile<C>::NT : 0)) * MlpTile<C>::IMGP; }
+template <int C, bool H2 = false>
+size_t pack_bytes(int H4, int with_proj) { return (size_t)(2 * (H4 / 32) + (with_proj ? MlpTile<C, H2>::NT : 0)) * MlpTile<C, H2>::IMGP; }
+
+template <bool H2>
+int pack_launch(const void* W1, const void* W2, const void* W0, void* out, int C, int H4, int n0, size_t bytes, hipStream_t s) {
+    const int64_t units = (int64_t)(bytes / 16);
+    const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
+    const uint4 *w1 = (const uint4*)W1, *w2 = (const uint4*)W2, *w0 = (const uint4*)W0;
+    if (C == 32) hipLaunchKernelGGL((mlp_pack_kernel<32, H2>), grid, block, 0, s, w1, w2, w0, (uint4*)out, H4, n0);
+    else if (C == 64) hipLaunchKernelGGL((mlp_pack_kernel<64, H2>), grid, block, 0, s, w1, w2, w0, (uint4*)out, H4, n0);
+    else if (C == 96) hipLaunchKernelGGL((mlp_pack_kernel<96, H2>), grid, block, 0, s, w1, w2, w0, (uint4*)out, H4, n0);
+    else if (C == 128) hipLaunchKernelGGL((mlp_pack_kernel<128, H2>), grid, block, 0, s, w1, w2, w0, (uint4*)out, H4, n0);
+    else hipLaunchKernelGGL((mlp_pack_kernel<192, H2>), grid, block, 0, s, w1, w2, w0, (uint4*)out, H4, n0);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+// the N inverse row scales behind the planes of an xp_split_weights_h2 buffer (gemm_h2.hip)
+const float* h2_scales_of(const void* Wh2, int N, int K) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(Wh2) + (size_t)N * ((K + H2_BK - 1) / H2_BK) * H2_SLAB_UNITS * 16);
+}
+
+int run_mlp(const MlpParams& p, int C, hipStream_t s) {
+    static const bool nw8 = getenv("XP_MLP_NW8") != nullptr && atoi(getenv("XP_MLP_NW8")) != 0;     // tuning experiment
+    switch (C) {
+        case 32: return nw8 ? launch_mlp<32, 8>(p, s) : launch_mlp<32, 4>(p, s);
+        case 64: return nw8 ? launch_mlp<64, 8>(p, s) : launch_mlp<64, 4>(p, s);
+        case 96: return nw8 ? launch_mlp<96, 8>(p, s) : launch_mlp<96, 4>(p, s);
+        case 128: return launch_mlp<128, 4>(p, s);
+        default: return launch_mlp<192, 4>(p, s);
+    }
+}
 
 }  // namespace
 
@@ -485,16 +603,7 @@ extern "C" int xp_mlp_fused_x3_pack(const void* W1x3, const void* W2x3, const vo
     XP_CHECK_ARG(W1x3 && W2x3 && out, "xp_mlp_fused_x3_pack: null pointer");
     XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_x3_pack: unsupported shape C = %d, hidden = %d", C, H4);
     XP_CHECK_ARG((((uintptr_t)W1x3 | (uintptr_t)W2x3 | (uintptr_t)W0x3 | (uintptr_t)out) & 15) == 0, "xp_mlp_fused_x3_pack: pointers must be 16-byte aligned");
-    const int64_t units = (int64_t)(xp_mlp_fused_x3_pack_bytes(C, H4, W0x3 != nullptr) / 16);
-    const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
-    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
-    else if (C == 96) hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
-    else if (C == 128) hipLaunchKernelGGL(mlp_pack_kernel<128>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
-    else hipLaunchKernelGGL(mlp_pack_kernel<192>, grid, block, 0, s, (const uint4*)W1x3, (const uint4*)W2x3, (const uint4*)W0x3, (uint4*)out, H4, C);
-    XP_LAUNCH_CHECK();
-    return XP_OK;
+    return pack_launch<false>(W1x3, W2x3, W0x3, out, C, H4, C, xp_mlp_fused_x3_pack_bytes(C, H4, W0x3 != nullptr), (hipStream_t)stream);
 }
 
 extern "C" int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const float* b1,
@@ -505,16 +614,8 @@ extern "C" int xp_mlp_fused_x3(float* X, const float* T1, const float* ln_w, con
     XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)T1 | (uintptr_t)Wpack | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
                  "xp_mlp_fused_x3: pointers must be 16-byte aligned");
     XP_CHECK_ARG(T1 != X, "xp_mlp_fused_x3: T1 must not alias X");
-    MlpParams p{X, T1, nullptr, 0, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps};
-    hipStream_t s = (hipStream_t)stream;
-    static const bool nw8 = getenv("XP_MLP_NW8") != nullptr && atoi(getenv("XP_MLP_NW8")) != 0;     // tuning experiment
-    switch (C) {
-        case 32: return nw8 ? launch_mlp<32, 8>(p, s) : launch_mlp<32, 4>(p, s);
-        case 64: return nw8 ? launch_mlp<64, 8>(p, s) : launch_mlp<64, 4>(p, s);
-        case 96: return nw8 ? launch_mlp<96, 8>(p, s) : launch_mlp<96, 4>(p, s);
-        case 128: return launch_mlp<128, 4>(p, s);
-        default: return launch_mlp<192, 4>(p, s);
-    }
+    MlpParams p{X, T1, nullptr, 0, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps, nullptr, nullptr, nullptr};
+    return run_mlp(p, C, (hipStream_t)stream);
 }
 
 extern "C" size_t xp_ln_proj_x3_pack_bytes(int C, int N) {
@@ -526,17 +627,7 @@ extern "C" int xp_ln_proj_x3_pack(const void* W0x3, void* out, int C, int N, voi
     XP_CHECK_ARG(W0x3 && out, "xp_ln_proj_x3_pack: null pointer");
     XP_CHECK_ARG(xp_ln_proj_x3_pack_bytes(C, N) != 0, "xp_ln_proj_x3_pack: unsupported shape C = %d, N = %d (C in {32, 64, 96, 128, 192}, N %% 32 == 0)", C, N);
     XP_CHECK_ARG((((uintptr_t)W0x3 | (uintptr_t)out) & 15) == 0, "xp_ln_proj_x3_pack: pointers must be 16-byte aligned");
-    const int64_t units = (int64_t)(xp_ln_proj_x3_pack_bytes(C, N) / 16);
-    const dim3 grid((unsigned)xp_cdiv(units, (int64_t)256)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const uint4* w0 = (const uint4*)W0x3;
-    if (C == 32) hipLaunchKernelGGL(mlp_pack_kernel<32>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
-    else if (C == 64) hipLaunchKernelGGL(mlp_pack_kernel<64>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
-    else if (C == 96) hipLaunchKernelGGL(mlp_pack_kernel<96>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
-    else if (C == 128) hipLaunchKernelGGL(mlp_pack_kernel<128>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
-    else hipLaunchKernelGGL(mlp_pack_kernel<192>, grid, block, 0, s, w0, w0, w0, (uint4*)out, 0, N);
-    XP_LAUNCH_CHECK();
-    return XP_OK;
+    return pack_launch<false>(W0x3, W0x3, W0x3, out, C, 0, N, xp_ln_proj_x3_pack_bytes(C, N), (hipStream_t)stream);
 }
 
 extern "C" int xp_ln_proj_x3(const float* X, const float* ln_w, const float* ln_b, const void* Wpack, float* Out, int M, int C, int N,
@@ -546,13 +637,62 @@ extern "C" int xp_ln_proj_x3(const float* X, const float* ln_w, const float* ln_
     XP_CHECK_ARG(xp_ln_proj_x3_pack_bytes(C, N) != 0, "xp_ln_proj_x3: unsupported shape C = %d, N = %d (C in {32, 64, 96, 128, 192}, N %% 32 == 0)", C, N);
     XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)Out | (uintptr_t)Wpack | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0, "xp_ln_proj_x3: pointers must be 16-byte aligned");
     XP_CHECK_ARG((const float*)Out != X, "xp_ln_proj_x3: Out must not alias X");
-    MlpParams p{const_cast<float*>(X), nullptr, Out, N, ln_w, ln_b, (const unsigned char*)Wpack, nullptr, nullptr, M, 64, eps};
-    hipStream_t s = (hipStream_t)stream;
-    switch (C) {
-        case 32: return launch_mlp<32, 4>(p, s);
-        case 64: return launch_mlp<64, 4>(p, s);
-        case 96: return launch_mlp<96, 4>(p, s);
-        case 128: return launch_mlp<128, 4>(p, s);
-        default: return launch_mlp<192, 4>(p, s);
-    }
+    MlpParams p{const_cast<float*>(X), nullptr, Out, N, ln_w, ln_b, (const unsigned char*)Wpack, nullptr, nullptr, M, 64, eps, nullptr, nullptr, nullptr};
+    return run_mlp(p, C, (hipStream_t)stream);
+}
+
+// ---- split-fp16 ("h2") instances: the same kernels on two fp16 planes and three products (gemm_h2_core.h); the weight streams are
+// packed from xp_split_weights_h2 buffers, whose row scales the kernels undo (fc1: before the GELU; fc2 / projections: at the end)
+extern "C" size_t xp_mlp_fused_h2_pack_bytes(int C, int H4, int with_proj) {
+    if (!xp_mlp_fused_x3_supported(C, H4)) return 0;
+    const int w = with_proj;
+    return C == 32 ? pack_bytes<32, true>(H4, w) : C == 64 ? pack_bytes<64, true>(H4, w) : C == 96 ? pack_bytes<96, true>(H4, w)
+         : C == 128 ? pack_bytes<128, true>(H4, w) : pack_bytes<192, true>(H4, w);
+}
+
+extern "C" int xp_mlp_fused_h2_pack(const void* W1h2, const void* W2h2, const void* W0h2, void* out, int C, int H4, void* stream) {
+    XP_CHECK_ARG(W1h2 && W2h2 && out, "xp_mlp_fused_h2_pack: null pointer");
+    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_h2_pack: unsupported shape C = %d, hidden = %d", C, H4);
+    XP_CHECK_ARG((((uintptr_t)W1h2 | (uintptr_t)W2h2 | (uintptr_t)W0h2 | (uintptr_t)out) & 15) == 0, "xp_mlp_fused_h2_pack: pointers must be 16-byte aligned");
+    return pack_launch<true>(W1h2, W2h2, W0h2, out, C, H4, C, xp_mlp_fused_h2_pack_bytes(C, H4, W0h2 != nullptr), (hipStream_t)stream);
+}
+
+// W1h2 (hidden, C), W2h2 (C, hidden), W0h2 (C, C) or NULL: the xp_split_weights_h2 buffers the stream was packed from (their row scales
+// are read here); T1 != NULL iff the stream was packed with W0h2.
+extern "C" int xp_mlp_fused_h2(float* X, const float* T1, const float* ln_w, const float* ln_b, const void* Wpack, const void* W1h2,
+                               const void* W2h2, const void* W0h2, const float* b1, const float* b2, int M, int C, int H4, float eps, void* stream) {
+    XP_CHECK_ARG(X && ln_w && ln_b && Wpack && W1h2 && W2h2 && b1 && b2, "xp_mlp_fused_h2: null pointer");
+    XP_CHECK_ARG((T1 != nullptr) == (W0h2 != nullptr), "xp_mlp_fused_h2: T1 and W0h2 go together");
+    XP_CHECK_ARG(M > 0, "xp_mlp_fused_h2: bad M %d", M);
+    XP_CHECK_ARG(xp_mlp_fused_x3_supported(C, H4), "xp_mlp_fused_h2: unsupported shape C = %d, hidden = %d", C, H4);
+    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)T1 | (uintptr_t)Wpack | (uintptr_t)b1 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0,
+                 "xp_mlp_fused_h2: pointers must be 16-byte aligned");
+    XP_CHECK_ARG(T1 != X, "xp_mlp_fused_h2: T1 must not alias X");
+    MlpParams p{X, T1, nullptr, 0, ln_w, ln_b, (const unsigned char*)Wpack, b1, b2, M, H4, eps,
+                W0h2 ? h2_scales_of(W0h2, C, C) : nullptr, h2_scales_of(W1h2, H4, C), h2_scales_of(W2h2, C, H4)};
+    return run_mlp(p, C, (hipStream_t)stream);
+}
+
+extern "C" size_t xp_ln_proj_h2_pack_bytes(int C, int N) {
+    if (!xp_mlp_fused_x3_supported(C, 64) || N <= 0 || N % 32) return 0;
+    return xp_mlp_fused_h2_pack_bytes(C, 64, 0) / 4 * (size_t)(N / 32);
+}
+
+extern "C" int xp_ln_proj_h2_pack(const void* W0h2, void* out, int C, int N, void* stream) {
+    XP_CHECK_ARG(W0h2 && out, "xp_ln_proj_h2_pack: null pointer");
+    XP_CHECK_ARG(xp_ln_proj_h2_pack_bytes(C, N) != 0, "xp_ln_proj_h2_pack: unsupported shape C = %d, N = %d", C, N);
+    XP_CHECK_ARG((((uintptr_t)W0h2 | (uintptr_t)out) & 15) == 0, "xp_ln_proj_h2_pack: pointers must be 16-byte aligned");
+    return pack_launch<true>(W0h2, W0h2, W0h2, out, C, 0, N, xp_ln_proj_h2_pack_bytes(C, N), (hipStream_t)stream);
+}
+
+extern "C" int xp_ln_proj_h2(const float* X, const float* ln_w, const float* ln_b, const void* Wpack, const void* W0h2, float* Out, int M, int C,
+                             int N, float eps, void* stream) {
+    XP_CHECK_ARG(X && ln_w && ln_b && Wpack && W0h2 && Out, "xp_ln_proj_h2: null pointer");
+    XP_CHECK_ARG(M > 0, "xp_ln_proj_h2: bad M %d", M);
+    XP_CHECK_ARG(xp_ln_proj_h2_pack_bytes(C, N) != 0, "xp_ln_proj_h2: unsupported shape C = %d, N = %d", C, N);
+    XP_CHECK_ARG((((uintptr_t)X | (uintptr_t)Out | (uintptr_t)Wpack | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0, "xp_ln_proj_h2: pointers must be 16-byte aligned");
+    XP_CHECK_ARG((const float*)Out != X, "xp_ln_proj_h2: Out must not alias X");
+    MlpParams p{const_cast<float*>(X), nullptr, Out, N, ln_w, ln_b, (const unsigned char*)Wpack, nullptr, nullptr, M, 64, eps,
+                h2_scales_of(W0h2, N, C), nullptr, nullptr};
+    return run_mlp(p, C, (hipStream_t)stream);
 }

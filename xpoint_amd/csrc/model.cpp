@@ -15,7 +15,7 @@ namespace {
 
 struct Param { std::string name; size_t offset; size_t numel; };
 struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset, h2_offset; };   // a GEMM weight and its split-bf16 / split-fp16 copies
-struct MlpPack { std::string block; int C, H4; size_t byte_offset, in_offset; };          // weight streams of one VSS block's fused tail (out_proj + MLP) and head (in_proj)
+struct MlpPack { std::string block; int C, H4; size_t byte_offset, in_offset, h2_offset, h2_in_offset; };   // weight streams of one VSS block's fused tail (out_proj + MLP) and head (in_proj), x3 and h2 forms
 
 struct Ctx {
     xp_model_cfg cfg;
@@ -59,6 +59,10 @@ struct Ctx {
         for (auto& p : packs) if (p.block == block) return p.in_offset;
         return (size_t)-1;
     }
+    size_t h2_pack_off(const std::string& block, bool in) const {      // offsets inside the whole buffer
+        for (auto& p : packs) if (p.block == block) return split_bytes + (in ? p.h2_in_offset : p.h2_offset);
+        return (size_t)-1;
+    }
 };
 
 int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1
@@ -88,10 +92,14 @@ void build_layout(Ctx& c) {
             c.add_gemm(b + "fc1_w", (int)H4, (int)C); c.add(b + "fc1_b", H4);
             c.add_gemm(b + "fc2_w", (int)C, (int)H4); c.add(b + "fc2_b", C);
             if (xp_mlp_fused_x3_supported((int)C, (int)H4)) {      // the wide stages run the MLP as one launch (csrc/mlp_fused.hip)
-                c.packs.push_back({b, (int)C, (int)H4, c.split_bytes, 0});
+                c.packs.push_back({b, (int)C, (int)H4, c.split_bytes, 0, 0, 0});
                 c.split_bytes += (xp_mlp_fused_x3_pack_bytes((int)C, (int)H4, 1) + 255) / 256 * 256;
                 c.packs.back().in_offset = c.split_bytes;
                 c.split_bytes += (xp_ln_proj_x3_pack_bytes((int)C, (int)C) + 255) / 256 * 256;
+                c.packs.back().h2_offset = c.h2_bytes;
+                c.h2_bytes += (xp_mlp_fused_h2_pack_bytes((int)C, (int)H4, 1) + 255) / 256 * 256;
+                c.packs.back().h2_in_offset = c.h2_bytes;
+                c.h2_bytes += (xp_ln_proj_h2_pack_bytes((int)C, (int)C) + 255) / 256 * 256;
             }
         }
         if (s < c.nstages - 1) {
@@ -219,6 +227,12 @@ extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* w
                                  (char*)wsplit + c->split_off(e.block + "out_w"), (char*)wsplit + e.byte_offset, e.C, e.H4, stream));
     for (auto& e : c->packs)
         RUN(xp_ln_proj_x3_pack((char*)wsplit + c->split_off(e.block + "in_w"), (char*)wsplit + e.in_offset, e.C, e.C, stream));
+    for (auto& e : c->packs) {
+        char* w = (char*)wsplit;
+        RUN(xp_mlp_fused_h2_pack(w + c->h2_off(e.block + "fc1_w"), w + c->h2_off(e.block + "fc2_w"), w + c->h2_off(e.block + "out_w"),
+                                 w + c->split_bytes + e.h2_offset, e.C, e.H4, stream));
+        RUN(xp_ln_proj_h2_pack(w + c->h2_off(e.block + "in_w"), w + c->split_bytes + e.h2_in_offset, e.C, e.C, stream));
+    }
     return XP_OK;
 }
 
@@ -256,6 +270,7 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     // split-bf16 back end only; XP_NO_FUSED_MLP=1 keeps the three-launch form (A/B timing, tests)
     static const bool no_fused_mlp = getenv("XP_NO_FUSED_MLP") != nullptr && atoi(getenv("XP_NO_FUSED_MLP")) != 0;
     const bool fuse_mlp = wsplit != nullptr && !no_fused_mlp;
+    static const bool fused_x3 = getenv("XP_FUSED_X3") != nullptr && atoi(getenv("XP_FUSED_X3")) != 0;     // A/B: fused block kernels on the x3 planes under the h2 engine
 
     // patch embed (VMamba.py:1405-1420)
     RUN(xp_stem_conv_ln_gelu(images, P("stem.w"), P("stem.b"), P("stem.ln_w"), P("stem.ln_b"), HB, batch, H, W, E / 2, eps, stream));
@@ -270,7 +285,9 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
             if (fuse_mlp && c->pack_off(b) != (size_t)-1) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
-                RUN(xp_ln_proj_x3(X, P(b + "ln1_w"), P(b + "ln1_b"), (const char*)wsplit + c->in_pack_off(b), T2, M, C, C, eps, stream));
+                const char* w = (const char*)wsplit;
+                if (h2 && !fused_x3) RUN(xp_ln_proj_h2(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->h2_pack_off(b, true), w + c->h2_off(b + "in_w"), T2, M, C, C, eps, stream));
+                else RUN(xp_ln_proj_x3(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->in_pack_off(b), T2, M, C, C, eps, stream));
             } else {
                 RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
                 RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
@@ -282,8 +299,10 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
             if (fuse_mlp && c->pack_off(b) != (size_t)-1) {
                 // out_proj + first residual + LN + MLP + second residual in one launch; the (M, 4C) hidden activation stays in
                 // registers (csrc/mlp_fused.hip)
-                RUN(xp_mlp_fused_x3(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), (const char*)wsplit + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"),
-                                    M, C, H4, eps, stream));
+                const char* w = (const char*)wsplit;
+                if (h2 && !fused_x3) RUN(xp_mlp_fused_h2(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), w + c->h2_pack_off(b, false), w + c->h2_off(b + "fc1_w"), w + c->h2_off(b + "fc2_w"),
+                                                         w + c->h2_off(b + "out_w"), P(b + "fc1_b"), P(b + "fc2_b"), M, C, H4, eps, stream));
+                else RUN(xp_mlp_fused_x3(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), w + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"), M, C, H4, eps, stream));
                 continue;
             }
             RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));

@@ -142,6 +142,12 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
     }
 }
 
+// Counter housekeeping as kernels, not hipMemsetAsync / hipMemcpyAsync: replayed from several hipGraphs on several streams
+// (PairPipeline.capture with overlap) the API memset / copy nodes left the counters holding stale bytes on ROCm 7.2, kernel
+// nodes do not.
+__global__ void nms_reset_counters_kernel(int* __restrict__ counters) { if (threadIdx.x < NMS_MAX_SWEEPS) counters[threadIdx.x] = 0; }
+__global__ void nms_publish_counter_kernel(int* __restrict__ counters, int from) { if (threadIdx.x == 0) counters[NMS_MAX_SWEEPS - 1] = counters[from]; }
+
 // keep_top_k: rank of every survivor among the survivors of its image under (score desc, index asc);
 // survivors with rank >= k are zeroed (utils.py:179-186: first k of the score-sorted survivors).
 // Two launches: every rank is computed before any score is zeroed.
@@ -351,7 +357,7 @@ static int box_nms_enqueue(const float* prob, float* out, void* workspace, int b
                            float min_prob, int sweeps, bool first_round, hipStream_t s) {
     const NmsWs w = nms_ws(workspace, batch, H, W);
     XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
-    XP_HIP(hipMemsetAsync(w.counters, 0, sizeof(int) * NMS_MAX_SWEEPS, s));
+    hipLaunchKernelGGL(nms_reset_counters_kernel, dim3(1), dim3(64), 0, s, w.counters);
     dim3 grid(xp_cdiv(W, NMS_TILE), xp_cdiv(H, NMS_TILE), batch);
     // Local fixed-point iterations per sweep.  Early sweeps are dominated by decisions that wait on a neighbouring tile, so
     // iterating long inside a tile is wasted there (measured: 8 iterations in sweep 0 cost 256 us, 2 cost 128 us, and the
@@ -395,7 +401,7 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
         int rc = box_nms_enqueue(prob, out, workspace, batch, H, W, tab, min_prob, max_sweeps_async, true, s);
         if (rc) return rc;
         if (max_sweeps_async != NMS_MAX_SWEEPS)
-            XP_HIP(hipMemcpyAsync(w.counters + NMS_MAX_SWEEPS - 1, w.counters + max_sweeps_async - 1, sizeof(int), hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(nms_publish_counter_kernel, dim3(1), dim3(64), 0, s, w.counters, max_sweeps_async - 1);
     } else {
         bool first = true;
         const int per_round = 4;
