@@ -122,6 +122,88 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h2_kernel(GemmParams p) {
     gemm_epilogue<T, TM, TN>(p, m0, n0, acc);
 }
 
+// Row-stationary variant (GemmTileH2R): A fragments straight from global memory, only the weights in LDS.  K % 8 == 0 (conv: Ci % 8 == 0).
+template <int TN, int MODE>
+__global__ __launch_bounds__(256) void gemm_h2r_kernel(GemmParams p) {
+    using T = GemmTileH2R<TN>;
+    extern __shared__ __align__(16) unsigned char lds_h2[];
+    const int ntn = (p.N + T::BN - 1) / T::BN;
+    const int total = gridDim.x;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int m0 = (logical / ntn) * T::BM, n0 = (logical % ntn) * T::BN;
+    const int fh = (threadIdx.x & 63) >> 5;
+
+    const int m = m0 + T::a_row();
+    const int mc = m < p.M ? m : 0;              // rows past M only feed output rows that are never stored
+    const float* a_ptr;
+    int a_oh = 0, a_ow = 0, a_tap[2] = {0, 0}, a_ci[2] = {0, 0};
+    if (MODE == 0) a_ptr = p.A + (int64_t)mc * p.lda;
+    else {
+        const int hw = p.Ho * p.Wo;
+        const int b = mc / hw, rr = mc - b * hw;
+        a_oh = (rr / p.Wo) * p.stride - 1; a_ow = (rr % p.Wo) * p.stride - 1;
+        a_ptr = p.A + (int64_t)b * p.Hi * p.Wi * p.Ci;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int k = s * 16 + fh * 8; a_tap[s] = k / p.Ci; a_ci[s] = k - a_tap[s] * p.Ci; }
+    }
+    const int nslab = (p.K + H2_BK - 1) / H2_BK;
+    const uint4* w_unit[T::B_LD];
+#pragma unroll
+    for (int s = 0; s < T::B_LD; ++s) {
+        const int n = n0 + T::b_row(s);
+        w_unit[s] = reinterpret_cast<const uint4*>(p.Wt) + (int64_t)(n < p.N ? n : 0) * H2_SLAB_UNITS + T::b_unit(s);
+    }
+    const int64_t w_slab = (int64_t)p.N * H2_SLAB_UNITS;
+    int which = 0;         // the engine asks for k-step 0, then k-step 1 of every slab, slabs in order
+    auto ldA8 = [&](int k, float4& lo, float4& hi) -> bool {
+        bool ok = k < p.K;
+        const float* src;
+        if (MODE == 0) {
+            src = a_ptr + (ok ? k : p.K - 8);
+        } else {
+            const int s = which; which ^= 1;
+            int tap = a_tap[s], ci = a_ci[s];
+            if (!ok) { tap = 8; ci = p.Ci - 8; }
+            a_ci[s] += H2_BK;                              // Ci >= 8: at most four wraps per 32-wide slab, as selects
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const bool wrap = a_ci[s] >= p.Ci; a_ci[s] -= wrap ? p.Ci : 0; a_tap[s] += wrap ? 1 : 0; }
+            int ih = a_oh + tap / 3, iw = a_ow + tap % 3;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : (ih >= p.Hi ? 2 * p.Hi - 2 - ih : ih);
+                iw = iw < 0 ? -iw : (iw >= p.Wi ? 2 * p.Wi - 2 - iw : iw);
+            } else {
+                ok = ok && ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi;
+                ih = ih < 0 ? 0 : (ih >= p.Hi ? p.Hi - 1 : ih);
+                iw = iw < 0 ? 0 : (iw >= p.Wi ? p.Wi - 1 : iw);
+            }
+            src = a_ptr + ((int64_t)ih * p.Wi + iw) * p.Ci + ci;
+        }
+        lo = *reinterpret_cast<const float4*>(src);
+        hi = *reinterpret_cast<const float4*>(src + 4);
+        return ok;
+    };
+    auto ldB = [&](int s, int t) -> uint4 { return w_unit[s][(t < nslab ? t : nslab - 1) * w_slab]; };
+
+    f32x16 acc[1][TN];
+    T::run(lds_h2, p.K, ldA8, ldB, acc);
+    gemm_epilogue<T, 1, TN>(p, m0, n0, acc);
+}
+
+template <int TN>
+void launch_r(const GemmParams& p, hipStream_t s) {
+    using T = GemmTileH2R<TN>;
+    dim3 grid(xp_cdiv(p.N, T::BN) * xp_cdiv(p.M, T::BM));
+    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
+    std::string tag = std::string(p.mode ? "conv3x3_h2r_mfma_" : "gemm_h2r_mfma_") + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    if (by_shape) tag += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
+    const double in_elems = p.mode == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci;
+    XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K, 4.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
+    if (p.mode == 0) hipLaunchKernelGGL((gemm_h2r_kernel<TN, 0>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+    else hipLaunchKernelGGL((gemm_h2r_kernel<TN, 1>), grid, dim3(T::NT), T::kLdsBytes, s, p);
+}
+
 template <int WM, int WN, int TM, int TN>
 void launch(const GemmParams& p, hipStream_t s) {
     using T = GemmTileH2<WM, WN, TM, TN>;
@@ -148,6 +230,22 @@ int dispatch(const GemmParams& p, hipStream_t s) {
     const int sel = force >= 0 ? force
                   : N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2
                   : (p.M <= 8192 && N >= 512 && (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 512) ? 3 : 4;
+    // Row-stationary engine for the implicit-GEMM convolutions (measured: 0.55 vs 0.71 ms for the four big convs of a step; the gathered
+    // A rows cost the tile engine an LDS round trip they do not need), the tile engine for plain GEMMs (equal at K >= 384, 15 % faster at
+    // K = 96 where the row-stationary lane-per-row loads touch 32 cache lines per instruction).  XP_H2_ENGINE = rs | lds forces one (A/B).
+    static const char* eng = getenv("XP_H2_ENGINE");
+    const bool want_rs = eng ? (eng[0] == 'r') : p.mode == 1;
+    const bool rs_ok = want_rs && p.K % 8 == 0 && (p.mode == 0 ? p.lda % 4 == 0 : p.Ci % 8 == 0) && sel != 3;
+    if (rs_ok) {
+        switch (sel) {
+            case 0: launch_r<1>(p, s); break;
+            case 1: launch_r<2>(p, s); break;
+            case 2: launch_r<3>(p, s); break;
+            default: launch_r<4>(p, s); break;
+        }
+        XP_LAUNCH_CHECK();
+        return XP_OK;
+    }
     switch (sel) {
         case 0: launch<4, 1, 1, 1>(p, s); break;       // 128 x 32
         case 1: launch<4, 1, 1, 2>(p, s); break;       // 128 x 64

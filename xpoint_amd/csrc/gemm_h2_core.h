@@ -188,3 +188,116 @@ struct GemmTileH2 {
         return ((wave % WN) * TN + j) * 32 + (lane & 31);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-stationary variant: the A operand never touches LDS.  In the tile engine above the LDS pipe is the busiest unit of the CU
+// (per 32-wide slab and CU: 64 KB of A/B staging stores + 128 KB of fragment reads against 1536 matrix-pipe cycles: ~85 % busy).
+// Here a workgroup is 4 waves x 32 rows (BM = 128), every wave owns ALL TN * 32 columns of its rows, so no other wave needs its A
+// rows: each lane loads the 8 consecutive f32 of its row that make up its MFMA fragment (lane l: row l & 31, k = 8 (l >> 5) .. + 7)
+// straight from global memory, splits them in registers and feeds the MFMAs from there.  Only the weights go through LDS
+// (straight 16-byte copies of the offline layout, shared by the four waves): LDS traffic per slab and CU drops to a third.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TN>
+struct GemmTileH2R {
+    static constexpr int BK = H2_BK;
+    static constexpr bool kRowScale = true;
+    static constexpr int BM = 128, BN = TN * 32, NT = 256;
+    static constexpr int B_TOT = BN * H2_SLAB_UNITS;
+    static constexpr int B_LD = (B_TOT + NT - 1) / NT;       // = TN
+    static constexpr int kBufBytes = BN * H2_ROWB;
+    static constexpr size_t kLdsBytes = 2 * (size_t)kBufBytes;
+    __device__ static __forceinline__ int b_id(int s) { const int id = (int)threadIdx.x + s * NT; return (s + 1) * NT <= B_TOT ? id : (id < B_TOT ? id : B_TOT - 1); }
+    __device__ static __forceinline__ int b_row(int s) { return b_id(s) / H2_SLAB_UNITS; }
+    __device__ static __forceinline__ int b_unit(int s) { return b_id(s) % H2_SLAB_UNITS; }
+    __device__ static __forceinline__ int a_row() { return (int)(threadIdx.x >> 6) * 32 + (int)(threadIdx.x & 31); }   // this lane's tile row
+
+    struct RawA { float4 lo[2], hi[2]; bool ok[2]; };     // the lane's 2 x 8 floats of one slab (k-steps 0 and 1)
+    struct PlanesA { unsigned p[2][2][4]; };              // [k-step][plane] as MFMA operand bits
+    struct RawB { uint4 b[B_LD]; };
+
+    // ldA8(k, lo, hi) -> ok: the 8 consecutive f32 of THIS LANE's row starting at absolute k (a multiple of 8), loaded unconditionally
+    //                        from a valid address; ok = real (else they count as zeros).  Called twice per slab, in k order.
+    // ldB(slot, slab)      : as in GemmTileH2.
+    template <class LA, class LB>
+    __device__ static __forceinline__ void run(unsigned char* lds, int K, LA ldA8, LB ldB, f32x16 (&acc)[1][TN]) {
+        const int lane = threadIdx.x & 63;
+        const int fr = lane & 31, fh = lane >> 5;
+        auto gloadA = [&](RawA& r, int t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) r.ok[s] = ldA8(t * H2_BK + s * 16 + fh * 8, r.lo[s], r.hi[s]);
+        };
+        auto gloadB = [&](RawB& r, int t) {
+#pragma unroll
+            for (int s = 0; s < B_LD; ++s) r.b[s] = ldB(s, t);
+        };
+        auto split = [&](const RawA& r, PlanesA& o) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned m = r.ok[s] ? 0xffffffffu : 0u;
+                auto mk = [&](float v) { return __uint_as_float(__float_as_uint(v) & m); };
+                uint2 a0, a1, b0, b1;
+                h2_split4(make_float4(mk(r.lo[s].x), mk(r.lo[s].y), mk(r.lo[s].z), mk(r.lo[s].w)), a0, a1);
+                h2_split4(make_float4(mk(r.hi[s].x), mk(r.hi[s].y), mk(r.hi[s].z), mk(r.hi[s].w)), b0, b1);
+                o.p[s][0][0] = a0.x; o.p[s][0][1] = a0.y; o.p[s][0][2] = b0.x; o.p[s][0][3] = b0.y;
+                o.p[s][1][0] = a1.x; o.p[s][1][1] = a1.y; o.p[s][1][2] = b1.x; o.p[s][1][3] = b1.y;
+            }
+        };
+        int b_dst[B_LD];
+#pragma unroll
+        for (int s = 0; s < B_LD; ++s) b_dst[s] = b_row(s) * H2_ROWB + b_unit(s) * 16;
+        auto lstoreB = [&](const RawB& rb, unsigned char* buf) {
+#pragma unroll
+            for (int s = 0; s < B_LD; ++s) *reinterpret_cast<uint4*>(buf + b_dst[s]) = rb.b[s];
+        };
+        const int b_frag = fr * H2_ROWB + 16 * fh;
+        typedef unsigned ubits4 __attribute__((ext_vector_type(4)));
+        auto kstep = [&](const unsigned char* buf, const PlanesA& ap, int ks) {
+            f16x8_t bf[2][TN];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const f16x8_t*>(buf + b_frag + pl * 64 + ks * 32 + j * 32 * H2_ROWB);
+            const f16x8_t a0 = __builtin_bit_cast(f16x8_t, ubits4{ap.p[ks][0][0], ap.p[ks][0][1], ap.p[ks][0][2], ap.p[ks][0][3]});
+            const f16x8_t a1 = __builtin_bit_cast(f16x8_t, ubits4{ap.p[ks][1][0], ap.p[ks][1][1], ap.p[ks][1][2], ap.p[ks][1][3]});
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[0][j], acc[0][j], 0, 0, 0);      // smallest products first
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[1][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[0][j], acc[0][j], 0, 0, 0);
+        };
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+        unsigned char* bufs[2] = {lds, lds + kBufBytes};
+        const int nslab = ((K + H2_BK - 1) / H2_BK + 1) & ~1;       // even; a slab past K adds exact zeros
+        RawA ra[2]; RawB rb; PlanesA ap[2];
+        // slab t: A loaded during slab t-2 into ra[t & 1], split during slab t-1 into ap[t & 1]; B loaded during slab t-2, stored during t-1
+        gloadA(ra[0], 0); gloadB(rb, 0);
+        gloadA(ra[1], 1);
+        split(ra[0], ap[0]);
+        lstoreB(rb, bufs[0]);
+        gloadB(rb, 1); gloadA(ra[0], 2);
+        h2_lds_barrier();
+        auto step = [&](int t, auto u_tag) {
+            constexpr int U = decltype(u_tag)::value;          // t & 1
+            kstep(bufs[U], ap[U], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lstoreB(rb, bufs[U ^ 1]);                           // B slab t+1
+            gloadB(rb, t + 2);
+            kstep(bufs[U], ap[U], 1);
+            split(ra[U ^ 1], ap[U ^ 1]);                        // A slab t+1 (loaded during slab t-1) ...
+            gloadA(ra[U ^ 1], t + 3);                           // ... whose registers then take slab t+3
+            h2_lds_barrier();
+        };
+        for (int t = 0; t < nslab; t += 2) { step(t, std::integral_constant<int, 0>{}); step(t + 1, std::integral_constant<int, 1>{}); }
+    }
+
+    __device__ static __forceinline__ int row_of(int, int r) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        return wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int col_of(int j) { return j * 32 + (int)(threadIdx.x & 31); }
+};
