@@ -1,14 +1,27 @@
 #!/bin/bash
-# Evidence run for profiles/: bench line (with cpu_baseline), rocprofv3 kernel stats and PMC HBM traffic of the same command.
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r1_03
+# Evidence run for profiles/: bench lines (c2 with cpu_baseline, c4, c5), rocprofv3 kernel stats, PMC HBM traffic and MFMA utilisation of the
+# same commands.   usage (on the GPU box, from the repo root): bash tools/profile_round.sh r2_03
 TAG=${1:-rX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/hip_event_breakdown.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d > $OUT/bench_under_rocprof.json 2> /dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d > /dev/null 2>&1
+python3 $R/bench.py --config c4 --steps 30 --no-cpu-baseline > $OUT/c4_bench.json 2> $OUT/c4_hip_event_breakdown.txt
+python3 $R/bench.py --config c5 --steps 30 --no-cpu-baseline > $OUT/c5_bench.json 2> $OUT/c5_hip_event_breakdown.txt
+COMMON="--no-cpu-baseline --no-other-backend --no-overlap --no-h2d"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 $COMMON > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -- python3 $R/bench.py --config c4 --steps 5 --warmup 2 $COMMON > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $R/bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 $COMMON > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 $COMMON > /dev/null 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+cp $(find $OUT/stats4 -name "*kernel_stats.csv" | head -1) $OUT/c4_kernel_stats.csv
+cp $(find $OUT/stats5 -name "*kernel_stats.csv" | head -1) $OUT/c5_kernel_stats.csv
 python3 $R/tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_hbm_traffic.txt
-rm -rf $OUT/stats $OUT/fetch $OUT/write
+rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write
+bash $R/tools/mfma_util.sh > /dev/null 2>&1
+cp $R/gpurun_out/mfma_utilisation.txt $OUT/
+python3 $R/tools/match_bench.py 4060 8192 8 > $OUT/match_microbench.txt 2>&1
+GB_H2=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_h2_microbench.txt 2>&1
+GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1
+python3 $R/tools/scan_bench.py > $OUT/selective_scan_microbench.txt 2>&1
 cat $OUT/bench.json; head -12 $OUT/kernel_stats.csv | cut -c1-200; head -20 $OUT/pmc_hbm_traffic.txt
