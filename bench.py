@@ -126,6 +126,11 @@ def main():
         args.graph = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # stdout carries exactly ONE line, the JSON: keep the real stdout for it and point fd 1 at stderr for everything else (RCCL prints its
+    # version banner to stdout from C code when NCCL_DEBUG asks for it)
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -357,6 +362,7 @@ def main():
             roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
                     "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
+            roof["frac_vs_f32_matrix_peak"] = round(ach / MFMA_F32_PEAK_TFLOPS, 4)      # orientation only: algorithmic flops against the exact-f32 MFMA peak
             if x3:
                 roof["peak_note"] = (f"f32-equivalent: bf16 / fp16 dense MFMA peak {MFMA_BF16_PEAK_TFLOPS:.0f} TFLOP/s / {nprod} partial products per "
                                      f"f32-grade multiply; executed 16-bit MFMA rate = {ach * nprod:.0f} TFLOP/s = {ach * nprod / MFMA_BF16_PEAK_TFLOPS:.3f} of peak")
@@ -456,7 +462,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
             except Exception as e:   # the baseline must never hide the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 
