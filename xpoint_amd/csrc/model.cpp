@@ -270,6 +270,7 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     // split-bf16 back end only; XP_NO_FUSED_MLP=1 keeps the three-launch form (A/B timing, tests)
     static const bool no_fused_mlp = getenv("XP_NO_FUSED_MLP") != nullptr && atoi(getenv("XP_NO_FUSED_MLP")) != 0;
     const bool fuse_mlp = wsplit != nullptr && !no_fused_mlp;
+    static const int fuse_max_c = getenv("XP_FUSE_MAXC") ? atoi(getenv("XP_FUSE_MAXC")) : 1 << 30;      // A/B: blocks wider than this run unfused
     static const bool fused_x3 = getenv("XP_FUSED_X3") != nullptr && atoi(getenv("XP_FUSED_X3")) != 0;     // A/B: fused block kernels on the x3 planes under the h2 engine
 
     // patch embed (VMamba.py:1405-1420)
@@ -284,7 +285,7 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
         for (int j = 0; j < c->cfg.depths[s]; ++j) {
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
-            if (fuse_mlp && c->pack_off(b) != (size_t)-1) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
+            if (fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
                 const char* w = (const char*)wsplit;
                 if (h2 && !fused_x3) RUN(xp_ln_proj_h2(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->h2_pack_off(b, true), w + c->h2_off(b + "in_w"), T2, M, C, C, eps, stream));
                 else RUN(xp_ln_proj_x3(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->in_pack_off(b), T2, M, C, C, eps, stream));
@@ -296,7 +297,7 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
             RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
             RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
                                  T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
-            if (fuse_mlp && c->pack_off(b) != (size_t)-1) {
+            if (fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1) {
                 // out_proj + first residual + LN + MLP + second residual in one launch; the (M, 4C) hidden activation stays in
                 // registers (csrc/mlp_fused.hip)
                 const char* w = (const char*)wsplit;
