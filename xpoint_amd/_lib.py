@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxpoint_hip.so")
+LIB_PATH = os.environ.get("XP_LIB_PATH") or os.path.join(_HERE, "libxpoint_hip.so")      # XP_LIB_PATH: another build of the same library (A/B runs of compiler flags)
 
 _lib = None
 

@@ -22,6 +22,7 @@
 #include <string>
 #include <type_traits>
 
+#include "gemm_h2_core.h"
 #include "xp_common.h"
 
 namespace {
@@ -470,6 +471,164 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan(SS2DParams p, float* __restr
     }
 }
 
+// Sequential form for dt_rank >= 16 (the deep stages), written for INSTRUCTION COUNT: with one wave per SIMD every instruction of any
+// kind — scalar address arithmetic, branches, LDS reads — is issue time, and the first kernel above spends ~3 500 of them per 32-pixel
+// tile (64-bit scalar address chains per access, a branchy scalar walk of the pixel order, R FMAs per step).  Here
+//  * the dt projection of a tile runs on the matrix pipe:  dt[pixel][channel] = bias[channel] + sum_r x[pixel][r] Wdt[channel][r]  as two
+//    32x32 MFMA tiles (64 channels) x ceil(R / 16) slabs, both operands split into two fp16 planes, three products per slab
+//    (gemm_h2_core.h: operand error 2^-24 — f32-grade); the weight fragments stay in registers (as many as the R scalar weights they
+//    replace), the pixel rows are split from the LDS tile.  The accumulator layout (lane = column = channel, 16 registers = rows
+//    {0-3, 8-11, 16-19, 24-27} + 4 (lane >> 5)) becomes "lane = channel, 32 registers = the tile's 32 pixels" with one
+//    v_permlane32_swap per register pair of the two tiles — the scan's own layout;
+//  * a tile's pixel offsets are computed once by 32 lanes (vector arithmetic, one reciprocal multiply for the column-major routes) and
+//    reach the memory instructions as the SCALAR offset of a buffer access (v_readlane + buffer_load / buffer_store: two instructions
+//    per access); pixels past the end get an out-of-range offset, which the buffer hardware turns into a dropped store / a zero load,
+//    so there is one code path for full and partial tiles;
+//  * the tile's xdbl rows are fetched one row per lane pair with immediate offsets (no address arithmetic).
+template <int R>
+__global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __restrict__ ys) {
+    constexpr int RW = R + 2, NP = RW / 2, NPL = (NP + 1) / 2;          // float2 pieces per xdbl row of one route; pieces fetched by one lane
+    constexpr int KS = (R + 15) / 16;
+    static_assert(R % 8 == 0 && R >= 16, "whole 8-value fragment halves");
+    __shared__ __align__(16) float s_x[2][SEQ_TP * RW];
+    const int lane = threadIdx.x, d = blockIdx.y, b = blockIdx.z;
+    const int pair = d >> 1, back = d & 1;                              // directions in the stored order (0, 2, 1, 3)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int L = p.H * p.W, XD = 4 * RW;
+    const int c = blockIdx.x * 64 + lane;                               // C % 64 == 0 (host)
+    f16x8_t bw[2][KS][2];                                               // [channel tile][k slab][plane]
+    float tile_bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cj = blockIdx.x * 64 + 32 * j + fr;
+        tile_bias[j] = XP_L2E * p.dtb[d * p.C + cj];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool inside = ks * 16 + fh * 8 < R;                   // a half slab is inside or outside R as a whole
+            float wv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = p.wdt[((int64_t)d * R + (inside ? ks * 16 + fh * 8 + e : 0)) * p.C + cj];
+                wv[e] = inside ? XP_L2E * t : 0.f;
+            }
+            uint2 a0, a1, b0, b1;
+            h2_split4(make_float4(wv[0], wv[1], wv[2], wv[3]), a0, a1);
+            h2_split4(make_float4(wv[4], wv[5], wv[6], wv[7]), b0, b1);
+            union { uint4 u; f16x8_t h; } hi, lo;
+            hi.u = make_uint4(a0.x, a0.y, b0.x, b0.y); lo.u = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            bw[j][ks][0] = hi.h; bw[j][ks][1] = lo.h;
+        }
+    }
+    const float Av = XP_L2E * p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
+    const int plane_bytes = L * p.C * 4;                                // host: < 2^31
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + (int64_t)b * L * p.C), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(ys + ((int64_t)d * p.Bn + b) * L * p.C), 0, plane_bytes, 0x00020000);
+    const int cbyte = c * 4;
+    const char* xb = reinterpret_cast<const char*>(p.xdbl + (int64_t)b * L * XD + pair * 2 * RW + back * RW) + fh * (NPL * 8);
+    const float invH = 1.f / (float)p.H;
+    // tile t, pixel (lane & 31) of the route's sequence: byte offset of its row in a (L, C) plane (out of range past the end) and of its xdbl row
+    auto tile_offsets = [&](int t, int& off_uy, int& off_x) {
+        const int i = t * SEQ_TP + fr;
+        const int ic = min(i, L - 1);
+        const int l = back ? L - 1 - ic : ic;                           // backward routes walk the flipped sequence (csm_triton.py:33-36)
+        int px = l;
+        if (pair == 1) {                                                // column-major routes: l = w * H + h
+            const int ww = (int)(((float)l + 0.5f) * invH);             // exact: (l + 0.5) / H is at least 0.5 / H away from an integer
+            px = (l - ww * p.H) * p.W + ww;
+        }
+        off_uy = i < L ? px * (p.C * 4) : 0x7fffffff;
+        off_x = px * (XD * 4);
+    };
+    float ucur[SEQ_TP], unext[SEQ_TP];
+    float2 xreg[NPL];
+    int offc, offn, offx;
+    auto load_tile = [&](int off_uy, int off_x, float (&uv)[SEQ_TP]) {
+#pragma unroll
+        for (int j = 0; j < SEQ_TP; ++j)
+            uv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, cbyte, __builtin_amdgcn_readlane(off_uy, j), 0));
+        const char* xr = xb + off_x;
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) {
+            // the upper half-wave fetches pieces NPL .. NP-1; when NP is odd its last slot repeats piece NP-1 (same data, same LDS address)
+            const int pe = (e == NPL - 1 && 2 * NPL > NP) ? (fh ? e - 1 : e) : e;
+            xreg[e] = *reinterpret_cast<const float2*>(xr + pe * 8);
+        }
+    };
+    const int xdst = fr * RW + fh * (NPL * 2);
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) {
+            const int pe = (e == NPL - 1 && 2 * NPL > NP) ? (fh ? e - 1 : e) : e;
+            *reinterpret_cast<float2*>(&s_x[buf][xdst + pe * 2]) = xreg[e];
+        }
+    };
+    const int ntile = (L + SEQ_TP - 1) / SEQ_TP;
+    tile_offsets(0, offc, offx);
+    load_tile(offc, offx, ucur);
+    store_x(0);
+    float h = 0.f;
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) { tile_offsets(t + 1, offn, offx); load_tile(offn, offx, unext); }
+        const float* sx = s_x[t & 1];
+        // dt of the tile on the matrix pipe
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = tile_bias[j];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool inside = ks * 16 + fh * 8 < R;                   // the zero-padded half slab of R = 24 reads the row start instead and is cleared
+            const float* ar = sx + fr * RW + (inside ? ks * 16 + fh * 8 : 0);
+            float2 tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tq[q] = *reinterpret_cast<const float2*>(ar + 2 * q); if (!inside) tq[q] = make_float2(0.f, 0.f); }
+            uint2 a0, a1, b0, b1;
+            h2_split4(make_float4(tq[0].x, tq[0].y, tq[1].x, tq[1].y), a0, a1);
+            h2_split4(make_float4(tq[2].x, tq[2].y, tq[3].x, tq[3].y), b0, b1);
+            union { uint4 u; f16x8_t h; } hi, lo;
+            hi.u = make_uint4(a0.x, a0.y, b0.x, b0.y); lo.u = make_uint4(a1.x, a1.y, b1.x, b1.y);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo.h, bw[j][ks][0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi.h, bw[j][ks][1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi.h, bw[j][ks][0], acc[j], 0, 0, 0);
+            }
+        }
+        float dtv[2][16];                                               // dt of pixel j = dtv[(j >> 2) & 1][(j & 3) + 4 * (j >> 3)]
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][e]), __float_as_uint(acc[1][e]), false, false);
+            dtv[0][e] = __uint_as_float(sw[0]); dtv[1][e] = __uint_as_float(sw[1]);
+        }
+        // four steps at a time: their operand evaluation (softplus, exp) is independent and interleaves; only the h update is a chain
+#pragma unroll
+        for (int j0 = 0; j0 < SEQ_TP; j0 += 4) {
+            float a[4], bb[4], cv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float2 bc = *reinterpret_cast<const float2*>(sx + (j0 + k) * RW + R);
+                float delta;
+                xp_softplus_decay_l2_nb(dtv[(j0 >> 2) & 1][k + 4 * (j0 >> 3)], Av, delta, a[k]);
+                bb[k] = delta * bc.x * ucur[j0 + k];
+                cv[k] = bc.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                h = a[k] * h + bb[k];
+                const float y = cv[k] * h + Dv * ucur[j0 + k];          // y = C*h + D*u (csms6s.py:61,67)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), ry, cbyte, __builtin_amdgcn_readlane(offc, j0 + k), 0);
+            }
+        }
+        if (t + 1 < ntile) {
+            store_x((t + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < SEQ_TP; ++j) ucur[j] = unext[j];
+            offc = offn;
+        }
+    }
+}
+
 // out[b][px][:] = LayerNorm_C((y0 + y2) + (y1 + y3)); one wave per pixel, the row held in registers (C <= 768)
 __global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const float* __restrict__ ys) {
     const int lane = threadIdx.x & 63;
@@ -502,6 +661,12 @@ __global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const flo
     }
 }
 
+// ss2d_seq_scan2 serves dt_rank >= 16 (whole 8-value fragment halves) while a plane's byte offsets fit the 32-bit buffer offsets
+bool seq_scan2_applies(int R, int H, int W, int C) {
+    static const bool old_seq = getenv("XP_SS2D_SEQ_V1") && atoi(getenv("XP_SS2D_SEQ_V1")) != 0;      // A/B: first kernel (dt projection on the vector ALU)
+    return !old_seq && R >= 16 && R % 8 == 0 && (int64_t)H * W * C < (1ll << 29) && (int64_t)H * W * 4 * (R + 2) < (1ll << 29);
+}
+
 template <int R>
 int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s) {
     const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * 4 * (R + 2);
@@ -509,7 +674,11 @@ int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s) {
     const std::string sfx = by_shape ? "_C" + std::to_string(p.C) : std::string();
     {   // every route reads u and its quarter of xdbl, writes its y
         XpProfScope prof(("ss2d_seq_scan" + sfx).c_str(), s, 4.0 * MC * (2.0 * R + 14.0), 4.0 * (8.0 * MC + MX));
-        hipLaunchKernelGGL(ss2d_seq_scan<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+        const bool v2 = seq_scan2_applies(R, p.H, p.W, p.C);
+        if constexpr (R >= 16 && R % 8 == 0) {
+            if (v2) hipLaunchKernelGGL(ss2d_seq_scan2<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+        }
+        if (!v2) hipLaunchKernelGGL(ss2d_seq_scan<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
     }
     {
         XpProfScope prof(("ss2d_seq_merge_ln" + sfx).c_str(), s, 12.0 * MC, 4.0 * 5.0 * MC);
@@ -603,11 +772,16 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
     const int64_t nps = (int64_t)batch * 2 * p.nc * 2 * C;
     p.wsP = workspace; p.wsS = workspace + nps; p.ya = workspace + 2 * nps;
     hipStream_t s = (hipStream_t)stream;
-    // deep stages: short sequences and enough (image, route, 64-channel) waves to cover the chip -> the sequential form
-    const int64_t seq_waves = (int64_t)batch * 4 * xp_cdiv(C, 64);
+    // Deep stages -> the sequential form.  The choice uses per-image quantities only (dt_rank, L), never the batch: the two forms differ
+    // by rounding (~1e-7), and a result that changed with the number of images sharing a call would make grouped / split / single-image
+    // runs of the same image disagree.  tools/ss2d_bench.py: C = 768, L = 300: 44 / 46 / 56 / 103 us for 2 / 4 / 16 / 32 images against
+    // 51 / 65 / 169 / 292 us chunked; C = 768, L = 1024, 8 images: 131 vs 248 us; C = 384, L = 1200 is a draw in the timed step
+    // (148 vs 195 us alone at 16 images, 117 vs 47 us at 2) and stays chunked.  XP_SS2D_SEQ_MAXL overrides the L bound of the
+    // matrix-pipe kernel; xp_ss2d_core_set_mode / XP_SS2D_SEQ force one form.
     const int mode = g_ss2d_mode.load();
-    static const int64_t min_waves = getenv("XP_SS2D_SEQ_WAVES") ? atoi(getenv("XP_SS2D_SEQ_WAVES")) : 384;
-    const bool seq = mode >= 0 ? mode != 0 : (L <= 512 && seq_waves >= min_waves);
+    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
+    const bool seq2 = seq_scan2_applies(R, H, W, C);
+    const bool seq = mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512)));
     if (seq && C <= 768 && C % 64 == 0) {
         switch (R) {
             case 2: return launch_ss2d_seq<2>(p, workspace, s);

@@ -117,6 +117,19 @@ __device__ __forceinline__ void xp_softplus_decay_l2(float xl2, float Al2, float
         a = __builtin_amdgcn_exp2f(Al2 * delta);
     }
 }
+// Branch-free form of the same function for kernels that run one wave per SIMD (every instruction is issue time and a divergent
+// branch executes both sides anyway): the logarithm path for every x below the threshold — v_log_f32 plus the Kahan correction keeps
+// ~2e-7 relative down to e -> 0 (see xp_log1p_fast) — and a select for the linear tail.  12 vector instructions, 4 of them
+// transcendental, no scalar control flow.  Differs from xp_softplus_decay_l2 by rounding only (<= ~3e-7 relative in delta).
+__device__ __forceinline__ void xp_softplus_decay_l2_nb(float xl2, float Al2, float& delta, float& a) {
+    const float e = __builtin_amdgcn_exp2f(xl2);
+    const float uu = 1.f + e;
+    const float l2 = __builtin_amdgcn_logf(uu);
+    const float cc = ((uu - 1.f) - e) * __builtin_amdgcn_rcpf(uu);
+    const float dl = l2 * 0.693147180559945309f - cc;
+    delta = xl2 <= 20.f * 1.44269504088896340736f ? dl : xl2 * 0.693147180559945309f;
+    a = __builtin_amdgcn_exp2f(Al2 * delta);
+}
 __device__ __forceinline__ float xp_softplus_fast(float x) { return x <= 20.f ? xp_log1p_fast(xp_exp_fast(x)) : x; }
 __device__ __forceinline__ float xp_silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + xp_exp_fast(-x)); }   // ~3 ulp
 __device__ __forceinline__ float xp_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
