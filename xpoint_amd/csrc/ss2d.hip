@@ -82,6 +82,85 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
     Cv = xv[R + 1];
 }
 
+// ---- dt projection of a 32-pixel tile on the matrix pipe (dt_rank >= 12: the deep stages) ------------------------------------------
+//   dt[pixel][channel] = bias[channel] + sum_r x[pixel][r] Wdt[channel][r]   for the wave's 64 channels: two 32x32 MFMA tiles x ceil(R / 16)
+// slabs, both operands split into two fp16 planes, three products per slab (gemm_h2_core.h: operand error 2^-24 — f32-grade) instead of R
+// FMAs per step and lane.  The weight fragments stay in registers (as many as the R scalar weights they replace), the pixel rows are split
+// from the LDS tile.  The accumulator layout (lane = column = channel, 16 registers = rows {0-3, 8-11, 16-19, 24-27} + 4 (lane >> 5))
+// becomes "lane = channel, 32 registers = the tile's 32 pixels" with one v_permlane32_swap per register pair of the two tiles — the
+// scan's own layout: dt of tile pixel j is dtv[(j >> 2) & 1][(j & 3) + 4 (j >> 3)].
+template <int R>
+struct DtWeights {
+    static constexpr int KS = (R + 15) / 16;
+    f16x8_t bw[2][KS][2];                                               // [channel tile][k slab][plane]
+    float bias[2];
+};
+__device__ __forceinline__ void dt_split8(const float (&v)[8], f16x8_t& hi, f16x8_t& lo) {
+    uint2 a0, a1, b0, b1;
+    h2_split4(make_float4(v[0], v[1], v[2], v[3]), a0, a1);
+    h2_split4(make_float4(v[4], v[5], v[6], v[7]), b0, b1);
+    union { uint4 u; f16x8_t h; } x, y;
+    x.u = make_uint4(a0.x, a0.y, b0.x, b0.y); y.u = make_uint4(a1.x, a1.y, b1.x, b1.y);
+    hi = x.h; lo = y.h;
+}
+// wdt_dir: (R, C) weights of one direction, dtb_dir: (C); cbase: first of the wave's 64 channels.  log2(e) folded in (see step_vals).
+template <int R>
+__device__ __forceinline__ void dt_load_weights(DtWeights<R>& w, const float* __restrict__ wdt_dir, const float* __restrict__ dtb_dir, int C, int cbase) {
+    const int fr = threadIdx.x & 31, fh = (threadIdx.x >> 5) & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cj = cbase + 32 * j + fr;
+        w.bias[j] = XP_L2E * dtb_dir[cj];
+#pragma unroll
+        for (int ks = 0; ks < DtWeights<R>::KS; ++ks) {
+            float wv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = ks * 16 + fh * 8 + e;                     // clamped unconditional load + select: no branch per element
+                const float t = wdt_dir[(int64_t)(r < R ? r : 0) * C + cj];
+                wv[e] = r < R ? XP_L2E * t : 0.f;
+            }
+            dt_split8(wv, w.bw[j][ks][0], w.bw[j][ks][1]);
+        }
+    }
+}
+// rows: LDS, tile pixel i's dt_rank values at rows + i * stride (floats, 8-byte aligned)
+template <int R>
+__device__ __forceinline__ void dt_tile(const DtWeights<R>& w, const float* rows, int stride, float (&dtv)[2][16]) {
+    const int fr = threadIdx.x & 31, fh = (threadIdx.x >> 5) & 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = w.bias[j];
+#pragma unroll
+    for (int ks = 0; ks < DtWeights<R>::KS; ++ks) {
+        const int k0 = ks * 16 + fh * 8;
+        const float* ar = rows + fr * stride + (k0 < R ? k0 : 0);      // a half slab wholly past R reads the row start instead and is cleared
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2 t = *reinterpret_cast<const float2*>(ar + 2 * q);
+            v[2 * q] = k0 + 2 * q < R ? t.x : 0.f;                      // (R is even: a float2 is inside or outside as a whole)
+            v[2 * q + 1] = k0 + 2 * q < R ? t.y : 0.f;
+        }
+        f16x8_t hi, lo;
+        dt_split8(v, hi, lo);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, w.bw[j][ks][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, w.bw[j][ks][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, w.bw[j][ks][0], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][e]), __float_as_uint(acc[1][e]), false, false);
+        dtv[0][e] = __uint_as_float(sw[0]); dtv[1][e] = __uint_as_float(sw[1]);
+    }
+}
+#define XP_DTV(dtv, j) (dtv)[((j) >> 2) & 1][((j) & 3) + 4 * ((j) >> 3)]
+
 // Shared staging of one block's chunk(s): pixel indices and the xdbl rows of this route pair.
 template <int R>
 __device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair, int chunk0, int* s_pix, int* s_off, float* s_x) {
@@ -488,37 +567,14 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan(SS2DParams p, float* __restr
 template <int R>
 __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __restrict__ ys) {
     constexpr int RW = R + 2, NP = RW / 2, NPL = (NP + 1) / 2;          // float2 pieces per xdbl row of one route; pieces fetched by one lane
-    constexpr int KS = (R + 15) / 16;
-    static_assert(R % 8 == 0 && R >= 16, "whole 8-value fragment halves");
     __shared__ __align__(16) float s_x[2][SEQ_TP * RW];
     const int lane = threadIdx.x, d = blockIdx.y, b = blockIdx.z;
     const int pair = d >> 1, back = d & 1;                              // directions in the stored order (0, 2, 1, 3)
     const int fr = lane & 31, fh = lane >> 5;
     const int L = p.H * p.W, XD = 4 * RW;
     const int c = blockIdx.x * 64 + lane;                               // C % 64 == 0 (host)
-    f16x8_t bw[2][KS][2];                                               // [channel tile][k slab][plane]
-    float tile_bias[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cj = blockIdx.x * 64 + 32 * j + fr;
-        tile_bias[j] = XP_L2E * p.dtb[d * p.C + cj];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bool inside = ks * 16 + fh * 8 < R;                   // a half slab is inside or outside R as a whole
-            float wv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = p.wdt[((int64_t)d * R + (inside ? ks * 16 + fh * 8 + e : 0)) * p.C + cj];
-                wv[e] = inside ? XP_L2E * t : 0.f;
-            }
-            uint2 a0, a1, b0, b1;
-            h2_split4(make_float4(wv[0], wv[1], wv[2], wv[3]), a0, a1);
-            h2_split4(make_float4(wv[4], wv[5], wv[6], wv[7]), b0, b1);
-            union { uint4 u; f16x8_t h; } hi, lo;
-            hi.u = make_uint4(a0.x, a0.y, b0.x, b0.y); lo.u = make_uint4(a1.x, a1.y, b1.x, b1.y);
-            bw[j][ks][0] = hi.h; bw[j][ks][1] = lo.h;
-        }
-    }
+    DtWeights<R> dw;
+    dt_load_weights<R>(dw, p.wdt + (int64_t)d * R * p.C, p.dtb + d * p.C, p.C, blockIdx.x * 64);
     const float Av = XP_L2E * p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
     const int plane_bytes = L * p.C * 4;                                // host: < 2^31
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + (int64_t)b * L * p.C), 0, plane_bytes, 0x00020000);
@@ -570,37 +626,8 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __rest
     for (int t = 0; t < ntile; ++t) {
         if (t + 1 < ntile) { tile_offsets(t + 1, offn, offx); load_tile(offn, offx, unext); }
         const float* sx = s_x[t & 1];
-        // dt of the tile on the matrix pipe
-        f32x16 acc[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = tile_bias[j];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bool inside = ks * 16 + fh * 8 < R;                   // the zero-padded half slab of R = 24 reads the row start instead and is cleared
-            const float* ar = sx + fr * RW + (inside ? ks * 16 + fh * 8 : 0);
-            float2 tq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { tq[q] = *reinterpret_cast<const float2*>(ar + 2 * q); if (!inside) tq[q] = make_float2(0.f, 0.f); }
-            uint2 a0, a1, b0, b1;
-            h2_split4(make_float4(tq[0].x, tq[0].y, tq[1].x, tq[1].y), a0, a1);
-            h2_split4(make_float4(tq[2].x, tq[2].y, tq[3].x, tq[3].y), b0, b1);
-            union { uint4 u; f16x8_t h; } hi, lo;
-            hi.u = make_uint4(a0.x, a0.y, b0.x, b0.y); lo.u = make_uint4(a1.x, a1.y, b1.x, b1.y);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo.h, bw[j][ks][0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi.h, bw[j][ks][1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi.h, bw[j][ks][0], acc[j], 0, 0, 0);
-            }
-        }
-        float dtv[2][16];                                               // dt of pixel j = dtv[(j >> 2) & 1][(j & 3) + 4 * (j >> 3)]
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][e]), __float_as_uint(acc[1][e]), false, false);
-            dtv[0][e] = __uint_as_float(sw[0]); dtv[1][e] = __uint_as_float(sw[1]);
-        }
+        float dtv[2][16];
+        dt_tile<R>(dw, sx, RW, dtv);                                    // dt of the tile on the matrix pipe
         // four steps at a time: their operand evaluation (softplus, exp) is independent and interleaves; only the h update is a chain
 #pragma unroll
         for (int j0 = 0; j0 < SEQ_TP; j0 += 4) {
@@ -609,7 +636,7 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __rest
             for (int k = 0; k < 4; ++k) {
                 const float2 bc = *reinterpret_cast<const float2*>(sx + (j0 + k) * RW + R);
                 float delta;
-                xp_softplus_decay_l2_nb(dtv[(j0 >> 2) & 1][k + 4 * (j0 >> 3)], Av, delta, a[k]);
+                xp_softplus_decay_l2_nb(XP_DTV(dtv, j0 + k), Av, delta, a[k]);
                 bb[k] = delta * bc.x * ucur[j0 + k];
                 cv[k] = bc.y;
             }
