@@ -57,7 +57,10 @@ def parse():
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra PCIe-inclusive pass (pcie_inclusive_pairs_per_s: images uploaded from pinned host memory and "
                                                           "keypoints / match lists downloaded every step; reported beside the headline, never as `value`)")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the bounded CPU-baseline sample")
-    ap.add_argument("--split-encoder", type=int, default=2, help="encoder as S image groups on S streams (0/1 = whole batch on one stream); needs overlap")
+    ap.add_argument("--split-encoder", type=int, default=0, help="encoder as S image groups on S streams instead of the default schedule (round 2 until the alternating "
+                    "schedule: S = 2); needs overlap")
+    ap.add_argument("--no-alternate", action="store_true", help="default schedule off: by default the whole-batch encoders of consecutive steps alternate between two streams "
+                    "(two forwards in flight next to the detection / matching of the step before); with this flag and no --split-encoder: one encoder stream")
     ap.add_argument("--register", action="store_true", help="also run the registration step (robust homography per pair) inside every step; not part of the headline metric's definition")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: no overlap of step i's detection / matching kernels with step i+1's encoder")
     ap.add_argument("--no-other-backend", action="store_true", help="skip the extra timing passes (other dense-layer back end, single-stream rate): keeps profiler output to the headline configuration")
@@ -179,7 +182,7 @@ def main():
     pred = dict(topk=conf["topk"])
     sweeps = conf.get("nms_sweeps", 6)       # sweeps past the fixed point exit at once; 1024x1024 needs more than 480x640 (longer suppression chains)
     pipe = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, overlap=overlap, split_encoder=args.split_encoder,
-                        estimate_homography=args.register)
+                        estimate_homography=args.register, alternate_encoders=not args.no_alternate and args.split_encoder in (0, 1))
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
     pipe1 = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, estimate_homography=args.register) if overlap else pipe
@@ -417,7 +420,9 @@ def main():
             "config": {"workload": conf["label"] + f" (pairs/GPU/step = {B}): encode+detect(NMS 8, thr 0.015" + (f", keep_top_k {conf['topk']}" if conf["topk"] else "") +
                                    ")+describe+match(strict mutual NN)" + (", step replayed from hipGraphs" if args.graph else ""),
                        "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}, RCCL weight bcast",
-                       "stream_overlap": (f"{1 + max(pipe.split_encoder, 1)} HIP streams: step i+1's encoder ({max(pipe.split_encoder, 1)} image group(s)) overlaps "
+                       "stream_overlap": ("3 HIP streams: the whole-batch encoders of steps i+1 and i+2 (one stream each, alternating) overlap step i's detection / matching "
+                                          "kernels; all K steps complete inside the timed region") if (overlap and pipe.alternate) else
+                                         (f"{1 + max(pipe.split_encoder, 1)} HIP streams: step i+1's encoder ({max(pipe.split_encoder, 1)} image group(s)) overlaps "
                                           "step i's detection / matching kernels; all K steps complete inside the timed region") if overlap else "none (one stream)",
                        "keypoints_per_image_mean": round(sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res) / (2 * len(res)), 1),
                        "matches_per_pair_mean": round(sum(len(r["match_q"]) for r in res) / len(res), 1)},

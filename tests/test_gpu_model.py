@@ -105,9 +105,11 @@ def test_forward_224x320_and_end_to_end(gpu_lib, golden):
     assert not bad, parity.format_report("predict_keypoints", bad)
 
 
-def test_c2_batch8_end_to_end_indices_vs_reference(gpu_lib, golden, capsys):
+@pytest.mark.parametrize("schedule", ["alternate", "split2"])
+def test_c2_batch8_end_to_end_indices_vs_reference(gpu_lib, golden, capsys, schedule):
     """BASELINE config C2 on the GPU, end to end, against the REAL reference (tests/golden/g15_c2_batch8.npz, flow of
-    predict_align_image_pair.py:185-260): 8 pairs of 480x640 through the overlapped PairPipeline (the bench configuration).
+    predict_align_image_pair.py:185-260): 8 pairs of 480x640 through the overlapped PairPipeline — "alternate" is the bench
+    configuration (whole-batch encoders of consecutive steps on two streams), "split2" the image-group schedule.
     Keypoint lists and mutual-NN index pairs must be IDENTICAL to the reference's, except elements attributed, one by one, to a
     decision inside the 1e-4 parity budget (score vs threshold / vs an overlapping competitor, descriptor-distance gap);
     the near-tie report is printed.  Any unexplained difference fails."""
@@ -119,7 +121,7 @@ def test_c2_batch8_end_to_end_indices_vs_reference(gpu_lib, golden, capsys):
     assert (B, H, W) == (8, 480, 640)
     net = _net(synth.xpoint_exp1_config(H, W))
     data = _data(0, B, H, W)
-    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=True, split_encoder=2)
+    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=True, split_encoder=2 if schedule == "split2" else 0, alternate_encoders=schedule == "alternate")
     with torch.no_grad():
         for _ in range(2):      # second call: the other half of the double-buffered outputs, steady-state schedule
             pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
@@ -281,7 +283,7 @@ def test_config4_1024_topk_4096_pipeline(gpu_lib):
     assert [(m.queryIdx, m.trainIdx) for m in oms] == list(zip(out["match_q"].tolist(), out["match_t"].tolist()))
 
 
-@pytest.mark.parametrize("overlap,split", [(False, 0), (True, 0), (True, 2)])
+@pytest.mark.parametrize("overlap,split", [(False, 0), (True, 0), (True, 2), (True, -1)])
 def test_hipgraph_replay_equals_eager(gpu_lib, overlap, split):
     """BASELINE configs[4] asks for a hipGraph-captured forward: a captured PairPipeline step replays to the same results as the eager
     step, with new inputs at every replay — on one stream, and for the overlapped pipeline (per output buffer one graph per encoder
@@ -293,7 +295,7 @@ def test_hipgraph_replay_equals_eager(gpu_lib, overlap, split):
     with torch.no_grad():
         eager = PairPipeline(net, B, H, W, cap=2048)
         refs = [eager.run(d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"]).fetch() for d in seq]
-        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=overlap, split_encoder=split)
+        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=overlap, split_encoder=max(split, 0), alternate_encoders=split < 0)   # -1: alternating encoder streams
         d0 = seq[0]
         replay = pipe.capture(d0["optical"]["image"], d0["thermal"]["image"], d0["optical"]["valid_mask"], d0["thermal"]["valid_mask"])
         for d, ref in zip(seq[1:], refs[1:]):
@@ -310,12 +312,12 @@ def test_hipgraph_replay_equals_eager(gpu_lib, overlap, split):
             assert torch.equal(a["kp_thermal"], b["kp_thermal"]) and a["match_t"].tolist() == b["match_t"].tolist()
 
 
-@pytest.mark.parametrize("split", [0, 2, 4])
+@pytest.mark.parametrize("split", [0, 2, 4, -1])
 def test_overlapped_pipeline_equals_single_stream(gpu_lib, split):
     """overlap=True (two streams, encoder of call i+1 behind the detection / matching of call i, double-buffered encoder
     outputs) returns exactly the single-stream results: a sequence of calls with different inputs, the caller reusing
     its input tensors right after run() returns, masks included; also with the encoder split into image groups on
-    several streams."""
+    several streams, or (split = -1) with the whole-batch encoders of consecutive calls alternating between two streams."""
     from xpoint_amd.predict import PairPipeline
     H, W, B = 96, 128, 2
     net = _net(synth.xpoint_exp1_config(H, W))
@@ -325,7 +327,7 @@ def test_overlapped_pipeline_equals_single_stream(gpu_lib, split):
         refs = []
         for d in seq:
             refs.append(single.run(d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"]).fetch())
-        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=True, split_encoder=split)
+        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=True, split_encoder=max(split, 0), alternate_encoders=split < 0)
         io, it = torch.empty_like(seq[0]["optical"]["image"]), torch.empty_like(seq[0]["thermal"]["image"])
         mo, mt = torch.empty_like(seq[0]["optical"]["valid_mask"]), torch.empty_like(seq[0]["thermal"]["valid_mask"])
         for n_calls in (1, 2, 3, 4):

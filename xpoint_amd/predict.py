@@ -94,7 +94,7 @@ class PairPipeline:
     synchronises, checks NMS convergence / capacity and returns host lists."""
 
     def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=6, overlap=False,
-                 split_encoder=False, estimate_homography=False, ransac_iters=10000):
+                 split_encoder=False, estimate_homography=False, ransac_iters=10000, alternate_encoders=False):
         """overlap=True: two HIP streams — the encoder of call i+1 runs while the detection / matching kernels of call i
         (many small, latency-bound launches) are still in flight; encoder outputs are double-buffered.  Results of a
         call are complete after fetch() / torch.cuda.synchronize(), exactly as without overlap."""
@@ -105,6 +105,10 @@ class PairPipeline:
         self.split_encoder = (int(split_encoder) if self.overlap else 0)
         if self.split_encoder in (0, 1) or (2 * self.B) % max(self.split_encoder, 1):
             self.split_encoder = 0
+        # alternate_encoders: the encoders of consecutive calls run on two streams (call i on stream i & 1, whole batch, own
+        # workspace), so TWO full-batch forwards are in flight next to the detection / matching of the call before — the
+        # kernels keep their large-batch efficiency and fill each other's tails.  Results are those of the one-stream step.
+        self.alternate = bool(alternate_encoders) and self.overlap and not self.split_encoder
         self._call = 0
         self.pred = _cfg(cfg_prediction)
         self.mode = match_mode
@@ -127,6 +131,9 @@ class PairPipeline:
                 self.enc_streams = [self.enc_stream] + [torch.cuda.Stream() for _ in range(S - 1)]
                 self.encs_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
                 self.group_ws = [torch.empty(net.workspace_bytes(n // S, H, W), dtype=torch.uint8, device=dev) for _ in range(S)]
+            if self.alternate:
+                self.enc_streams = [self.enc_stream, torch.cuda.Stream()]
+                self.alt_ws = [torch.empty(net.workspace_bytes(n, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
             self.enc_done = [torch.cuda.Event() for _ in range(2)]
             self.post_done = [torch.cuda.Event() for _ in range(2)]
         self.nms_ws = torch.empty(lib.xp_box_nms_workspace_bytes(n, H, W, self.cap), dtype=torch.uint8, device=dev)
@@ -190,7 +197,9 @@ class PairPipeline:
                     self.encs_done[k][h].record()
                 self.post_stream.wait_event(self.encs_done[k][h])
         else:
-            with torch.cuda.stream(self.enc_stream):
+            stream = self.enc_streams[k] if self.alternate else self.enc_stream
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
                 self._encode(k, None, None)
                 self.enc_done[k].record()
             self.post_stream.wait_event(self.enc_done[k])
@@ -219,7 +228,8 @@ class PairPipeline:
     def _encode(self, k, optical, thermal):
         if optical is not None:
             self._stage_inputs(k, optical, thermal, None, None)
-        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], is_optical=self._flags())
+        ws = self.alt_ws[k] if getattr(self, "alternate", False) else None
+        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], workspace=ws, is_optical=self._flags())
 
     def _post(self, k, masked=False, _unused=None):
         B, H, W, n = self.B, self.H, self.W, 2 * self.B
@@ -290,12 +300,12 @@ class PairPipeline:
                     return self
                 return replay
             S = max(self.split_encoder, 1)
-            enc_streams = self.enc_streams if self.split_encoder else [self.enc_stream]
             graphs = []
+            streams_of = lambda k: self.enc_streams if self.split_encoder else [self.enc_streams[k] if self.alternate else self.enc_stream]
             for k in range(2):
                 enc_g = []
                 gsz = 2 * self.B // S
-                for h, stream in enumerate(enc_streams):
+                for h, stream in enumerate(streams_of(k)):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=stream):
                         if self.split_encoder:
@@ -322,7 +332,7 @@ class PairPipeline:
                     cur.wait_event(self.post_done[k])
                     self._stage_inputs(k, optical, thermal, mask_optical, mask_thermal)
                     enc_g, pg = graphs[k]
-                    for h, stream in enumerate(enc_streams):
+                    for h, stream in enumerate(streams_of(k)):
                         stream.wait_stream(cur)
                         with torch.cuda.stream(stream):
                             enc_g[h].replay()
