@@ -182,7 +182,7 @@ def main():
     pred = dict(topk=conf["topk"])
     sweeps = conf.get("nms_sweeps", 6)       # sweeps past the fixed point exit at once; 1024x1024 needs more than 480x640 (longer suppression chains)
     pipe = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, overlap=overlap, split_encoder=args.split_encoder,
-                        estimate_homography=args.register, alternate_encoders=not args.no_alternate and args.split_encoder in (0, 1))
+                        estimate_homography=args.register, alternate_encoders=(int(os.environ.get("XP_BENCH_DEPTH", "2")) if not args.no_alternate and args.split_encoder in (0, 1) else 0))
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
     pipe1 = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, estimate_homography=args.register) if overlap else pipe

@@ -109,6 +109,7 @@ class PairPipeline:
         # workspace), so TWO full-batch forwards are in flight next to the detection / matching of the call before — the
         # kernels keep their large-batch efficiency and fill each other's tails.  Results are those of the one-stream step.
         self.alternate = bool(alternate_encoders) and self.overlap and not self.split_encoder
+        self.depth = (max(2, int(alternate_encoders)) if self.alternate else 2) if self.overlap else 1      # calls in flight = sets of input / encoder-output buffers
         self._call = 0
         self.pred = _cfg(cfg_prediction)
         self.mode = match_mode
@@ -117,7 +118,7 @@ class PairPipeline:
         self.device = dev
         n = 2 * self.B
         lib = _lib.load()
-        nbuf = 2 if self.overlap else 1
+        nbuf = self.depth
         self.images_b = [torch.empty((n, 1, H, W), device=dev) for _ in range(nbuf)]
         self.images = self.images_b[0]
         self.raw_b = [None] * nbuf
@@ -129,13 +130,13 @@ class PairPipeline:
             if self.split_encoder:
                 S = self.split_encoder
                 self.enc_streams = [self.enc_stream] + [torch.cuda.Stream() for _ in range(S - 1)]
-                self.encs_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+                self.encs_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(nbuf)]
                 self.group_ws = [torch.empty(net.workspace_bytes(n // S, H, W), dtype=torch.uint8, device=dev) for _ in range(S)]
             if self.alternate:
-                self.enc_streams = [self.enc_stream, torch.cuda.Stream()]
-                self.alt_ws = [torch.empty(net.workspace_bytes(n, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
-            self.enc_done = [torch.cuda.Event() for _ in range(2)]
-            self.post_done = [torch.cuda.Event() for _ in range(2)]
+                self.enc_streams = [self.enc_stream] + [torch.cuda.Stream() for _ in range(nbuf - 1)]
+                self.alt_ws = [torch.empty(net.workspace_bytes(n, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+            self.enc_done = [torch.cuda.Event() for _ in range(nbuf)]
+            self.post_done = [torch.cuda.Event() for _ in range(nbuf)]
         self.nms_ws = torch.empty(lib.xp_box_nms_workspace_bytes(n, H, W, self.cap), dtype=torch.uint8, device=dev)
         self.kp = torch.zeros((n, self.cap, 2), dtype=torch.int32, device=dev)
         self.counts = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -171,7 +172,7 @@ class PairPipeline:
             self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
             self._encode(0, None, None)
             return self._post(0, mask_optical is not None, None)
-        k = self._call & 1
+        k = self._call % self.depth
         self._call += 1
         cur = torch.cuda.current_stream()
         # inputs are taken over on the CALLER's stream (so the caller may reuse its tensors right after run() returns),
@@ -272,7 +273,7 @@ class PairPipeline:
         """Make the caller's current stream wait for everything run() has enqueued so far (overlapped mode: the
         detection / matching stream); after it, stream-ordered reads of the result tensors are safe."""
         if self.overlap and self._call:
-            torch.cuda.current_stream().wait_event(self.post_done[(self._call - 1) & 1])
+            torch.cuda.current_stream().wait_event(self.post_done[(self._call - 1) % self.depth])
         return self
 
     def capture(self, optical, thermal, mask_optical=None, mask_thermal=None):
@@ -283,7 +284,7 @@ class PairPipeline:
         graph per encoder image group and one for the detection / matching kernels, each replayed on its own stream and
         chained by the same events as the eager schedule — the cross-step overlap survives capture."""
         with torch.cuda.device(self.device):
-            for _ in range(2 if self.overlap else 1):           # warm-up outside capture: one-time allocations, both buffers
+            for _ in range(self.depth):                         # warm-up outside capture: one-time allocations, every buffer set
                 self._run(optical, thermal, mask_optical, mask_thermal)
             torch.cuda.synchronize()
             masked = mask_optical is not None
@@ -302,7 +303,7 @@ class PairPipeline:
             S = max(self.split_encoder, 1)
             graphs = []
             streams_of = lambda k: self.enc_streams if self.split_encoder else [self.enc_streams[k] if self.alternate else self.enc_stream]
-            for k in range(2):
+            for k in range(self.depth):
                 enc_g = []
                 gsz = 2 * self.B // S
                 for h, stream in enumerate(streams_of(k)):
@@ -326,7 +327,7 @@ class PairPipeline:
 
             def replay(optical, thermal, mask_optical=None, mask_thermal=None):
                 with torch.cuda.device(self.device):
-                    k = self._call & 1
+                    k = self._call % self.depth
                     self._call += 1
                     cur = torch.cuda.current_stream()
                     cur.wait_event(self.post_done[k])
