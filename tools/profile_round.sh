@@ -24,4 +24,6 @@ python3 $R/tools/match_bench.py 4060 8192 8 > $OUT/match_microbench.txt 2>&1
 GB_H2=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_h2_microbench.txt 2>&1
 GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1
 python3 $R/tools/scan_bench.py > $OUT/selective_scan_microbench.txt 2>&1
+python3 $R/tools/ss2d_bench.py 0 1 2>&1 | grep -v amdgpu > $OUT/ss2d_core_microbench.txt
+python3 $R/tools/enc_only.py 2>&1 | grep stream > $OUT/encoder_only_streams.txt
 cat $OUT/bench.json; head -12 $OUT/kernel_stats.csv | cut -c1-200; head -20 $OUT/pmc_hbm_traffic.txt
