@@ -182,6 +182,12 @@ int xp_softmax_shuffle(const float* logits, float* prob, int batch, int Hc, int 
 int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, float eps, void* stream);
 int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int C, void* stream);
 int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_t n, void* stream);
+/* Batch staging of a step's inputs in ONE launch: images[0 .. n) = optical, images[n .. 2n) = thermal (f32, n = pairs*H*W elements)
+   and, when the masks are given (all three or none), masks[0 .. n) = mask_optical, masks[n .. 2n) = mask_thermal (u8).  Replaces the four
+   device-to-device copies of the reference's batch assembly (predict_align_image_pair.py:185-190 stacks the pair into one batch;
+   ImagePairDataset collate): the runtime's blit kernel moves a 9.8 MB image block at ~130 GB/s (76 us), this kernel at HBM speed. */
+int xp_stage_pair_batch(const float* optical, const float* thermal, float* images, const uint8_t* mask_optical,
+                        const uint8_t* mask_thermal, uint8_t* masks, int64_t n, void* stream);
 int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream);
 /* Data ingest (reference datasets/ImagePairDataset.py:199-208 cv2.imread + COLOR_BGR2GRAY + / 255.0, :254-274 crop):
  * src = decoded 8-bit image on the device, (H0, W0, channels) interleaved with channels 1 (gray), 3 (R,G,B) or 4 (R,G,B,A);

@@ -638,3 +638,28 @@ def test_image_pair_dataset_load_batch_equals_getitem(gpu_lib, tmp_path):
         ho = {k: {kk: torch.stack([h[k][kk] for h in host]).cuda() for kk in ("image", "valid_mask", "is_optical")} for k in ("optical", "thermal")}
         qo, qt, _ = net(ho)
     assert po["prob"].shape == (3, 1, 64, 96) and torch.equal(po["prob"], qo["prob"]) and torch.equal(pt["desc"], qt["desc"])
+
+
+@pytest.mark.parametrize("n,masked", [(8 * 96 * 128, True), (1003, True), (4 * 33 * 47, False), (16, True), (0, False)])
+def test_stage_pair_batch(gpu_lib, n, masked):
+    """xp_stage_pair_batch = the four device-to-device copies of the batch assembly (images f32, masks u8) in one launch:
+    16-byte and scalar paths, unaligned sizes, optional masks, empty input."""
+    L = _lib()
+    g = torch.Generator().manual_seed(n + 1)
+    a, b = torch.rand(n, generator=g).cuda(), torch.rand(n, generator=g).cuda()
+    ma = (torch.rand(n, generator=g) > 0.3).to(torch.uint8).cuda(); mb = (torch.rand(n, generator=g) > 0.6).to(torch.uint8).cuda()
+    out = torch.full((2 * n + 4,), -1.0, device="cuda"); mout = torch.full((2 * n + 4,), 7, dtype=torch.uint8, device="cuda")
+    L.call("xp_stage_pair_batch", L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(ma) if masked else None, L.ptr(mb) if masked else None,
+           L.ptr(mout) if masked else None, n, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out[:n], a) and torch.equal(out[n:2 * n], b) and bool((out[2 * n:] == -1).all())
+    if masked:
+        assert torch.equal(mout[:n], ma) and torch.equal(mout[n:2 * n], mb) and bool((mout[2 * n:] == 7).all())
+    else:
+        assert bool((mout == 7).all())
+    # unaligned base pointers take the scalar path
+    if n >= 16:
+        out2 = torch.full((2 * n + 8,), -1.0, device="cuda")
+        L.call("xp_stage_pair_batch", L.ptr(a[1:]), L.ptr(b[1:]), L.ptr(out2[1:]), None, None, None, n - 1, L.current_stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out2[1:n], a[1:]) and torch.equal(out2[n:2 * n - 1], b[1:])

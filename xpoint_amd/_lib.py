@@ -55,6 +55,7 @@ _SIGNATURES = {
     "xp_l2norm_rows": [c_p] * 2 + [c_l, c_i, c_f, c_p],
     "xp_nhwc_to_nchw": [c_p] * 2 + [c_i] * 3 + [c_p],
     "xp_mul_mask": [c_p] * 3 + [c_l, c_p],
+    "xp_stage_pair_batch": [c_p] * 6 + [c_l, c_p],
     "xp_maxpool2_nhwc": [c_p] * 2 + [c_i] * 4 + [c_p],
     "xp_ingest_u8": [c_p] + [c_i] * 7 + [c_p] * 3,
     "xp_ctx_create": [c_p, ctypes.POINTER(c_p)],

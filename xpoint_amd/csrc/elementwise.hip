@@ -5,6 +5,8 @@
 
 #include <string>
 
+#include <algorithm>
+
 #include "xp_common.h"
 
 namespace {
@@ -429,6 +431,53 @@ extern "C" int xp_nhwc_to_nchw(const float* x, float* y, int batch, int HW, int 
     dim3 grid(xp_cdiv(HW, 32), xp_cdiv(C, 32), batch);
     XpProfScope prof("nhwc_to_nchw", (hipStream_t)stream, 0.0, 8.0 * batch * HW * C);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+// two f32 blocks (and optionally two u8 blocks) of n elements each copied into the halves of the batch buffers; 16-byte units, scalar tails
+__global__ __launch_bounds__(256) void stage_pair_batch_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                               const uint8_t* __restrict__ ma, const uint8_t* __restrict__ mb, uint8_t* __restrict__ mout,
+                                                               int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n4 = n >> 2;
+    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) | (uintptr_t)(n * 4)) & 15) == 0;
+    if (al) {
+        for (int64_t i = t0; i < 2 * n4; i += stride) {
+            const bool second = i >= n4;
+            const int64_t j = second ? i - n4 : i;
+            reinterpret_cast<float4*>(out + (second ? n : 0))[j] = reinterpret_cast<const float4*>(second ? b : a)[j];
+        }
+        for (int64_t i = 4 * n4 + t0; i < n; i += stride) { out[i] = a[i]; out[n + i] = b[i]; }
+    } else {
+        for (int64_t i = t0; i < n; i += stride) { out[i] = a[i]; out[n + i] = b[i]; }
+    }
+    if (!mout) return;
+    const int64_t n16 = n >> 4;
+    const bool alm = ((reinterpret_cast<uintptr_t>(ma) | reinterpret_cast<uintptr_t>(mb) | reinterpret_cast<uintptr_t>(mout) | (uintptr_t)n) & 15) == 0;
+    if (alm) {
+        for (int64_t i = t0; i < 2 * n16; i += stride) {
+            const bool second = i >= n16;
+            const int64_t j = second ? i - n16 : i;
+            reinterpret_cast<uint4*>(mout + (second ? n : 0))[j] = reinterpret_cast<const uint4*>(second ? mb : ma)[j];
+        }
+        for (int64_t i = 16 * n16 + t0; i < n; i += stride) { mout[i] = ma[i]; mout[n + i] = mb[i]; }
+    } else {
+        for (int64_t i = t0; i < n; i += stride) { mout[i] = ma[i]; mout[n + i] = mb[i]; }
+    }
+}
+
+extern "C" int xp_stage_pair_batch(const float* optical, const float* thermal, float* images, const uint8_t* mask_optical,
+                                   const uint8_t* mask_thermal, uint8_t* masks, int64_t n, void* stream) {
+    XP_CHECK_ARG(n >= 0, "xp_stage_pair_batch: negative size");
+    if (n == 0) return XP_OK;
+    XP_CHECK_ARG(optical && thermal && images, "xp_stage_pair_batch: null pointer");
+    XP_CHECK_ARG((mask_optical != nullptr) == (masks != nullptr) && (mask_thermal != nullptr) == (masks != nullptr),
+                 "xp_stage_pair_batch: pass both masks and the mask buffer, or none of them");
+    XpProfScope prof("stage_pair_batch", (hipStream_t)stream, 0.0, (masks ? 20.0 : 16.0) * n);
+    const int64_t units = (n + 1) / 2;      // 2n / 4 sixteen-byte units of image data
+    hipLaunchKernelGGL(stage_pair_batch_kernel, dim3((unsigned)std::min<int64_t>(xp_cdiv(units, (int64_t)256), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       optical, thermal, images, mask_optical, mask_thermal, masks, n);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
