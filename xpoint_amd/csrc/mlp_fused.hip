@@ -110,13 +110,14 @@ __global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __res
     }
     n -= NPRE;
     if (u < T::UNITS && k < KD) {
-        // image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1); n = 2NC-1 -> W2(NC-1)
-        const bool is_w1 = (n == 0) || ((n & 1) && n < 2 * NC - 1);
+        // x3 (fc1 of chunk c+1 runs ahead of fc2 of chunk c): image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1);
+        // n = 2NC-1 -> W2(NC-1).   h2 (one hidden accumulator, chunk after chunk): even n -> W1(n/2), odd n -> W2(n/2).
+        const bool is_w1 = H2 ? !(n & 1) : ((n == 0) || ((n & 1) && n < 2 * NC - 1));
         if (is_w1) {
-            const int c = (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
+            const int c = H2 ? n >> 1 : (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
             v = mlp_src_unit<H2>(W1, H4, h, s, k);
         } else {
-            const int c = (n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1, j = row / C, nn = row - j * C;
+            const int c = H2 ? n >> 1 : ((n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1), j = row / C, nn = row - j * C;
             v = mlp_src_unit<H2>(W2, C, nn, 2 * c + j, k);
         }
     }
@@ -471,6 +472,20 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         end_phase();
     };
     int c = 0;
+    if constexpr (H2) {
+        // split-fp16 instances: ONE hidden accumulator, chunk after chunk — fc1(c), GELU + split, fc2(c) — over a stream packed in that
+        // order.  The x3 schedule below (fc1 of chunk c+1 with the GELU of chunk c between its MFMAs, two accumulator sets) spills 149
+        // registers at C = 192 with two planes resident and eight waves (8 here); measured 314 -> 272 us at C = 192, 278 -> 266 us at C = 96.
+        for (; c < NC; ++c) {
+            if (c > 0) { load_bias(c, h0); __builtin_amdgcn_sched_barrier(0); fc1(slot, h0, h0, std::integral_constant<int, 0>{}); end_phase(); }
+            if constexpr (H2) load_inv1(c, inv_cur);
+#pragma unroll
+            for (int k = 0; k < 20; ++k) slice(k, h0);
+            fc2(slot, h0);
+            if (c + 1 < NC) end_phase();
+        }
+        c = NC;
+    }
     for (; c + 2 < NC; c += 2) { iter(c, h0, h1); iter(c + 1, h1, h0); }
     auto tail = [&](f32x16& cur) {         // last chunk: nothing left to overlap the GELU with; image 2 NC - 1
         if constexpr (H2) load_inv1(NC - 1, inv_cur);
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         for (int k = 0; k < 20; ++k) slice(k, cur);
         fc2(slot, cur);
     };
-    if (c + 1 < NC) { iter(c, h0, h1); tail(h1); } else tail(h0);
+    if (c == NC) {} else if (c + 1 < NC) { iter(c, h0, h1); tail(h1); } else tail(h0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy DMAs of the last phases
 
     // ---- epilogue: x[m][n] = x[m][n] + (acc + b2[n]); lane = column n, registers = rows (r&3) + 8(r>>2) + 4g ----
