@@ -25,6 +25,10 @@
 #include "gemm_h2_core.h"
 #include "xp_common.h"
 
+#ifndef XP_SS2D_DBG
+#define XP_SS2D_DBG 0   /* timing experiments only (wrong results): 1 no out_norm tail, 2 no loads of the row pair's partial sums, 4 no step arithmetic */
+#endif
+
 namespace {
 
 constexpr float XP_L2E = 1.44269504088896340736f;   // log2(e): folded into the dt weights, the dt bias and A where they are loaded
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 const int po = (FULL || px[k] >= 0) ? px[k] : 0;
                 const float t = ub[po];
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
-                if (COLPAIR) pv[k] = prev[po];
+                if (COLPAIR) pv[k] = (XP_SS2D_DBG & 2) ? 0.f : prev[po];
             }
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
@@ -405,27 +409,55 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     }
     if (!COLPAIR) return;
     __syncthreads();
+    if (XP_SS2D_DBG & 1) { if (threadIdx.x < 4) p.out[(int64_t)b * L * p.C + blockIdx.x * 4 + threadIdx.x] = s_y[threadIdx.x]; return; }
     // out_norm: LayerNorm over C per pixel (two-pass mean / variance).  Narrow stages (C <= 192): 16 lanes per pixel, four
     // pixels per wave — with a whole wave per pixel two thirds of the lanes idle at C = 96 and the two 6-step shuffle
     // reductions dominate (this part was a third of the column pass at stage 0).  Wide stages: one wave per pixel.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     if (p.C <= 192) {
-        const int sub = lane & 15, grp = lane >> 4;
+        // 8 lanes per pixel, eight pixels per wave; a lane owns the float4 chunks sub + 8 j (C / 32 <= 6 of them): the row is read from LDS
+        // once (ds_read_b128), both reductions run on registers, every store instruction writes full 128-byte lines, and the out_norm
+        // weights are loaded once per lane.  (The first form — 16 lanes per pixel, scalar elements, three LDS reads of the row and the
+        // weights fetched per pixel — was 38 % of the column pass at stage 0.)
+        const int sub = lane & 7, grp = lane >> 3;
+        const int nj = p.C >> 5;
         const float invC = 1.f / (float)p.C;
-        for (int pi = wave * 4 + grp; pi < npx; pi += nw * 4) {      // a 16-lane group skips as a whole: shuffles stay inside the group
+        float4 gw[6], gb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < nj) {
+                gw[j] = *reinterpret_cast<const float4*>(p.ln_w + 4 * (sub + 8 * j));
+                gb[j] = *reinterpret_cast<const float4*>(p.ln_b + 4 * (sub + 8 * j));
+            }
+        for (int pi = wave * 8 + grp; pi < npx; pi += nw * 8) {      // an 8-lane group skips as a whole: the shuffles stay inside the group
             const int px = s_pix[pi];
             if (px < 0) continue;
             const float* row = s_y + pi * SY;
-            float s = 0.f;
-            for (int cc = sub; cc < p.C; cc += 16) s += row[cc];
-            s = xp_row16_sum(s);
-            const float mean = s * invC;
+            float4 r[6];
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < nj) { r[j] = *reinterpret_cast<const float4*>(row + 4 * (sub + 8 * j)); sm += (r[j].x + r[j].y) + (r[j].z + r[j].w); }
+            sm = xp_row8_sum(sm);
+            const float mean = sm * invC;
             float v = 0.f;
-            for (int cc = sub; cc < p.C; cc += 16) { const float d = row[cc] - mean; v = fmaf(d, d, v); }
-            v = xp_row16_sum(v);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < nj) {
+                    const float dx = r[j].x - mean, dy = r[j].y - mean, dz = r[j].z - mean, dw = r[j].w - mean;
+                    v = fmaf(dx, dx, v); v = fmaf(dy, dy, v); v = fmaf(dz, dz, v); v = fmaf(dw, dw, v);
+                }
+            v = xp_row8_sum(v);
             const float rstd = 1.f / sqrtf(v * invC + p.eps);
             float* orow = p.out + ((int64_t)b * L + px) * p.C;
-            for (int cc = sub; cc < p.C; cc += 16) orow[cc] = (row[cc] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < nj) {
+                    float4 o;
+                    o.x = (r[j].x - mean) * rstd * gw[j].x + gb[j].x; o.y = (r[j].y - mean) * rstd * gw[j].y + gb[j].y;
+                    o.z = (r[j].z - mean) * rstd * gw[j].z + gb[j].z; o.w = (r[j].w - mean) * rstd * gw[j].w + gb[j].w;
+                    *reinterpret_cast<float4*>(orow + 4 * (sub + 8 * j)) = o;
+                }
         }
         return;
     }

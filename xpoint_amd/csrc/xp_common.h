@@ -162,6 +162,13 @@ __device__ __forceinline__ float xp_row16_sum(float v) {
     v += xp_dpp_mov<0x121>(v);      // row_ror:1
     return v;
 }
+// sum over each aligned group of 8 lanes (every lane of the group gets it)
+__device__ __forceinline__ float xp_row8_sum(float v) {
+    v += xp_dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += xp_dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += xp_dpp_mov<0x141>(v);      // row_half_mirror: the other quad of the 8-lane half row
+    return v;
+}
 __device__ __forceinline__ float xp_row16_max(float v) {
     v = fmaxf(v, xp_dpp_mov<0x128>(v));
     v = fmaxf(v, xp_dpp_mov<0x124>(v));
