@@ -26,7 +26,7 @@
 #include "xp_common.h"
 
 #ifndef XP_SS2D_DBG
-#define XP_SS2D_DBG 0   /* timing experiments only (wrong results): 1 no out_norm tail, 2 no loads of the row pair's partial sums, 4 no step arithmetic */
+#define XP_SS2D_DBG 0   /* timing experiments only (wrong results): 1 no out_norm tail, 2 no loads of the row pair's partial sums, 4 no step arithmetic (projection, softplus, exp), 8 no u loads */
 #endif
 
 namespace {
@@ -76,6 +76,7 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
             xv[2 * q] = t.x; xv[2 * q + 1] = t.y;
         }
     }
+    if (XP_SS2D_DBG & 4) { a = 0.5f; b = xv[R] * u; Cv = xv[R + 1]; return; }
     // w, bias and A arrive pre-multiplied by log2(e) (XP_L2E at their loads): the chain below is x * log2(e) directly
     float dt = fmaf(w[0], xv[0], bias);
 #pragma unroll
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
-                const float t = ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
-                const float t = ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];
-                const float t = ub[(FULL || px[k] >= 0) ? px[k] : 0];
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[(FULL || px[k] >= 0) ? px[k] : 0];
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
             for (int k = 3; k >= 0; --k) {
                 px[k] = s_off[cl * p.T + i0 + k];
                 const int po = (FULL || px[k] >= 0) ? px[k] : 0;
-                const float t = ub[po];
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[po];
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
                 if (COLPAIR) pv[k] = (XP_SS2D_DBG & 2) ? 0.f : prev[po];
             }
