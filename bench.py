@@ -200,7 +200,6 @@ def main():
             crop = {"optical": {"image": o_img[:, :, :256, :256].contiguous()}, "thermal": {"image": t_img[:, :, :256, :256].contiguous()}}
             hm_out["hm"] = net_hm(crop)[2]
         pin_o, pin_t = opt.cpu().pin_memory(), thr.cpu().pin_memory()
-        dev_o, dev_t = torch.empty_like(opt), torch.empty_like(thr)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -241,13 +240,22 @@ def main():
             torch.cuda.synchronize(); lib.xp_prof_enable(0)
             replay = pipe.capture(opt, thr, mo, mt)
             if args.config == "c5":
+                hm_host = [None, None]; hm_ev = [torch.cuda.Event(), torch.cuda.Event()]; pending = []
+
                 def step():
-                    # streaming step: images arrive from pinned host memory, the step's result lists go back to the host
-                    dev_o.copy_(pin_o, non_blocking=True); dev_t.copy_(pin_t, non_blocking=True)
-                    replay(dev_o, dev_t, mo, mt)
-                    hm_step(dev_o, dev_t)
-                    pipe.wait()
-                    _ = (pipe.counts.cpu(), pipe.m["match_count"].cpu(), pipe.m["match_q"].cpu(), pipe.m["match_t"].cpu(), pipe.kp.cpu(), hm_out["hm"].cpu())
+                    # streaming step: the images arrive from pinned host memory (uploaded straight into the batch buffers), the step's result
+                    # lists go back to pinned host buffers behind its last kernel; the host consumes step i-1's results while step i runs
+                    replay(pin_o, pin_t, mo, mt)
+                    hm_step(pipe.images[:B], pipe.images[B:])
+                    j = len(pending) & 1
+                    if hm_host[j] is None:
+                        hm_host[j] = torch.empty(hm_out["hm"].shape, dtype=hm_out["hm"].dtype).pin_memory()
+                    hm_host[j].copy_(hm_out["hm"], non_blocking=True); hm_ev[j].record()
+                    bufs, ev = pipe.download_async()
+                    if pending:
+                        pev, phm = pending[-1]
+                        pev.synchronize(); phm.synchronize()              # results of the step before are on the host
+                    pending.append((ev, hm_ev[j]))
             else:
                 step = lambda: replay(opt, thr, mo, mt)
             for _ in range(2):
@@ -332,16 +340,16 @@ def main():
     pcie = None
     if not args.no_h2d and args.config == "c2":
         ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
-        do, dth = torch.empty_like(opt), torch.empty_like(thr)
         with torch.no_grad():
             sync_all()
             t1 = time.perf_counter()
+            prev = None
             for _ in range(args.steps):
-                do.copy_(ho, non_blocking=True); dth.copy_(ht, non_blocking=True)
-                pipe.run(do, dth, mo, mt)
-                pipe.wait()                                                    # results leave the device every step: no cross-step overlap here
-                kc = pipe.counts.cpu(); mc = pipe.m["match_count"].cpu()      # results leave the device (counts + match lists)
-                mq = pipe.m["match_q"].cpu(); mtt = pipe.m["match_t"].cpu(); kk = pipe.kp.cpu()
+                pipe.run(ho, ht, mo, mt)                                       # pinned host images uploaded straight into the batch buffers
+                bufs, ev = pipe.download_async()                               # counts, keypoints, match lists -> pinned host buffers behind the step
+                if prev is not None:
+                    prev.synchronize()                                         # the step before is on the host while this one runs
+                prev = ev
             sync_all()
             pcie = world * B * args.steps / (time.perf_counter() - t1)
     res = pipe.fetch()

@@ -524,3 +524,38 @@ def test_c4_1024_topk4096_end_to_end_vs_reference(gpu_lib, golden, capsys):
         print("\n" + "\n".join(lines))
     assert not bad, parity.format_report("matches", bad)
     assert len(rep) <= max(4, len(mine) // 50)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_download_async_equals_fetch(gpu_lib, overlap):
+    """Streaming use of PairPipeline: download_async() enqueues the result copies behind the step and the next run() before the host waits;
+    the pinned buffers of step i (consumed after step i+1 was enqueued) hold exactly what a synchronous fetch() of step i returns — also
+    when the images come from pinned host memory."""
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 96, 128, 2
+    net = _net(synth.xpoint_exp1_config(H, W))
+    seq = [_data(s, B, H, W) for s in (3, 8, 1)]
+    with torch.no_grad():
+        ref_pipe = PairPipeline(net, B, H, W, cap=2048)
+        refs = [ref_pipe.run(d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"]).fetch() for d in seq]
+        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=overlap, alternate_encoders=overlap)
+        got, prev = [], None
+
+        def consume(bufs, ev):
+            ev.synchronize()
+            got.append({k: v.clone() for k, v in bufs.items()})
+        for d in seq:
+            o, t = d["optical"]["image"].cpu().pin_memory(), d["thermal"]["image"].cpu().pin_memory()
+            pipe.run(o, t, d["optical"]["valid_mask"], d["thermal"]["valid_mask"])
+            cur = pipe.download_async()
+            if prev is not None:
+                consume(*prev)
+            prev = cur
+        consume(*prev)
+        torch.cuda.synchronize()
+        pipe.verify()
+    for g, ref in zip(got, refs):
+        for i in range(B):
+            no, nt, nm = int(g["counts"][i]), int(g["counts"][B + i]), int(g["match_count"][i])
+            assert torch.equal(g["kp"][i, :no].long(), ref[i]["kp_optical"]) and torch.equal(g["kp"][B + i, :nt].long(), ref[i]["kp_thermal"])
+            assert g["match_q"][i, :nm].tolist() == ref[i]["match_q"].tolist() and g["match_t"][i, :nm].tolist() == ref[i]["match_t"].tolist()

@@ -359,6 +359,33 @@ class PairPipeline:
                 return self
             return replay
 
+    def download_async(self):
+        """Streaming use: enqueue — right behind the detection / matching kernels of the last run() / replay — the copies of its result
+        lists (keypoint counts and coordinates, match counts and index lists, distances; the homography fields when estimated) into
+        pinned host buffers, and return (buffers, event).  The buffers are valid after event.synchronize(); the NEXT run() may be enqueued
+        before that, so the device-to-host traffic of step i overlaps step i+1 (two buffer sets alternate: consume a set before the
+        second call after it).  The copies are ordered on the stream that writes the results, ahead of the next step's kernels."""
+        with torch.cuda.device(self.device):
+            if not hasattr(self, "_host"):
+                def pin(t):
+                    return torch.empty(t.shape, dtype=t.dtype, device="cpu").pin_memory()
+                src = dict(counts=self.counts, kp=self.kp, match_count=self.m["match_count"], match_q=self.m["match_q"], match_t=self.m["match_t"],
+                           match_d=self.m["match_d"])
+                if self.estimate_homography:
+                    src.update(H_est=self.hg["H"], n_inliers=self.hg["n_inliers"], matchesMask=self.hg["mask"])
+                self._host_src = src
+                self._host = [{k: pin(v) for k, v in src.items()} for _ in range(2)]
+                self._host_ev = [torch.cuda.Event() for _ in range(2)]
+                self._host_i = 0
+            i = self._host_i
+            self._host_i ^= 1
+            stream = self.post_stream if self.overlap else torch.cuda.current_stream()
+            with torch.cuda.stream(stream):
+                for k, v in self._host_src.items():
+                    self._host[i][k].copy_(v, non_blocking=True)
+                self._host_ev[i].record()
+            return self._host[i], self._host_ev[i]
+
     def verify(self):
         """After a synchronisation point: the async NMS must have reached its fixed point and no list may have
         overflowed its capacity.  Raises otherwise (the caller can re-run with more sweeps / capacity)."""
