@@ -23,7 +23,11 @@ namespace {
 // Tiles of 32x32 pixels with a halo iterate locally in LDS; launches repeat until no pixel in the
 // batch is undecided (device counter).
 // ---------------------------------------------------------------------------------------------
-constexpr int NMS_TILE = 32;
+constexpr int NMS_TILE = 32;          // tile width: the row masks are 64-bit words, NMS_TILE + 2 * NMS_MAXR <= 64
+#ifndef XP_NMS_TH
+#define XP_NMS_TH 64   /* measured at 480 x 640, 16 images: 0.41 ms (32), 0.37-0.39 (64), 0.44 (128), 0.58 (192) — fewer tiles pay the fixed per-tile cost, taller ones serialise */
+#endif
+constexpr int NMS_TH = XP_NMS_TH;     // tile height (rows are not limited by the mask width)
 constexpr int NMS_MAXR = 15;
 constexpr int NMS_MAX_SWEEPS = 64;        // counters[] slots (one per sweep of a round)
 
@@ -45,22 +49,22 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
     if (sweep > 0 && counters[sweep - 1] == 0) return;   // converged in an earlier sweep (uniform early exit)
     const int tile_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (!first && !tile_active[tile_id]) return;
-    constexpr int TWMAX = NMS_TILE + 2 * NMS_MAXR;
-    __shared__ float s_sc[TWMAX * TWMAX];
-    __shared__ unsigned long long m_und[TWMAX], m_kept[TWMAX];
-    __shared__ unsigned short s_list[NMS_TILE * NMS_TILE];
+    constexpr int TWMAX = NMS_TILE + 2 * NMS_MAXR, THMAX = NMS_TH + 2 * NMS_MAXR;
+    __shared__ float s_sc[TWMAX * THMAX];
+    __shared__ unsigned long long m_und[THMAX], m_kept[THMAX];
+    __shared__ unsigned short s_list[NMS_TILE * NMS_TH];
     __shared__ int s_n, s_changed;
     const int R = tab.reach;
-    const int TW = NMS_TILE + 2 * R;
+    const int TW = NMS_TILE + 2 * R, TH = NMS_TH + 2 * R;
     const int b = blockIdx.z;
-    const int y0 = blockIdx.y * NMS_TILE - R, x0 = blockIdx.x * NMS_TILE - R;
+    const int y0 = blockIdx.y * NMS_TH - R, x0 = blockIdx.x * NMS_TILE - R;
     const float* pb = prob + (int64_t)b * H * W;
     uint8_t* sb = state + (int64_t)b * H * W;
     float* ob = out + (int64_t)b * H * W;
-    for (int i = threadIdx.x; i < TW; i += 256) { m_und[i] = 0ull; m_kept[i] = 0ull; }
+    for (int i = threadIdx.x; i < TH; i += 256) { m_und[i] = 0ull; m_kept[i] = 0ull; }
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < TW * TW; i += 256) {
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW;
         const int y = y0 + ty, x = x0 + tx;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
         s_sc[i] = sc;
         if (st == ST_UNDECIDED) {
             atomicOr(&m_und[ty], 1ull << tx);
-            const bool own = ty >= R && ty < R + NMS_TILE && tx >= R && tx < R + NMS_TILE;
+            const bool own = ty >= R && ty < R + NMS_TH && tx >= R && tx < R + NMS_TILE;
             if (own) { const int pos = atomicAdd(&s_n, 1); s_list[pos] = (unsigned short)(ty * 64 + tx); }
         } else if (st == ST_KEPT) {
             atomicOr(&m_kept[ty], 1ull << tx);
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
         }
     }
     int left = 0;
-    for (int o = threadIdx.x; o < NMS_TILE * NMS_TILE; o += 256) {
+    for (int o = threadIdx.x; o < NMS_TILE * NMS_TH; o += 256) {
         const int ty = R + o / NMS_TILE, tx = R + o % NMS_TILE;
         const int y = y0 + ty, x = x0 + tx;
         if (y < H && x < W) {
@@ -335,7 +339,7 @@ namespace {
 struct NmsWs { uint8_t* state; uint8_t* tile_active; int* counters; int* kp; };
 NmsWs nms_ws(void* workspace, int batch, int H, int W) {
     const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
-    const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TILE) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
+    const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TH) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
     NmsWs w;
     w.state = (uint8_t*)workspace;
     w.tile_active = w.state + n;
@@ -348,7 +352,7 @@ NmsWs nms_ws(void* workspace, int batch, int H, int W) {
 extern "C" size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap) {
     // state bytes + tile flags + counters + (top-k) keypoint list, counts, ranks
     const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
-    const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TILE) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
+    const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TH) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
     return n + nt + sizeof(int) * (NMS_MAX_SWEEPS + (size_t)batch * cap * 3 + batch + 64) + xp_extract_keypoints_workspace_bytes(batch, H, W);
 }
 
@@ -358,7 +362,7 @@ static int box_nms_enqueue(const float* prob, float* out, void* workspace, int b
     const NmsWs w = nms_ws(workspace, batch, H, W);
     XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
     hipLaunchKernelGGL(nms_reset_counters_kernel, dim3(1), dim3(64), 0, s, w.counters);
-    dim3 grid(xp_cdiv(W, NMS_TILE), xp_cdiv(H, NMS_TILE), batch);
+    dim3 grid(xp_cdiv(W, NMS_TILE), xp_cdiv(H, NMS_TH), batch);
     // Local fixed-point iterations per sweep.  Early sweeps are dominated by decisions that wait on a neighbouring tile, so
     // iterating long inside a tile is wasted there (measured: 8 iterations in sweep 0 cost 256 us, 2 cost 128 us, and the
     // number of sweeps to convergence is the same); late sweeps touch few tiles and finish them locally.
