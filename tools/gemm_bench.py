@@ -13,6 +13,8 @@ shapes = [  # (M, N, K, act, res)
     (10240, 384, 1536, 0, 0),   # 20: 240 workgroups of 128x128 = one per CU: the single-workgroup K-loop timeline
 ]
 import os
+if os.environ.get('GB_SHAPES'):      # "M,N,K,act,res;..."
+    shapes = [tuple(int(v) for v in t.split(',')) for t in os.environ['GB_SHAPES'].split(';')]
 if os.environ.get('GB_ONLY'):
     idx=[int(i) for i in os.environ['GB_ONLY'].split(',')]; shapes=[shapes[i] for i in idx]
 torch.manual_seed(0)

@@ -229,7 +229,8 @@ int dispatch(const GemmParams& p, hipStream_t s) {
     static const int force = getenv("XP_H2_TILE") ? atoi(getenv("XP_H2_TILE")) : -1;   // tuning experiments only
     const int sel = force >= 0 ? force
                   : N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2
-                  : (p.M <= 8192 && N >= 512 && (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 512) ? 3 : 4;
+                  : ((p.M <= 8192 && N >= 512 && (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 512) ||
+                     (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 256) ? 3 : 4;       // fewer 128 x 128 tiles than CUs (x_proj of the deep stages: N = 104 / 200): 64 x 128
     // Row-stationary engine for the implicit-GEMM convolutions (measured: 0.55 vs 0.71 ms for the four big convs of a step; the gathered
     // A rows cost the tile engine an LDS round trip they do not need), the tile engine for plain GEMMs (equal at K >= 384, 15 % faster at
     // K = 96 where the row-stationary lane-per-row loads touch 32 cache lines per instruction).  XP_H2_ENGINE = rs | lds forces one (A/B).
