@@ -206,7 +206,7 @@ def main():
             if "g" in hm_graph:
                 hm_graph["g"].replay()
             else:
-                hm_out["hm"] = net_hm({"optical": {"image": crop_o}, "thermal": {"image": crop_t}})[2]
+                hm_out["hm"] = net_hm.predict_homography(crop_o, crop_t)
 
         def hm_capture():
             for _ in range(2):
@@ -214,7 +214,7 @@ def main():
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                hm_out["hm"] = net_hm({"optical": {"image": crop_o}, "thermal": {"image": crop_t}})[2]
+                hm_out["hm"] = net_hm.predict_homography(crop_o, crop_t)
             hm_graph["g"] = g
         pin_o, pin_t = opt.cpu().pin_memory(), thr.cpu().pin_memory()
 

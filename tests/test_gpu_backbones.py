@@ -99,5 +99,9 @@ def test_regnet_head_256(gpu_lib, golden):
     with torch.no_grad():
         o, t, hm2 = net(synth.to_torch(synth.make_pair_batch(7, 1, 256, 256), "cuda"))
     assert float(np.abs(hm2.cpu().numpy() - g["hm"]).max()) < 5e-4           # includes the encoder's own 1e-5-level error
+    with torch.no_grad():                                                      # the head alone (encoder + RegNet, no detector / descriptor heads)
+        d = synth.to_torch(synth.make_pair_batch(7, 1, 256, 256), "cuda")
+        hm3 = net.predict_homography(d["optical"]["image"], d["thermal"]["image"])
+    assert torch.equal(hm3, hm2)
     with pytest.raises(RuntimeError):                                          # 480x640: the reference fails too
         regnet_forward(w, torch.zeros(1, 60, 80, 48, device="cuda"), torch.zeros(1, 60, 80, 48, device="cuda"))

@@ -468,3 +468,17 @@ class XPoint(torch.nn.Module):
                 self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
             pred_hm = regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
         return pred_optical, pred_thermal, pred_hm
+
+    def predict_homography(self, optical, thermal):
+        """Homography-regression head alone (the third value of forward(), reference XPoint.py:205-212 / RegNet.py:7-52) for callers that take
+        keypoints and descriptors from another forward (bench config C5 runs the head on 256x256 crops, the only size the reference's RegNet
+        is defined for): encoder + RegNet, the detector / descriptor heads are not evaluated.  optical, thermal: (B, 1, H, W) device tensors."""
+        from .convmodels import regnet_forward, regnet_weights
+        if not self.config["homography_regression_head"]["check"] or self.config["homography_regression_head"]["type"] != "RegNet":
+            raise NotImplementedError("predict_homography needs homography_regression_head.check with type 'RegNet'")
+        B = optical.shape[0]
+        flags = [True] * B + [False] * thermal.shape[0] if self.config['multispectral'] else None
+        raw = self.forward_raw(torch.cat([optical, thermal], 0), want_prob=False, want_desc=False, is_optical=flags)
+        if self._regnet_w is None:
+            self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
+        return regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
