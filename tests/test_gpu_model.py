@@ -559,3 +559,34 @@ def test_download_async_equals_fetch(gpu_lib, overlap):
             no, nt, nm = int(g["counts"][i]), int(g["counts"][B + i]), int(g["match_count"][i])
             assert torch.equal(g["kp"][i, :no].long(), ref[i]["kp_optical"]) and torch.equal(g["kp"][B + i, :nt].long(), ref[i]["kp_thermal"])
             assert g["match_q"][i, :nm].tolist() == ref[i]["match_q"].tolist() and g["match_t"][i, :nm].tolist() == ref[i]["match_t"].tolist()
+
+
+def test_pipeline_flags_fp16_range_overflow(gpu_lib):
+    """The default dense engine splits f32 operands into two fp16 values: activations beyond 65504 overflow.  The pipeline must say so
+    (verify() / fetch() raise) instead of returning silently wrong keypoints — the heads' ReLU turns a NaN encoder map into finite scores —;
+    the split-bf16 engine runs the same weights.  Provoked with a
+    LayerNorm gain of 1e6 in front of a stage-2 GEMM (unfused path: the value reaches xp_gemm_nt_h2 as an activation)."""
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 64, 96, 1
+    cfg = synth.xpoint_exp1_config(H, W)
+    data = _data(5, B, H, W)
+    sd = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
+    sd["encoder.layers.2.blocks.0.norm2.weight"] *= 1.0e6
+    for mode, must_raise in (("h2", True), ("x3", False)):
+        net = _net(cfg, sd); net.gemm_mode = mode
+        with torch.no_grad():
+            if must_raise:
+                with pytest.raises(RuntimeError, match="non-finite"):          # the model's own first-forward check
+                    net(data)
+                pipe = PairPipeline(net, B, H, W, cap=4096)                     # later forwards are not checked by the model; the pipeline's verify() is
+                pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
+                torch.cuda.synchronize()
+                with pytest.raises(RuntimeError, match="non-finite"):
+                    pipe.verify()
+            else:
+                net(data)
+                pipe = PairPipeline(net, B, H, W, cap=4096)
+                pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
+                torch.cuda.synchronize()
+                pipe.verify()
+                assert bool(torch.isfinite(pipe.raw["enc_nhwc"]).all())

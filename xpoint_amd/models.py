@@ -80,6 +80,7 @@ class XPoint(torch.nn.Module):
         self._ws: Dict[str, torch.Tensor] = {}
         self._conv_impl = None
         self._regnet_w = None
+        self._finite_checked = set()      # gemm modes whose first forward after a weight load was checked for non-finite encoder output
         self.encoder_downsample_ratio = 8
         self.detector_head_last_dim = 65
         self.head_channels = 256
@@ -175,6 +176,7 @@ class XPoint(torch.nn.Module):
         self._wsplit_t = None
         self._conv_impl = None
         self._regnet_w = None
+        self._finite_checked = set()      # gemm modes whose first forward after a weight load was checked for non-finite encoder output
         return _LoadResult(missing, unexpected)
 
     def _bn_affine(self, pre, eps=1e-5):
@@ -411,6 +413,14 @@ class XPoint(torch.nn.Module):
                 _lib.call("xp_set_dense_products", prev)
             if engine != prev_engine:
                 _lib.call("xp_set_dense_engine", prev_engine)
+        if self.gemm_mode not in self._finite_checked and not torch.cuda.is_current_stream_capturing():
+            # One-time sanity check per weight load and dense back end (one host synchronisation): the split-fp16 engine overflows where
+            # an activation exceeds 65504, and the heads' ReLU (max(NaN, 0) = 0 on the GPU) would turn a NaN encoder map into finite,
+            # wrong scores.  Weights whose first forward is clean are taken as in range; PairPipeline.verify() checks every fetched step.
+            self._finite_checked.add(self.gemm_mode)
+            if not bool(torch.isfinite(out["enc_nhwc"]).all()):
+                raise RuntimeError("xpoint_amd.XPoint: non-finite encoder output"
+                                   + (" — activations beyond the fp16 range of gemm_mode 'h2' (|x| < 65504)? set gemm_mode = 'x3'" if self.gemm_mode == "h2" else ""))
         return out
 
     @staticmethod

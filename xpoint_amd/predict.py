@@ -399,6 +399,11 @@ class PairPipeline:
         mx = int(self.counts.max().item())
         if mx > self.cap:
             raise RuntimeError(f"PairPipeline: {mx} keypoints exceed capacity {self.cap}")
+        if self.raw is not None and self.raw.get("enc_nhwc") is not None and not bool(torch.isfinite(self.raw["enc_nhwc"]).all()):
+            # Checked on the ENCODER output: the heads' ReLU (max(NaN, 0) = 0 on the GPU) would wash a NaN out into finite, wrong scores.
+            # The split-fp16 dense engine needs activations below 65504 (include/xpoint_hip.h, xp_xpoint_forward); the split-bf16 one has no such limit.
+            raise RuntimeError("PairPipeline: non-finite encoder output"
+                               + (" — activations beyond the fp16 range of gemm_mode 'h2'? retry with net.gemm_mode = 'x3'" if getattr(self.net, "gemm_mode", "") == "h2" else ""))
 
     def fetch(self):
         torch.cuda.synchronize()        # device-wide: covers both streams of the overlapped mode
