@@ -229,7 +229,11 @@ int xp_prepare_split_weights(void* ctx, const float* weights, void* wsplit, size
 /* images (batch,1,H,W) in [0,1]; outputs: prob (batch,H,W) or NULL; desc_nhwc (batch,Hc,Wc,desc_size) or NULL;
  * enc_nhwc (batch,Hc,Wc,embed_dim/2) required; logits_nhwc (batch,Hc,Wc,65) or NULL.
  * wsplit: the buffer prepared by xp_prepare_split_weights -> dense layers run on xp_gemm_nt_x3 / xp_conv3x3_nhwc_x3;
- * NULL -> they run on the exact-f32 MFMA kernels (xp_gemm_nt / xp_conv3x3_nhwc).  Same results to f32 rounding. */
+ * NULL -> they run on the exact-f32 MFMA kernels (xp_gemm_nt / xp_conv3x3_nhwc).  Same results to f32 rounding.
+ * With the split-fp16 engine selected (xp_set_dense_engine(1), the default of the Python host) every dense-layer INPUT must stay
+ * below 65504 in magnitude; beyond it the products turn into NaN, and because the heads apply ReLU (max(NaN, 0) = 0 on the GPU) `prob`
+ * then looks finite.  Callers should test enc_nhwc for non-finite values after the first forward on new weights (the Python host
+ * does: models.XPoint, PairPipeline.verify) and fall back to engine 0 (split-bf16: no range limit). */
 int xp_xpoint_forward(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
                       void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
                       float* logits_nhwc, void* stream);
