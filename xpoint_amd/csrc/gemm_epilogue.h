@@ -23,6 +23,7 @@ struct GemmParams {
     int M, N, K;
     int lda, ldc, ldres;
     int act;              // 0 none, 1 GELU(erf), 2 ReLU (before scale/shift), 3 ReLU after scale/shift
+    int ngroup;           // split-fp16 tile engine: column tiles per group of the tile order (0 = N-fastest), gemm_h2.hip
     int mode;             // 0: plain A; 1: implicit 3x3 conv over NHWC (K order = kh, kw, ci)
     int Hi, Wi, Ci, Ho, Wo, stride, reflect;
     int stagger_cycles;   // start-up delay of the second workgroup slot of every CU (see gemm_kernel)

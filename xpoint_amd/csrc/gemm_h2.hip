@@ -9,6 +9,7 @@
 //   once per weight upload: slab-major, so the BN rows a workgroup needs for one slab are BN * 128 contiguous bytes.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <string>
 
 #include "gemm_h2_core.h"
@@ -62,7 +63,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h2_kernel(GemmParams p) {
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int q = total >> 3, r = total & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int m0 = (logical / ntn) * T::BM, n0 = (logical % ntn) * T::BN;
+    // Wide layers (the weights do not fit an XCD's 4 MB L2: fc1 of the deep stages): column tiles in groups of p.ngroup — all row blocks of a
+    // group before the next group — so that a group's weight slabs stay in L2 while the activations stream past (tools/gemm_traffic.sh:
+    // 275 -> MB fetched per launch for M 4800, N 3072, K 768 with the plain N-fastest order: every row block pulled all of W again).
+    int mt, nt;
+    if (p.ngroup > 0) {
+        const int ntm = (p.M + T::BM - 1) / T::BM;
+        const int per = ntm * p.ngroup;
+        const int g = logical / per, rem = logical - g * per;
+        const int gw = min(p.ngroup, ntn - g * p.ngroup);
+        mt = rem / gw; nt = g * p.ngroup + (rem - mt * gw);
+    } else {
+        mt = logical / ntn; nt = logical - mt * ntn;
+    }
+    const int m0 = mt * T::BM, n0 = nt * T::BN;
 
     const float* a_ptr[T::A_LD];     // plain: row base; conv: image base
     int a_oh[T::A_LD], a_ow[T::A_LD], a_tap[T::A_LD], a_ci[T::A_LD];
@@ -224,8 +238,22 @@ void launch(const GemmParams& p, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_h2_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), T::kLdsBytes, s, p);
 }
 
-int dispatch(const GemmParams& p, hipStream_t s) {
+int dispatch(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
     const int N = p.N;
+    // column-tile groups (tile engine): when W (two fp16 planes = 4 bytes per element) exceeds what an XCD's L2 can keep next to the activations,
+    // process the column tiles in groups whose weight slabs take ~2 MB (XP_H2_NGROUP overrides; 0 = plain N-fastest order)
+    {
+        static const int force_g = getenv("XP_H2_NGROUP") ? atoi(getenv("XP_H2_NGROUP")) : -1;
+        const int ntn128 = xp_cdiv(N, 128);
+        int g = 0;
+        if (p.mode == 0 && (int64_t)N * p.K * 4 > (2 << 20) && ntn128 > 2 && p.K <= 1024) {      // long K with few columns: the activations are the big operand — N-fastest shares them
+            const int gmax = (int)std::max<int64_t>(1, (int64_t)(2 << 20) / ((int64_t)128 * p.K * 4));
+            const int ngroups = xp_cdiv(ntn128, gmax);
+            g = ngroups > 1 ? xp_cdiv(ntn128, ngroups) : 0;                                        // balanced group widths
+        }
+        p.ngroup = force_g >= 0 ? force_g : g;
+    }
     static const int force = getenv("XP_H2_TILE") ? atoi(getenv("XP_H2_TILE")) : -1;   // tuning experiments only
     const int sel = force >= 0 ? force
                   : N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2
