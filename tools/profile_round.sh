@@ -26,4 +26,8 @@ GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1
 python3 $R/tools/scan_bench.py > $OUT/selective_scan_microbench.txt 2>&1
 python3 $R/tools/ss2d_bench.py 0 1 2>&1 | grep -v amdgpu > $OUT/ss2d_core_microbench.txt
 python3 $R/tools/enc_only.py 2>&1 | grep stream > $OUT/encoder_only_streams.txt
+# the headline line again with THIS run's PMC traffic in roofline.traffic (bench.py reads profiles/pmc_traffic.json)
+cp $OUT/bench.json $OUT/bench_before_pmc.json
+cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/hip_event_breakdown.txt
 cat $OUT/bench.json; head -12 $OUT/kernel_stats.csv | cut -c1-200; head -20 $OUT/pmc_hbm_traffic.txt
