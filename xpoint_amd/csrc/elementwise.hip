@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_silu_kernel(const float* __rest
     const int C4 = C >> 2;
     const int WG = (W + DW_PW - 1) / DW_PW, HG = (H + DW_PH - 1) / DW_PH;
     const int64_t total = (int64_t)B * HG * WG * C4;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order (workgroup ids go round-robin to the 8 XCDs, one L2 each): every XCD takes one contiguous run of blocks = a band of
+    // image rows, so the halo rows that vertically adjacent blocks share are fetched once per band, not once per block (144 -> MB per launch mix)
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = nb >> 3, r = nb & 7;
+    const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int64_t idx = (int64_t)blk * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c4 = (int)(idx % C4);
     const int64_t g = idx / C4;
