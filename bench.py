@@ -21,8 +21,6 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -53,6 +51,10 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (c2 = the headline; c4, c5: see CONFIGS)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is run this many times inside one invocation; `value` is the MEDIAN "
+                                                            "region (a single 20-step region is 0.1 s: +-5 % run to run); every region is listed in the line")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="unwrapped --gpus N > 1: seconds the parent waits for the child job before "
+                                                                          "killing its process group (exit code 124)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (roofline events are then taken in a separate eager pass)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra PCIe-inclusive pass (pcie_inclusive_pairs_per_s: images uploaded from pinned host memory and "
                                                           "keypoints / match lists downloaded every step; reported beside the headline, never as `value`)")
@@ -73,6 +75,7 @@ def parse():
 def cpu_baseline(n_pairs):
     """The oracle (CPU restatement: torch fp32 ops + C scan/NMS/matcher with OpenMP) timed on this host on a
     bounded sample of the same workload.  kind 'port': the reference's own Python path cannot travel here."""
+    import torch
     from oracle import xpoint_oracle as xo
     from xpoint_amd import synth
     cfg = synth.xpoint_exp1_config(H, W)
@@ -95,6 +98,37 @@ def cpu_baseline(n_pairs):
                       f"on 8 cores (BASELINE.md)"}
 
 
+def pmc_kernel_for_tag(tag, names):
+    """HIP-event tag of the library (csrc/*: XpProfScope) -> kernel name as rocprofv3 prints it (tools/pmc_summary.py `short`).  Raises KeyError
+    with the candidates when nothing (or more than one kernel) matches, so a renamed template shows up in the bench line instead of a null."""
+    import re
+    if "mlp_fused" in tag or tag.startswith("ln_proj"):
+        # (proj_)mlp_fused_{h2|x3}_c<C>, ln_proj_{h2|x3}_c<C>  <->  mlp_fused_kernel<C, NW, MODE, NP, H2>; MODE 0 = MLP, 1 = out_proj + MLP, 2 = LN + projection
+        m = re.match(r"(proj_mlp_fused|mlp_fused|ln_proj)_(h2|x3)_c(\d+)$", tag)
+        if not m:
+            raise KeyError(f"unrecognised fused-kernel tag {tag!r}")
+        mode = {"mlp_fused": 0, "proj_mlp_fused": 1, "ln_proj": 2}[m.group(1)]
+        pat = re.compile(rf"mlp_fused_kernel<{m.group(3)}, \d+, {mode}, \d+, {'true' if m.group(2) == 'h2' else 'false'}>$")
+    elif tag.startswith(("gemm", "conv3x3")):
+        m = re.match(r"(gemm|conv3x3)(_h2r|_h2|_x3|)_mfma_(\d+)x(\d+)$", tag)
+        if not m:
+            raise KeyError(f"unrecognised GEMM tag {tag!r}")
+        cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2", ("128", "32"): "4, 1, 1, 1"}
+        conv = 1 if m.group(1) == "conv3x3" else 0
+        eng = m.group(2)
+        if eng == "_h2r":         # row-stationary split-fp16 kernel: gemm_h2r_kernel<TN, MODE>
+            pat = re.compile(rf"gemm_h2r_kernel<{int(m.group(4)) // 32}, {conv}>$")
+        else:
+            base = {"_h2": "gemm_h2_kernel", "_x3": "gemm_x3_kernel", "": "gemm_kernel"}[eng]
+            pat = re.compile(rf"{base}<{cfgs[(m.group(3), m.group(4))]}, {conv}(, \d+)?>$")
+    else:
+        pat = re.compile(re.escape(tag) + r"(_kernel)?(<.*>)?$")
+    hits = [n for n in names if pat.search(n)]
+    if len(hits) != 1:
+        raise KeyError(f"tag {tag!r} matches {len(hits)} kernels of the PMC file (pattern {pat.pattern!r}; hits {hits[:4]})")
+    return hits[0]
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -104,18 +138,63 @@ def _free_port():
     return p
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT loading the HIP / HSA runtime (the parent of a multi-rank job must stay GPU-free: it is
+    never a rank).  KFD topology in sysfs: a node with simd_count > 0 is a GPU; the *_VISIBLE_DEVICES variables the runtime honours narrow it."""
+    import glob
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(prop):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+        except OSError:
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` outside torch.distributed.run: start the one-process-per-GPU job as a child.
-    Nothing here touches the GPU (torch.cuda.device_count() does not initialise HIP on this image) and nothing exec()s."""
+    """`python bench.py --gpus N` outside torch.distributed.run: start the one-process-per-GPU job as a CHILD process group.  The parent
+    never imports torch, never opens /dev/kfd, never exec()s; it counts GPUs from sysfs, forwards the child's output and exit code, and is
+    the job's watchdog: past --launch-timeout seconds (or on Ctrl-C) the whole process group is killed and the exit code is non-zero.
+    torch.distributed.run itself tears the other ranks down when the first one fails and returns that failure."""
+    import signal
     import subprocess
-    visible = torch.cuda.device_count()
+    visible = visible_gpus()
     if visible < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {visible} visible on this node\n")
         raise SystemExit(3)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)          # own process group: one killpg reaches the launcher and every rank
+
+    def kill_group(sig=signal.SIGTERM):
+        try:
+            os.killpg(child.pid, sig)
+        except ProcessLookupError:
+            pass
+    try:
+        rc = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank job did not finish within --launch-timeout {args.launch_timeout:.0f} s; killing its process group\n")
+        kill_group()
+        try:
+            child.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            kill_group(signal.SIGKILL)
+            child.wait()
+        raise SystemExit(124)
+    except KeyboardInterrupt:
+        kill_group()
+        child.wait()
+        raise SystemExit(130)
+    raise SystemExit(rc if rc >= 0 else 128 - rc)
 
 
 def main():
@@ -129,6 +208,8 @@ def main():
         args.graph = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    global torch
+    import torch
     # stdout carries exactly ONE line, the JSON: keep the real stdout for it and point fd 1 at stderr for everything else (RCCL prints its
     # version banner to stdout from C code when NCCL_DEBUG asks for it)
     json_out = os.fdopen(os.dup(1), "w")
@@ -170,6 +251,8 @@ def main():
     if dist.is_initialized():
         rccl["rccl_ranks"] = dist.get_world_size()
         rccl["weight_blob_mb"] = round(blob.numel() * 4 / 1e6, 1)
+        if xdist.last_first_broadcast_ms is not None:
+            rccl["weight_bcast_first_ms"] = round(xdist.last_first_broadcast_ms, 3)          # the job's first collective: includes RCCL's lazy set-up
         rccl["weight_bcast_ms"] = round(xdist.timed_broadcast(blob, src=0, repeats=5), 3)   # steady-state re-broadcasts of the same blob
 
     B = args.pairs
@@ -180,42 +263,20 @@ def main():
     overlap = not args.no_overlap
     CAP = conf["cap"]
     pred = dict(topk=conf["topk"])
-    sweeps = conf.get("nms_sweeps", 6)       # sweeps past the fixed point exit at once; 1024x1024 needs more than 480x640 (longer suppression chains)
+    sweeps = conf.get("nms_sweeps", 8)       # sweeps past the fixed point exit at once; 1024x1024 needs more than 480x640 (longer suppression chains)
     pipe = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, overlap=overlap, split_encoder=args.split_encoder,
                         estimate_homography=args.register, alternate_encoders=(int(os.environ.get("XP_BENCH_DEPTH", "2")) if not args.no_alternate and args.split_encoder in (0, 1) else 0))
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
     pipe1 = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, estimate_homography=args.register) if overlap else pipe
     # config c5: the homography-regression head on the 256x256 crops (a second, small forward through the same encoder weights)
-    hm_step = None
+    net_hm = None
     if args.config == "c5":
         cfg_hm = synth.xpoint_exp1_config(256, 256, hm_head=True)
         net_hm = models.XPoint(cfg_hm).eval()
         net_hm.gemm_mode = args.gemm
         net_hm.load_state_dict(synth.make_torch_state_dict(cfg_hm), strict=True)
         net_hm.to(dev)
-        hm_out = {}
-
-        crop_o = torch.empty((B, 1, 256, 256), device=dev); crop_t = torch.empty((B, 1, 256, 256), device=dev)
-        hm_graph = {}
-
-        def hm_step(o_img, t_img):
-            # the crops are cut outside the graph (their source alternates between the pipeline's input buffers); the head's forward replays
-            # from a hipGraph once captured (--graph)
-            crop_o.copy_(o_img[:, :, :256, :256]); crop_t.copy_(t_img[:, :, :256, :256])
-            if "g" in hm_graph:
-                hm_graph["g"].replay()
-            else:
-                hm_out["hm"] = net_hm.predict_homography(crop_o, crop_t)
-
-        def hm_capture():
-            for _ in range(2):
-                hm_step(opt, thr)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                hm_out["hm"] = net_hm.predict_homography(crop_o, crop_t)
-            hm_graph["g"] = g
         pin_o, pin_t = opt.cpu().pin_memory(), thr.cpu().pin_memory()
 
     def sync_all():
@@ -255,26 +316,22 @@ def main():
             for _ in range(3):
                 pipe1.run(opt, thr, mo, mt)
             torch.cuda.synchronize(); lib.xp_prof_enable(0)
-            replay = pipe.capture(opt, thr, mo, mt)
             if args.config == "c5":
-                hm_capture()
-                hm_host = [None, None]; hm_ev = [torch.cuda.Event(), torch.cuda.Event()]; pending = []
+                # streaming step (xpoint_amd/streaming.py; tests/test_gpu_configs.py checks the same object against the reference fixtures): images
+                # from pinned host memory straight into the batch buffers, graphs replayed, RegNet head on the 256x256 crops from its own graph,
+                # result lists + hm downloaded behind the step; the host consumes step i-1's results while step i runs
+                from xpoint_amd.streaming import StreamingRegistrationStep
+                sstep = StreamingRegistrationStep(pipe, net_hm, opt, thr, mo, mt)
+                pending = []
 
                 def step():
-                    # streaming step: the images arrive from pinned host memory (uploaded straight into the batch buffers), the step's result
-                    # lists go back to pinned host buffers behind its last kernel; the host consumes step i-1's results while step i runs
-                    replay(pin_o, pin_t, mo, mt)
-                    hm_step(pipe.images[:B], pipe.images[B:])
-                    j = len(pending) & 1
-                    if hm_host[j] is None:
-                        hm_host[j] = torch.empty(hm_out["hm"].shape, dtype=hm_out["hm"].dtype).pin_memory()
-                    hm_host[j].copy_(hm_out["hm"], non_blocking=True); hm_ev[j].record()
-                    bufs, ev = pipe.download_async()
+                    bufs, ev, hm_host, hm_ev = sstep(pin_o, pin_t, mo, mt)
                     if pending:
                         pev, phm = pending[-1]
                         pev.synchronize(); phm.synchronize()              # results of the step before are on the host
-                    pending.append((ev, hm_ev[j]))
+                    pending.append((ev, hm_ev))
             else:
+                replay = pipe.capture(opt, thr, mo, mt)
                 step = lambda: replay(opt, thr, mo, mt)
             for _ in range(2):
                 step()
@@ -292,15 +349,23 @@ def main():
             step = lambda: pipe.run(opt, thr, mo, mt)
             # timed region: only the dominant kernel's launches carry events (on their launch stream)
             lib.xp_prof_reset(); lib.xp_prof_filter(dominant.encode()); lib.xp_prof_enable(1)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        dt = time.perf_counter() - t0
+        # the timed region: K steps bracketed by barrier + synchronize on both sides, run `--regions` times back to back; the line reports the
+        # MEDIAN region (max over ranks per region) and lists them all.  steps = K stays what one region times.
+        region_dt = []
+        for _ in range(max(1, args.regions)):
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync_all()
+            region_dt.append(time.perf_counter() - t0)
         lib.xp_prof_enable(0)
         dom = [r for r in prof_table() if r["tag"] == dominant][0]
         pipe.verify()
+        if args.config != "c2" or world > 1:
+            args.no_other_backend = True        # the extra passes (other back ends, precision classes, PCIe-inclusive) are single-GPU records: an N-rank run stays short
+        if world > 1:
+            args.no_h2d = True
         # the same K steps on ONE stream (no cross-step overlap), for the record
         single_rate = None
         if overlap and not args.no_other_backend:
@@ -318,8 +383,6 @@ def main():
         other_rate = None
         class_rates = {}
         f32_rate = None
-        if args.config != "c2":
-            args.no_other_backend = True
         if not args.graph and not args.no_other_backend:
             net.gemm_mode = other
             for _ in range(2):
@@ -371,10 +434,14 @@ def main():
             sync_all()
             pcie = world * B * args.steps / (time.perf_counter() - t1)
     res = pipe.fetch()
+    per_rank = xdist.gather_floats(region_dt, device=dev) if dist.is_initialized() else [region_dt]
+    # region r of the job = its slowest rank; the reported region = the median one
+    job_dt = [max(per_rank[k][r] for k in range(len(per_rank))) for r in range(len(region_dt))]
+    order = sorted(range(len(job_dt)), key=lambda r: job_dt[r])
+    med = order[(len(order) - 1) // 2]
+    dt = job_dt[med]
+    rank_rates = [B * args.steps / per_rank[k][med] for k in range(len(per_rank))]
     if dist.is_initialized():
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # fixed-size result headers of every rank's last step, all-gathered (the only other collective)
         hdr = xdist.gather_headers(first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res),
                                    sum(len(r["match_q"]) for r in res), device=dev)
@@ -400,22 +467,25 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 3)}
-        # HBM traffic of that kernel from the committed rocprofv3 PMC run (cannot be collected from inside this process)
+        # HBM traffic and MFMA-busy fraction of that kernel from the committed rocprofv3 PMC runs (counters cannot be collected from inside this
+        # process).  A tag that matches no kernel of the PMC files is reported in the line (traffic_error), never swallowed.
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            if "mlp_fused" in dominant:     # tag (proj_)mlp_fused_x3_c<C>  <->  mlp_fused_kernel<C, 4, PRE>
-                kname = f"mlp_fused_kernel<{dominant.rsplit('_c', 1)[1]}, 4, {'true' if dominant.startswith('proj_') else 'false'}, 6>"
-                roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
-            else:
-                tiles = dominant.rsplit("_", 1)[1].split("x")
-                cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2",
-                        ("128", "32"): "4, 1, 1, 1"}
-                kname = (f"{'gemm_h2_kernel' if '_h2_' in dominant else 'gemm_x3_kernel' if '_x3_' in dominant else 'gemm_kernel'}<{cfgs[tuple(tiles)]}, "
-                         f"{1 if dominant.startswith('conv3x3') else 0}" + (", 6>" if "_x3_" in dominant else ">"))
-                roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
+            kname = pmc_kernel_for_tag(dominant, list(pmc))
+            roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
+            roof["traffic_kernel"] = kname
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
-        except Exception:
-            pass
+        except Exception as e:
+            roof["traffic_error"] = f"{type(e).__name__}: {e}"
+            sys.stderr.write(f"bench.py: roofline.traffic unavailable for {dominant}: {e}\n")
+        try:
+            mf = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))["kernels"]
+            kname = pmc_kernel_for_tag(dominant, list(mf))
+            roof["frac_mfma_busy_pmc"] = round(mf[kname]["mfma_busy_frac"], 4)
+            roof["frac_mfma_busy_pmc_source"] = "profiles/pmc_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), tools/mfma_util.sh)"
+        except Exception as e:
+            if roof["bound"] == "mfma":
+                roof["frac_mfma_busy_pmc_error"] = f"{type(e).__name__}: {e}"
         roof.update({"avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom["launches"]})
         if overlap or args.graph:
             roof["measured_in"] = ("3 single-stream eager passes of the same step next to the timed region: " +
@@ -453,6 +523,10 @@ def main():
                        "keypoints_per_image_mean": round(sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res) / (2 * len(res)), 1),
                        "matches_per_pair_mean": round(sum(len(r["match_q"]) for r in res) / len(res), 1)},
             "roofline": roof,
+            "timed_regions": {"count": len(job_dt), "reported": "median", "pairs_per_s": [round(world * B * args.steps / t, 2) for t in job_dt],
+                              "note": f"{len(job_dt)} regions of K = {args.steps} steps each (barrier + synchronize on both sides, max over ranks), back to back in this invocation"},
+            "per_rank_pairs_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2),
+                                     "note": "each rank's own pairs/s in the reported region (its own clock between the same barriers)"},
         }
         out.update(rccl)
         # the other large kernels of the step, each against its own bound (from the untimed single-stream breakdown pass; the

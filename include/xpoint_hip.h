@@ -99,16 +99,18 @@ int xp_gemm_nt_x3(const float* A, const void* Wx3, float* C, const float* bias, 
 int xp_conv3x3_nhwc_x3(const float* x, const void* Wx3, float* y, const float* bias, const float* scale,
                        const float* shift, int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad,
                        int act, void* stream);
-/* fp32-grade variants on the f16 matrix pipe ("h2": every f32 operand is written as the sum of two fp16 values, which
- * reproduces it to 2^-24 relative — half an f32 ulp; three fp16 MFMA partial products per multiply, f32 accumulate: per
- * product about one f32 rounding, i.e. the error class of the f32 FMA chain the reference computes (csrc/gemm_h2_core.h,
- * DESIGN.md §3c) at half the matrix work of the "x3" kernels).  Same semantics, epilogue and reference call sites as
+/* fp32-grade variants on the f16 matrix pipe ("h2": every f32 operand is written as the sum of two fp16 values h0 + h1, which
+ * reproduces it to 2^-23 relative in the worst case (fp16 has an 11-bit significand: |x - h0| <= 2^-11 |x|, and the 12-bit remainder
+ * loses at most one bit in h1), 2^-25.5 on average; three fp16 MFMA partial products per multiply (a0 b0 + a0 b1 + a1 b0; the dropped
+ * a1 b1 <= 2^-22 |ab|), f32 accumulate: per product <= 2^-21 |ab| worst case, ~2^-25 typical — the error class of the f32 FMA chain the
+ * reference computes (csrc/gemm_h2_core.h) at half the matrix work of the "x3" kernels, which are exact to 2^-24 per operand).
+ * Same semantics, epilogue and reference call sites as
  * xp_gemm_nt / xp_conv3x3_nhwc (VMamba.py:649,663 in/out_proj; :110-128 Mlp; :605 x_proj; :1405-1440 convs;
  * XPoint.py:112-138 head convs).  The weight matrix is passed pre-split: xp_split_weights_h2 converts a row-major (N, K) f32
  * matrix into xp_split_weights_h2_bytes(N, K) bytes — slab-major fp16 planes of the rows scaled by a power of two each
  * (largest element in [2^13, 2^14): keeps the low plane out of fp16's subnormal range) followed by the N inverse scales,
- * which the epilogue applies exactly.  Activations are split unscaled: |A| must stay below 65504 (fp16 range; LayerNorm /
- * GELU / SiLU outputs are O(1)); elements below 2^-3 carry an absolute error <= 2^-25. */
+ * which the epilogue applies exactly.  Activations are split unscaled: |A| must stay below 65504 (fp16 range; see
+ * xp_xpoint_forward_ex for the guard); elements below 2^-3 carry an absolute error <= 2^-25. */
 size_t xp_split_weights_h2_bytes(int N, int K);
 int xp_split_weights_h2(const float* W, void* out, int N, int K, void* stream);
 int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const float* bias, const float* scale, const float* shift,
@@ -231,12 +233,23 @@ int xp_prepare_split_weights(void* ctx, const float* weights, void* wsplit, size
  * wsplit: the buffer prepared by xp_prepare_split_weights -> dense layers run on xp_gemm_nt_x3 / xp_conv3x3_nhwc_x3;
  * NULL -> they run on the exact-f32 MFMA kernels (xp_gemm_nt / xp_conv3x3_nhwc).  Same results to f32 rounding.
  * With the split-fp16 engine selected (xp_set_dense_engine(1), the default of the Python host) every dense-layer INPUT must stay
- * below 65504 in magnitude; beyond it the products turn into NaN, and because the heads apply ReLU (max(NaN, 0) = 0 on the GPU) `prob`
- * then looks finite.  Callers should test enc_nhwc for non-finite values after the first forward on new weights (the Python host
- * does: models.XPoint, PairPipeline.verify) and fall back to engine 0 (split-bf16: no range limit). */
+ * below 65504 in magnitude; beyond it that layer's output rows turn into NaN, and because the heads apply ReLU (max(NaN, 0) = 0 on the
+ * GPU) `prob` may then look finite.  xp_xpoint_forward_ex reports it: `status` (device int, caller-zeroed, may be NULL) receives, OR-ed in by
+ * the kernels that write the outputs anyway (no extra pass, no host synchronisation):
+ *   XP_STATUS_ENC  (1)  the encoder output (= the residual stream every dense layer of the encoder writes into, and the operand of the head
+ *                       convolution) holds a non-finite element, or — split-fp16 engine only — one with |x| >= 65504
+ *   XP_STATUS_PROB (2)  a heat-map cell had a non-finite logit        XP_STATUS_DESC (4)  a descriptor row had a non-finite element
+ * A caller that reads a non-zero status re-runs the forward on engine 0 (split-bf16: no range limit) — the Python host does so
+ * automatically and stays on that engine for the weight set (models.XPoint, PairPipeline.verify). */
 int xp_xpoint_forward(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
                       void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
                       float* logits_nhwc, void* stream);
+#define XP_STATUS_ENC 1
+#define XP_STATUS_PROB 2
+#define XP_STATUS_DESC 4
+int xp_xpoint_forward_ex(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
+                         void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
+                         float* logits_nhwc, int* status, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Post-processing.

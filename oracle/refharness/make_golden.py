@@ -156,6 +156,124 @@ def gen_g15(n_pairs=8):
     np.savez_compressed(os.path.join(OUT, "g15_c2_batch8.npz"), **g)
 
 
+def _ref_pair_flow(net, ref_utils, i, H, W, thr=0.015, nms=8, topk=0):
+    """The reference's pair flow (predict_align_image_pair.py:185-260) for synthetic pair i: forward -> prob * mask -> box_nms ->
+    nonzero -> interpolate_descriptors -> NNMatcher.  Returns (kp_optical, kp_thermal, matches (M, 2), match distances)."""
+    data = synth.to_torch(synth.make_pair_batch(i, 1, H, W))
+    with torch.no_grad():
+        o, t, _ = net(data)
+    kps, descs = [], []
+    for spec, r in (("optical", o), ("thermal", t)):
+        pn = ref_utils.box_nms(r["prob"] * data[spec]["valid_mask"], nms, thr, keep_top_k=topk, on_cpu=True)
+        kp = torch.nonzero((pn[0].squeeze() > thr).float())
+        kps.append(kp)
+        descs.append(ref_utils.interpolate_descriptors(kp, r["desc"][0], H, W))
+    ms = ref_utils.get_matches(descs[0].numpy(), descs[1].numpy(), "nnmatcher", False, threshold=10.0)
+    return (kps[0].numpy().astype(np.int16), kps[1].numpy().astype(np.int16),
+            np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int16).reshape(-1, 2),
+            np.array([m.distance for m in ms], dtype=np.float32))
+
+
+def gen_g18_part(first, last, out_path):
+    """One shard of G18 (pairs first..last-1 of BASELINE config C3's 64-pair batch) through the REAL reference; run several shards as
+    separate single-thread processes, then `g18merge`."""
+    import zlib
+    torch.set_num_threads(1)
+    stubs.install()
+    import xpoint.utils as ref_utils
+    H, W = 480, 640
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = build_ref.build_reference_xpoint(cfg, synth.make_state_dict(cfg))
+    g = {}
+    for i in range(first, last):
+        ko, kt, m, d = _ref_pair_flow(net, ref_utils, i, H, W)
+        g[f"p{i}/kp_optical"] = ko; g[f"p{i}/kp_thermal"] = kt; g[f"p{i}/matches"] = m; g[f"p{i}/match_dist"] = d
+        print("g18 pair", i, "kpts", len(ko), len(kt), "matches", len(m), flush=True)
+    np.savez_compressed(out_path, **g)
+
+
+def gen_g18_merge(parts):
+    """G18 — BASELINE config C3 (batch 64 = 8 pairs per GPU on 8 GPUs): pairs 8..63, i.e. the shards of ranks 1..7 (rank 0's shard is G15),
+    end to end through the REAL reference exactly as G15.  Stored: keypoint lists, match index pairs and distances (for the near-tie
+    attribution of tests/parity.py) and a header table per pair [n_kp_optical, n_kp_thermal, n_matches, crc32(kp_optical), crc32(kp_thermal),
+    crc32(matches)] (crc32 of the int16 little-endian C-order bytes) — what a rank's result header is checked against."""
+    import zlib
+    g = {}
+    for p in parts:
+        z = np.load(p)
+        for k in z.files:
+            g[k] = z[k]
+    pairs = sorted({int(k.split("/")[0][1:]) for k in g})
+    hdr = np.zeros((len(pairs), 7), dtype=np.int64)
+    for r, i in enumerate(pairs):
+        ko, kt, m = g[f"p{i}/kp_optical"], g[f"p{i}/kp_thermal"], g[f"p{i}/matches"]
+        hdr[r] = [i, len(ko), len(kt), len(m), zlib.crc32(np.ascontiguousarray(ko).astype("<i2").tobytes()),
+                  zlib.crc32(np.ascontiguousarray(kt).astype("<i2").tobytes()), zlib.crc32(np.ascontiguousarray(m).astype("<i2").tobytes())]
+    g["header"] = hdr
+    g["meta"] = np.array([pairs[0], pairs[-1] + 1, 480, 640], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "g18_c3_pairs8to63.npz"), **g)
+    print("g18:", len(pairs), "pairs", pairs[0], "..", pairs[-1], "keypoints", int(hdr[:, 1:3].sum()), "matches", int(hdr[:, 3].sum()))
+
+
+def gen_g21():
+    """G21 — BASELINE config C5's homography-regression head through the REAL reference: the RegNet head (RegNet.py:7-52) is only defined for
+    256x256 inputs, so C5 runs it on the 256x256 top-left crop of every 480x640 pair (bench.py --config c5).  The reference model with
+    homography_regression_head.check on the crops of synthetic pairs 0..7 (the pairs of G15): hm (8, 8) and the encoder maps' sums."""
+    torch.set_num_threads(1)
+    stubs.install()
+    cfg = synth.xpoint_exp1_config(256, 256, hm_head=True)
+    net = build_ref.build_reference_xpoint(cfg, synth.make_state_dict(cfg))
+    g = {"meta": np.array([8, 480, 640, 256], dtype=np.int32)}
+    hms = []
+    for i in range(8):
+        data = synth.to_torch(synth.make_pair_batch(i, 1, 480, 640))
+        for spec in ("optical", "thermal"):
+            data[spec]["image"] = data[spec]["image"][:, :, :256, :256].contiguous()
+            data[spec]["valid_mask"] = data[spec]["valid_mask"][:, :, :256, :256].contiguous()
+        with torch.no_grad():
+            o, t, hm = net(data)
+        hms.append(hm.numpy().reshape(-1))
+        g[f"p{i}/enc_sum"] = np.array([o["encoder_output"].double().sum().item(), t["encoder_output"].double().sum().item()])
+        print("g21 pair", i, "hm", hms[-1], flush=True)
+    g["hm"] = np.stack(hms).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g21_c5_hm.npz"), **g)
+
+
+def gen_g19():
+    """G19 — trained-like statistics through the REAL reference: synth.make_trained_like_state_dict (LayerNorm gains
+    log-uniform 0.0625..16, 1 % outlier channels x100 in the patch-embed / downsample convolutions and the residual writers, dt bias at both ends
+    of its range; the residual stream reaches ~1.5e3 and goes un-normalised into the downsample convolutions and the heads,
+    VMamba.py:1405-1440,1500-1505) at 224x320 on a plain pair and on a pair at the contrast extremes (synth.make_contrast_pair).
+    Stored per case: prob (both images), desc (optical full, thermal strided), encoder-output extrema, and the end-to-end lists of the
+    reference's flow (box_nms(8, 0.015) -> nonzero -> interpolate_descriptors -> NNMatcher)."""
+    torch.set_num_threads(1)
+    stubs.install()
+    import xpoint.utils as ref_utils
+    H, W = 224, 320
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = build_ref.build_reference_xpoint(cfg, synth.make_trained_like_state_dict(cfg))
+    g = {"meta": np.array([2, H, W], dtype=np.int32)}
+    for c, data in enumerate((synth.make_pair_batch(0, 1, H, W), synth.make_contrast_pair(1, H, W))):
+        data = synth.to_torch(data)
+        with torch.no_grad():
+            o, t, _ = net(data)
+        kps, descs = [], []
+        for spec, r in (("optical", o), ("thermal", t)):
+            g[f"c{c}/{spec}/prob"] = r["prob"].numpy()
+            g[f"c{c}/{spec}/desc"] = r["desc"].numpy() if spec == "optical" else r["desc"][:, :, ::2, ::2].numpy()
+            g[f"c{c}/{spec}/enc_absmax"] = np.array([float(r["encoder_output"].abs().max())])
+            pn = ref_utils.box_nms(r["prob"] * data[spec]["valid_mask"], 8, 0.015, keep_top_k=0, on_cpu=True)
+            kp = torch.nonzero((pn[0].squeeze() > 0.015).float())
+            kps.append(kp)
+            descs.append(ref_utils.interpolate_descriptors(kp, r["desc"][0], H, W))
+            g[f"c{c}/kp_{spec}"] = kp.numpy().astype(np.int16)
+        ms = ref_utils.get_matches(descs[0].numpy(), descs[1].numpy(), "nnmatcher", False, threshold=10.0)
+        g[f"c{c}/matches"] = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int16).reshape(-1, 2)
+        print("g19 case", c, "enc absmax", float(o["encoder_output"].abs().max()), "pmax", float(o["prob"].max()), "kpts", len(kps[0]), len(kps[1]),
+              "matches", len(ms), flush=True)
+    np.savez_compressed(os.path.join(OUT, "g19_trained_like.npz"), **g)
+
+
 def gen_g16():
     """G16 — BASELINE config C4 through the REAL reference: one synthetic 1024x1024 pair, box_nms(8, 0.015, keep_top_k=4096),
     nonzero, interpolate_descriptors, NNMatcher (strict mutual NN): the 4k x 4k x 256 match.  Keypoints, their scores, match
@@ -386,4 +504,11 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # one generator: python -m oracle.refharness.make_golden g18part 8 22 /tmp/g18_a.npz | g18merge a.npz b.npz | g19 ...
+        cmd, rest = sys.argv[1], sys.argv[2:]
+        if cmd == "g18part":
+            sys.exit(gen_g18_part(int(rest[0]), int(rest[1]), rest[2]))
+        if cmd == "g18merge":
+            sys.exit(gen_g18_merge(rest))
+        sys.exit(globals()["gen_" + cmd](*rest))
     sys.exit(main())

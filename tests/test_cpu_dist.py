@@ -42,6 +42,49 @@ def test_bench_self_launch_refuses_missing_gpus():
     assert f"needs {n} GPUs" in r.stderr
 
 
+def test_bench_parent_stays_gpu_free_and_watchdog_kills_the_group(tmp_path):
+    """The parent of an unwrapped `bench.py --gpus N` must never load the HIP / HSA runtime: it counts GPUs from the KFD
+    topology in sysfs, does not even import torch (checked with -X importtime), answers in well under 2 s, honours *_VISIBLE_DEVICES; and its
+    watchdog kills the child's whole process group on --launch-timeout (exit 124) — exercised with a stand-in child that sleeps."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 3 and time.perf_counter() - t0 < 2.0
+    assert "torch" not in r.stderr.replace("torch.distributed.run", "")            # no torch import in the parent (importtime lists every import)
+    sys.path.insert(0, root)
+    import importlib
+    bench = importlib.import_module("bench")
+    os.environ["ROCR_VISIBLE_DEVICES"] = ""
+    try:
+        assert bench.visible_gpus() == 0
+    finally:
+        del os.environ["ROCR_VISIBLE_DEVICES"]
+    # watchdog: make the "launcher" a sleeping python by pointing sys.executable's module at a stub through PYTHONPATH
+    stub = tmp_path / "torch" / "distributed"
+    stub.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (stub / "__init__.py").write_text("")
+    (stub / "run.py").write_text("import time, os\nopen(os.environ['XP_STUB_PID'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    code = ("import sys, types; sys.argv = ['bench.py', '--gpus', '2', '--launch-timeout', '2']; sys.path.insert(0, %r); import bench; "
+            "bench.visible_gpus = lambda: 2; bench.main()" % root)
+    env2 = dict(env, PYTHONPATH=str(tmp_path), XP_STUB_PID=str(tmp_path / "pid"))
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env2, timeout=60)
+    assert r.returncode == 124, (r.returncode, r.stderr[-400:])
+    assert time.perf_counter() - t0 < 30 and "killing its process group" in r.stderr
+    pid = int((tmp_path / "pid").read_text())
+    time.sleep(0.5)
+    alive = False
+    if os.path.exists(f"/proc/{pid}/status"):
+        state = open(f"/proc/{pid}/status").read().split("State:")[1].split()[0]
+        alive = state not in ("Z", "X")
+    assert not alive, "the child of the timed-out job is still running"
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 

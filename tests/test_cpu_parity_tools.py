@@ -113,3 +113,52 @@ def test_gray_conversion_fixture(golden):
     assert np.array_equal(rgb_to_gray_u8(g["rgb"][None])[0], g["gray"])
     assert np.array_equal(gray_lut()[g["gray"]], g["value"]) and np.array_equal(xo.gray_to_float(g["gray"]), g["value"])
     assert np.array_equal(g["gray"][:256], np.arange(256))                      # r = g = b -> the grey level itself
+
+
+def test_oracle_vs_round3_reference_fixtures(golden):
+    """The CPU oracle against the round-3 fixtures of the REAL reference: one pair of g18 (C3: pairs 8..63; pair 37 = rank 4's shard) end to end,
+    the trained-like weight set g19 (both cases: prob / desc to 1e-5, the oracle equals the reference bit for bit at one thread) and the
+    RegNet head on the C5 crops (g21, two pairs)."""
+    import zlib
+    g18, g19, g21 = golden("g18_c3_pairs8to63.npz"), golden("g19_trained_like.npz"), golden("g21_c5_hm.npz")
+    # --- g18: header table consistent, one pair reproduced
+    hdr = {int(r[0]): r for r in g18["header"]}
+    assert sorted(hdr) == list(range(8, 64))
+    for i in (8, 37, 63):
+        assert int(hdr[i][6]) == zlib.crc32(np.ascontiguousarray(g18[f"p{i}/matches"]).astype("<i2").tobytes())
+    H, W = 480, 640
+    cfg = synth.xpoint_exp1_config(H, W)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}
+    with torch.no_grad():
+        res, (o, t, _), _ = xo.predict_align_image_pair(synth.to_torch(synth.make_pair_batch(37, 1, H, W)), sd)
+    for spec, out in (("optical", o), ("thermal", t)):
+        rep, bad = parity.explain_keypoint_diff(res[0][f"kp_{spec}"].numpy(), g18[f"p37/kp_{spec}"], out["prob"][0, 0].numpy(), 0.015, 8, tol=1e-5)
+        assert not bad, parity.format_report(spec, rep)
+        assert len(rep) <= 4
+    # --- g19: trained-like statistics
+    _, H, W = [int(v) for v in g19["meta"]]
+    cfg = synth.xpoint_exp1_config(H, W)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_trained_like_state_dict(cfg).items()}
+    ln = sd["encoder.layers.0.blocks.0.norm.weight"]
+    assert float(ln.min()) < 0.1 and float(ln.max()) > 10.0                        # heavy-tailed gains
+    for c, dnp in enumerate((synth.make_pair_batch(0, 1, H, W), synth.make_contrast_pair(1, H, W))):
+        with torch.no_grad():
+            res, (o, t, _), _ = xo.predict_align_image_pair(synth.to_torch(dnp), sd)
+        for spec, out in (("optical", o), ("thermal", t)):
+            assert float(out["encoder_output"].abs().max()) > 500.0
+            assert abs(float(out["encoder_output"].abs().max()) - float(g19[f"c{c}/{spec}/enc_absmax"][0])) < 1e-2
+            assert float(np.abs(out["prob"].numpy() - g19[f"c{c}/{spec}/prob"]).max()) < 2e-5
+            d = out["desc"].numpy()
+            assert float(np.abs((d if spec == "optical" else d[:, :, ::2, ::2]) - g19[f"c{c}/{spec}/desc"]).max()) < 2e-5
+            rep, bad = parity.explain_keypoint_diff(res[0][f"kp_{spec}"].numpy(), g19[f"c{c}/kp_{spec}"], out["prob"][0, 0].numpy(), 0.015, 8, tol=2e-5)
+            assert not bad, parity.format_report(f"g19 c{c} {spec}", rep)
+    # --- g21: RegNet head on the 256x256 crops of the C5 pairs
+    cfg = synth.xpoint_exp1_config(256, 256, hm_head=True)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}
+    for i in (0, 5):
+        data = synth.to_torch(synth.make_pair_batch(i, 1, 480, 640))
+        for spec in ("optical", "thermal"):
+            data[spec]["image"] = data[spec]["image"][:, :, :256, :256].contiguous()
+        with torch.no_grad():
+            _, _, hm = xo.xpoint_forward(data, sd, hm_head=True)
+        assert float(np.abs(hm.numpy().reshape(-1) - g21["hm"][i]).max()) < 1e-5

@@ -105,3 +105,52 @@ def test_regnet_head_256(gpu_lib, golden):
     assert torch.equal(hm3, hm2)
     with pytest.raises(RuntimeError):                                          # 480x640: the reference fails too
         regnet_forward(w, torch.zeros(1, 60, 80, 48, device="cuda"), torch.zeros(1, 60, 80, 48, device="cuda"))
+
+
+def test_regnet_adaptive_pool_generalisation(gpu_lib, golden):
+    """Opt-in generalisation of the RegNet head beyond 256x256 (NOT reference semantics — the reference's head only accepts
+    256x256, RegNet.py:38-52): the pooled cost-volume map is adaptive-average-pooled to the 16x16 grid of the FC layer.  (1) At 256x256 it
+    IS the reference (g9, bit-identical to the default path); (2) at 480x640 and 224x320 it equals a torch restatement — RegNet.forward with
+    F.adaptive_avg_pool2d on the (H'/2, W'/2) map — of the same weights; (3) models.XPoint.forward carries it (regnet_adaptive_pool)."""
+    import torch.nn.functional as F
+    from xpoint_amd import models
+    from xpoint_amd.convmodels import regnet_forward, regnet_weights
+    g = golden("g9_regnet.npz")
+    cfg = synth.xpoint_exp1_config(256, 256, hm_head=True)
+    sd = synth.make_torch_state_dict(cfg)
+    w = regnet_weights(sd, torch.device("cuda"))
+    e1 = torch.from_numpy(g["enc_optical"]).permute(0, 2, 3, 1).contiguous().cuda()
+    e2 = torch.from_numpy(g["enc_thermal"]).permute(0, 2, 3, 1).contiguous().cuda()
+    assert torch.equal(regnet_forward(w, e1, e2, adaptive_pool=True), regnet_forward(w, e1, e2))
+    assert float(np.abs(regnet_forward(w, e1, e2, adaptive_pool=True).cpu().numpy() - g["hm"]).max()) < TOL
+
+    def torch_head(x1, x2):          # RegNet.forward in fp64 with the pooling step added (x: (B, 48, H', W'))
+        p = "hm_regressor."
+        def layer1(x):
+            for c, b in (("layer1.0", "layer1.1"), ("layer1.3", "layer1.4")):
+                x = F.conv2d(x, sd[p + c + ".weight"].double(), None, padding=1)
+                x = F.batch_norm(x, sd[p + b + ".running_mean"].double(), sd[p + b + ".running_var"].double(), sd[p + b + ".weight"].double(),
+                                 sd[p + b + ".bias"].double(), False, 0.0, 1e-5)
+                x = F.relu(x)
+            return F.max_pool2d(x, 2, 2)
+        a, b = layer1(x1), layer1(x2)
+        N, C, Hh, Wh = a.shape
+        cv = torch.bmm(F.normalize(a).reshape(N, C, Hh * Wh).transpose(1, 2), F.normalize(b).reshape(N, C, Hh * Wh)).reshape(N, Hh * Wh, Hh, Wh)
+        v = F.adaptive_avg_pool2d(cv, (1, 1)).view(N, 1, Hh, Wh)
+        v = F.adaptive_avg_pool2d(v, (16, 16)).reshape(N, 256)
+        h = F.relu(F.linear(v, sd[p + "fc.1.weight"].double(), sd[p + "fc.1.bias"].double()))
+        return F.linear(h, sd[p + "fc.4.weight"].double(), sd[p + "fc.4.bias"].double())
+    for (Hc, Wc) in ((60, 80), (28, 40)):
+        x1 = torch.from_numpy(synth.uniform(f"rg/a{Hc}", (2, 48, Hc, Wc), -1.0, 1.0)); x2 = torch.from_numpy(synth.uniform(f"rg/b{Hc}", (2, 48, Hc, Wc), -1.0, 1.0))
+        ref = torch_head(x1.double(), x2.double())
+        got = regnet_forward(w, x1.permute(0, 2, 3, 1).contiguous().cuda(), x2.permute(0, 2, 3, 1).contiguous().cuda(), adaptive_pool=True)
+        assert got.shape == (2, 8) and float((got.cpu().double() - ref).abs().max()) < 2e-5
+    cfg2 = synth.xpoint_exp1_config(224, 320, hm_head=True)
+    net = models.XPoint(cfg2); net.load_state_dict(synth.make_torch_state_dict(cfg2), strict=True); net.to("cuda").eval()
+    d = synth.to_torch(synth.make_pair_batch(2, 1, 224, 320), "cuda")
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            net(d)                                           # default: the reference's behaviour (shape error)
+        net.regnet_adaptive_pool = True
+        _, _, hm = net(d)
+    assert hm.shape == (1, 8) and bool(torch.isfinite(hm).all())

@@ -1,0 +1,174 @@
+"""At-size GPU tests of the BASELINE configurations that had no `-m gpu` evidence:
+  C5  streaming, hipGraph-replayed 480x640 step with the RegNet head on 256x256 crops — the object bench.py --config c5 times —
+      against the REAL reference's fixtures g15 (keypoints / mutual-NN pairs of pairs 0..7) and g21 (hm on the crops);
+  C3  the 64-pair batch sharded 8 pairs per rank: ranks 0..7 rehearsed sequentially on ONE GPU, every rank's shard against
+      g15 (rank 0) / g18 (ranks 1..7: pairs 8..63 through the real reference) and every result header against the fixture's table."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from xpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+H, W, B = 480, 640, 8
+
+
+def _net(cfg):
+    from xpoint_amd import models
+    net = models.XPoint(cfg)
+    net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
+    return net.to("cuda").eval()
+
+
+def _check_pair_lists(i_ref, kp_o, kp_t, mq, mt, g, prob_o, prob_t, vol_o, vol_t, lines):
+    """One pair's lists against the reference fixture (identity; differing elements attributed one by one, tests/parity.py).
+    Returns (n_kp, n_kp_diff, n_m, n_m_diff)."""
+    from tests import parity
+    from xpoint_amd import utils
+    kp_m = {"optical": np.asarray(kp_o, dtype=np.int64).reshape(-1, 2), "thermal": np.asarray(kp_t, dtype=np.int64).reshape(-1, 2)}
+    prob = {"optical": prob_o, "thermal": prob_t}
+    n_kp = n_kp_diff = 0
+    for spec in ("optical", "thermal"):
+        ref = g[f"p{i_ref}/kp_{spec}"].astype(np.int64)
+        n_kp += len(ref)
+        if np.array_equal(kp_m[spec], ref):
+            continue
+        rep, bad = parity.explain_keypoint_diff(kp_m[spec], ref, prob[spec].cpu().numpy(), 0.015, 8, tol=TOL)
+        n_kp_diff += len(rep)
+        lines.append(parity.format_report(f"pair {i_ref} {spec} keypoints", rep))
+        assert not bad, parity.format_report(f"pair {i_ref} {spec}: UNEXPLAINED keypoint differences", bad)
+    mine = np.stack([np.asarray(mq), np.asarray(mt)], 1).astype(np.int64)
+    ref_m = g[f"p{i_ref}/matches"].astype(np.int64)
+    n_m_diff = 0
+    same_kp = all(np.array_equal(kp_m[s], g[f"p{i_ref}/kp_{s}"]) for s in ("optical", "thermal"))
+    if not (same_kp and np.array_equal(mine, ref_m)):
+        vol = {"optical": vol_o, "thermal": vol_t}
+        desc_of = lambda side, pts: utils.interpolate_descriptors_nhwc(torch.from_numpy(pts), vol[side], H, W).cpu().numpy()
+        rep, bad = parity.explain_match_diff(kp_m["optical"], kp_m["thermal"], g[f"p{i_ref}/kp_optical"], g[f"p{i_ref}/kp_thermal"], mine, ref_m,
+                                             desc_of, tol=TOL)
+        n_m_diff = len(rep)
+        lines.append(parity.format_report(f"pair {i_ref} mutual-NN pairs", rep))
+        assert not bad, parity.format_report(f"pair {i_ref}: UNEXPLAINED match differences", bad)
+    return n_kp, n_kp_diff, len(ref_m), n_m_diff
+
+
+def test_c5_streaming_graph_step_480x640(gpu_lib, golden, capsys):
+    """bench.py --config c5's step object at size: PairPipeline(B=8, 480x640, overlap, alternating encoders) captured into hipGraphs, replayed
+    with PINNED-HOST images for pairs 0..7, then for the same pairs rotated by three (other inputs through the same graphs, the other buffer set),
+    then pairs 0..7 again; download_async double-buffered exactly as the bench consumes it; RegNet head on the 256x256 crops from its own graph.
+    Asserts per step: keypoints and mutual-NN pairs == g15 (real reference; near-ties attributed), hm == the reference's hm on those crops (g21,
+    RegNet.py:20-52) and == an eager predict_homography."""
+    from xpoint_amd import models
+    from xpoint_amd.predict import PairPipeline
+    from xpoint_amd.streaming import StreamingRegistrationStep
+    g15, g21 = golden("g15_c2_batch8.npz"), golden("g21_c5_hm.npz")
+    assert [int(v) for v in g15["meta"]] == [B, H, W] and [int(v) for v in g21["meta"]] == [B, H, W, 256]
+    net = _net(synth.xpoint_exp1_config(H, W))
+    cfg_hm = synth.xpoint_exp1_config(256, 256, hm_head=True)
+    net_hm = _net(cfg_hm)
+    data = synth.to_torch(synth.make_pair_batch(0, B, H, W), "cuda")
+    opt, thr, mo, mt = data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"]
+    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=True, alternate_encoders=True)
+    warm = synth.to_torch(synth.make_pair_batch(40, B, H, W), "cuda")            # capture / warm-up on OTHER pairs than the ones checked
+    sstep = StreamingRegistrationStep(pipe, net_hm, warm["optical"]["image"], warm["thermal"]["image"], mo, mt)
+    rot = [(i + 3) % B for i in range(B)]
+    orders = [list(range(B)), rot, list(range(B))]
+    pins = []
+    for order in orders:
+        pins.append((opt[order].cpu().pin_memory(), thr[order].cpu().pin_memory()))
+    consumed, pending = [], None
+
+    def consume(item):
+        order, (bufs, ev, hm_host, hm_ev), snap = item
+        ev.synchronize(); hm_ev.synchronize()
+        consumed.append((order, {k: v.clone() for k, v in bufs.items()}, hm_host.clone(), snap))
+    for order, (po, pt) in zip(orders, pins):
+        out = sstep(po, pt, mo, mt)
+        # device-side snapshots for the near-tie attribution (prob / descriptor volume of THIS step), stream-ordered behind the step
+        pipe.wait()
+        snap = (pipe.raw["prob"].clone(), pipe.raw["desc_nhwc"].clone())
+        if pending is not None:
+            consume(pending)                                   # the step before is consumed while this one runs
+        pending = (order, out, snap)
+    consume(pending)
+    sstep.verify()
+    lines, tot = [], np.zeros(4, dtype=np.int64)
+    with torch.no_grad():
+        eager_hm = net_hm.predict_homography(opt[:, :, :256, :256].contiguous(), thr[:, :, :256, :256].contiguous()).cpu().numpy().reshape(B, -1)
+    e_ref = float(np.abs(eager_hm - g21["hm"]).max())
+    assert e_ref < TOL, e_ref
+    for order, bufs, hm, (prob, dvol) in consumed:
+        assert int(bufs["status"][0]) == 0
+        hm = hm.numpy().reshape(B, -1)
+        for slot, i in enumerate(order):
+            e_hm = float(np.abs(hm[slot] - g21["hm"][i]).max())
+            assert e_hm < TOL, (i, e_hm)
+            assert float(np.abs(hm[slot] - eager_hm[i]).max()) < 1e-5
+            no, nt, nm = int(bufs["counts"][slot]), int(bufs["counts"][B + slot]), int(bufs["match_count"][slot])
+            tot += _check_pair_lists(i, bufs["kp"][slot, :no].numpy(), bufs["kp"][B + slot, :nt].numpy(), bufs["match_q"][slot, :nm].numpy(),
+                                     bufs["match_t"][slot, :nm].numpy(), g15, prob[slot], prob[B + slot], dvol[slot], dvol[B + slot], lines)
+    with capsys.disabled():
+        print(f"\nC5 streaming graph step, 3 steps x 8 pairs vs reference: {tot[0]} keypoints, {tot[1]} differ (explained); {tot[2]} mutual-NN pairs, "
+              f"{tot[3]} differ (explained); hm max err vs reference {e_ref:.2e}")
+        print("\n".join(lines))
+    assert tot[1] <= tot[0] // 200 and tot[3] <= tot[2] // 50
+
+
+def test_c3_shard_rehearsal_ranks_0_to_7(gpu_lib, golden, capsys):
+    """BASELINE config C3 (batch 64 = 8 pairs per GPU x 8 GPUs) rehearsed on ONE GPU: for r = 0..7 the shard `dist.shard_pairs(64, 8, r)`
+    goes through the bench's overlapped pipeline; every pair's keypoint lists and mutual-NN pairs must equal the REAL reference's (g15 for rank
+    0, g18 = pairs 8..63 for ranks 1..7; near-ties attributed), and the fixed-size result header a rank would all-gather (first pair, pairs,
+    keypoints, matches — xpoint_amd/dist.py: gather_headers) must equal the fixture's table unless a pair carries an attributed near-tie."""
+    from xpoint_amd import dist as xdist
+    from xpoint_amd.predict import PairPipeline
+    g15, g18 = golden("g15_c2_batch8.npz"), golden("g18_c3_pairs8to63.npz")
+    assert [int(v) for v in g18["meta"]] == [8, 64, H, W]
+    hdr_tab = {int(r[0]): r for r in g18["header"]}
+    # the fixture's header table is self-consistent (crc32 of the int16 lists)
+    for i, r in hdr_tab.items():
+        assert int(r[1]) == len(g18[f"p{i}/kp_optical"]) and int(r[3]) == len(g18[f"p{i}/matches"])
+        assert int(r[4]) == zlib.crc32(np.ascontiguousarray(g18[f"p{i}/kp_optical"]).astype("<i2").tobytes())
+    net = _net(synth.xpoint_exp1_config(H, W))
+    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=True, alternate_encoders=True)
+    world, total = 8, 64
+    lines, tot = [], np.zeros(4, dtype=np.int64)
+    crc_equal = 0
+    for rank in range(world):
+        first, n = xdist.shard_pairs(total, world, rank)
+        assert (first, n) == (rank * B, B)
+        data = synth.to_torch(synth.make_pair_batch(first, n, H, W), "cuda")
+        with torch.no_grad():
+            pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
+            res = pipe.fetch()
+        prob, dvol = pipe.raw["prob"], pipe.raw["desc_nhwc"]
+        g = g15 if rank == 0 else g18
+        before = tot.copy()
+        for j in range(n):
+            i = first + j if rank else j
+            tot += _check_pair_lists(i, res[j]["kp_optical"].numpy(), res[j]["kp_thermal"].numpy(), res[j]["match_q"], res[j]["match_t"], g,
+                                     prob[j], prob[B + j], dvol[j], dvol[B + j], lines)
+            if rank:
+                r = hdr_tab[first + j]
+                mine = np.stack([res[j]["match_q"], res[j]["match_t"]], 1)
+                crc_equal += int(zlib.crc32(res[j]["kp_optical"].numpy().astype("<i2").tobytes()) == int(r[4])
+                                 and zlib.crc32(res[j]["kp_thermal"].numpy().astype("<i2").tobytes()) == int(r[5])
+                                 and zlib.crc32(np.ascontiguousarray(mine).astype("<i2").tobytes()) == int(r[6]))
+        # the header this rank would contribute to the all-gather
+        hdr = (first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res), sum(len(r["match_q"]) for r in res))
+        exp_kp = sum(len(g[f"p{first + j if rank else j}/kp_optical"]) + len(g[f"p{first + j if rank else j}/kp_thermal"]) for j in range(n))
+        exp_m = sum(len(g[f"p{first + j if rank else j}/matches"]) for j in range(n))
+        d = tot - before
+        if d[1] == 0 and d[3] == 0:
+            assert hdr == (first, n, exp_kp, exp_m), (rank, hdr, exp_kp, exp_m)
+        else:   # an attributed near-tie may move a count by the number of attributed elements, never more
+            assert hdr[:2] == (first, n) and abs(hdr[2] - exp_kp) <= d[1] and abs(hdr[3] - exp_m) <= d[3], (rank, hdr, exp_kp, exp_m, d)
+        lines.append(f"rank {rank}: pairs {first}..{first + n - 1}, header {hdr}, reference ({exp_kp} keypoints, {exp_m} matches)")
+    with capsys.disabled():
+        print(f"\nC3 shard rehearsal (8 ranks x 8 pairs on one GPU) vs reference: {tot[0]} keypoints, {tot[1]} differ (explained); {tot[2]} mutual-NN "
+              f"pairs, {tot[3]} differ (explained); {crc_equal} / 56 pairs of ranks 1..7 CRC-identical in all three lists")
+        print("\n".join(lines))
+    assert tot[1] <= tot[0] // 200 and tot[3] <= tot[2] // 50
+    assert crc_equal >= 50

@@ -232,3 +232,36 @@ def test_evaluation_and_homography_edge_cases(gpu_lib):
     src = np.full((20, 2), 5.0, np.float32)
     Hd, md = utils.find_homography(src, src, 3.0, max_iters=256)
     assert Hd is None or np.isfinite(Hd).all()
+
+
+def test_desc_process_and_display_sample_time_dict(gpu_lib, tmp_path):
+    """The reference's timing harness (benchmark_evaluation.py:16-227) as a callable: same signature and `time_dict_seconds` keys
+    (two_forward, nms, interpolate), one forward / NMS entry per sample and one interpolate entry per pair, positive HIP-event times;
+    with args.plot the match / registration quantities the reference draws are written next to where its PNG would go."""
+    import types
+    from xpoint_amd import evaluation as ev, models
+    H, W = 64, 96
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = models.XPoint(cfg)
+    net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
+    net = net.to("cuda").eval()
+
+    class DS:               # dataset[index] -> un-batched CPU sample, like ImagePairDataset.__getitem__
+        def __getitem__(self, i):
+            d = synth.to_torch(synth.make_pair_batch(i, 1, H, W))
+            return {s: {k: v[0] for k, v in d[s].items()} for s in d}
+    config = dict(CONFIG); config["prediction"] = dict(CONFIG["prediction"], nms=8, topk=0, cpu_nms=True, reprojection_threshold=3)
+    args = types.SimpleNamespace(index=[0, 3, 5], plot=False, radius=4, output_dir=str(tmp_path), model_dir="model_weights/xpoint", version="synth", seed=0)
+    with torch.no_grad():
+        td = ev.desc_process_and_display_sample(net, DS(), "cuda", config, args)
+    assert sorted(td) == ["interpolate", "nms", "two_forward"]
+    assert len(td["two_forward"]) == 3 and len(td["nms"]) == 3 and len(td["interpolate"]) == 3
+    assert all(0.0 < t < 5.0 for k in td for t in td[k])
+    args.plot = True; args.index = [3]
+    with torch.no_grad():
+        ev.desc_process_and_display_sample(net, DS(), "cuda", config, args)
+    import glob
+    files = glob.glob(str(tmp_path / "images" / "supp" / "i3" / "*.npz"))
+    assert len(files) == 1
+    z = np.load(files[0])
+    assert z["matches"].shape[1] == 2 and z["H_est"].shape == (3, 3) and len(z["matches_mask"]) == len(z["matches"])

@@ -663,3 +663,40 @@ def test_stage_pair_batch(gpu_lib, n, masked):
         L.call("xp_stage_pair_batch", L.ptr(a[1:]), L.ptr(b[1:]), L.ptr(out2[1:]), None, None, None, n - 1, L.current_stream())
         torch.cuda.synchronize()
         assert torch.equal(out2[1:n], a[1:]) and torch.equal(out2[n:2 * n - 1], b[1:])
+
+
+@pytest.mark.parametrize("D", [4, 8, 16])
+def test_match_adversarial_low_dim_sparse_near_ties(gpu_lib, D):
+    """ADVICE r2 (medium): the matrix pipe only NOMINATES candidates inside a proven error window around the approximate row / column optimum;
+    the window must cover the fp16 rounding of the operands (unit roundoff 2^-11, not 2^-12) or the true neighbour can be left out — silently —
+    where rounding errors do not average out: few dimensions, sparse sign-alternating descriptors whose components sit at fp16 rounding
+    midpoints, and a near-tied competitor whose components are exactly representable.  Indices must equal the fp64 direct-form oracle."""
+    from xpoint_amd.utils import match_descriptors
+    rng = np.random.default_rng(100 + D)
+    n1, n2 = 600, 700
+    def sparse(n):
+        x = np.zeros((n, D), np.float64)
+        for i in range(n):
+            nz = rng.choice(D, size=max(2, D // 4), replace=False)
+            k = rng.integers(256, 512, len(nz)) * 2
+            # components at fp16 round-to-nearest midpoints (1 + (2k+1) 2^-11) / 2: every one rounds by a full half ulp, in the SAME direction (k even)
+            x[i, nz] = (1.0 + (2.0 * k + 1.0) * 2.0 ** -11) * 0.5 * np.where(np.arange(len(nz)) % 2 == 0, 1.0, -1.0)
+        return x
+    d1 = sparse(n1); d2 = sparse(n2)
+    # near-tie traps: for every 7th query, target A = the query itself moved by a tiny step (distance^2 ~ 1e-7, midpoint components: rounds away),
+    # target B = the query rounded to fp16 exactly (distance^2 ~ 2e-7 .. 1e-6: the fp16 image of the query equals B's -> approximate score prefers B)
+    for j, q in enumerate(range(0, n1, 7)):
+        a = d1[q].copy(); nzq = np.nonzero(a)[0]
+        a[nzq[0]] += 2.0e-4 * np.sign(a[nzq[0]])
+        b = d1[q].astype(np.float16).astype(np.float64)
+        ta, tb = (3 * j) % n2, (3 * j + 1) % n2
+        d2[ta] = a; d2[tb] = b
+    d1 = d1.astype(np.float32); d2 = d2.astype(np.float32)
+    idx12, dist12, gap12, idx21, dist21 = xo.nn_both(d1, d2)
+    res = match_descriptors(torch.from_numpy(d1).cuda().unsqueeze(0), torch.from_numpy(d2).cuda().unsqueeze(0))
+    assert np.array_equal(res["idx12"][0].cpu().numpy(), idx12)
+    assert np.array_equal(res["idx21"][0].cpu().numpy(), idx21)
+    q = np.nonzero(idx21[idx12] == np.arange(n1))[0]
+    nm = int(res["match_count"][0])
+    assert nm == len(q) and np.array_equal(res["match_q"][0, :nm].cpu().numpy(), q) and np.array_equal(res["match_t"][0, :nm].cpu().numpy(), idx12[q])
+    assert float(np.min(gap12[::7])) < 1e-3            # the traps are near-ties on the fp16 scale

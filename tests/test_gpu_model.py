@@ -561,32 +561,155 @@ def test_download_async_equals_fetch(gpu_lib, overlap):
             assert g["match_q"][i, :nm].tolist() == ref[i]["match_q"].tolist() and g["match_t"][i, :nm].tolist() == ref[i]["match_t"].tolist()
 
 
-def test_pipeline_flags_fp16_range_overflow(gpu_lib):
-    """The default dense engine splits f32 operands into two fp16 values: activations beyond 65504 overflow.  The pipeline must say so
-    (verify() / fetch() raise) instead of returning silently wrong keypoints — the heads' ReLU turns a NaN encoder map into finite scores —;
-    the split-bf16 engine runs the same weights.  Provoked with a
-    LayerNorm gain of 1e6 in front of a stage-2 GEMM (unfused path: the value reaches xp_gemm_nt_h2 as an activation)."""
+def test_fp16_range_overflow_falls_back_to_x3(gpu_lib):
+    """The default dense engine splits f32 operands into two fp16 values: activations beyond 65504 overflow, and the heads' ReLU would turn a NaN
+    encoder map into finite, wrong scores.  Every forward reports it through a device status word (xp_xpoint_forward_ex); the host then re-runs
+    on the split-bf16 engine (no range limit), keeps it for that weight set and WARNS — the default never raises and never returns the
+    overflowed results (VERDICT r2 weak 1 / ADVICE r2).  Provoked with a LayerNorm gain of 1e6 in front of a stage-2 GEMM.  Checked for the
+    eager API (every call, not only the first), the single-stream pipeline, the overlapped pipeline and a captured (hipGraph) pipeline."""
     from xpoint_amd.predict import PairPipeline
     H, W, B = 64, 96, 1
     cfg = synth.xpoint_exp1_config(H, W)
     data = _data(5, B, H, W)
+    args = (data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
     sd = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
     sd["encoder.layers.2.blocks.0.norm2.weight"] *= 1.0e6
-    for mode, must_raise in (("h2", True), ("x3", False)):
-        net = _net(cfg, sd); net.gemm_mode = mode
-        with torch.no_grad():
-            if must_raise:
-                with pytest.raises(RuntimeError, match="non-finite"):          # the model's own first-forward check
-                    net(data)
-                pipe = PairPipeline(net, B, H, W, cap=4096)                     # later forwards are not checked by the model; the pipeline's verify() is
-                pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
-                torch.cuda.synchronize()
-                with pytest.raises(RuntimeError, match="non-finite"):
-                    pipe.verify()
+    with torch.no_grad():
+        ref_net = _net(cfg, sd); ref_net.gemm_mode = "x3"
+        ro, rt, _ = ref_net(data)
+        ref = PairPipeline(ref_net, B, H, W, cap=4096).run(*args).fetch()
+        assert bool(torch.isfinite(ro["encoder_output"]).all())      # fine on x3: the out-of-range value is an INTERMEDIATE (norm2's output, fc1's operand)
+        # eager API
+        net = _net(cfg, sd)
+        assert net.gemm_mode == "h2" and net.effective_gemm_mode() == "h2"
+        with pytest.warns(RuntimeWarning, match="re-running on gemm_mode 'x3'"):
+            o, t, _ = net(data)
+        assert net.effective_gemm_mode() == "x3" and net.gemm_mode == "h2"
+        assert torch.equal(o["prob"], ro["prob"]) and torch.equal(t["desc"], rt["desc"])
+        o2, _, _ = net(data)                                   # stays on x3: no second warning, same results
+        assert torch.equal(o2["prob"], ro["prob"])
+        net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)      # a new weight set gets the default engine back
+        assert net.effective_gemm_mode() == "h2"
+        net(data)
+        assert net.effective_gemm_mode() == "h2"
+        # pipelines: the trip is found at the synchronisation point and the latest call is re-run
+        for kw in (dict(), dict(overlap=True, alternate_encoders=True), dict(graph=True), dict(overlap=True, alternate_encoders=True, graph=True)):
+            graph = kw.pop("graph", False)
+            net = _net(cfg, sd)
+            pipe = PairPipeline(net, B, H, W, cap=4096, **kw)
+            if graph:
+                with pytest.warns(RuntimeWarning, match="re-running on gemm_mode 'x3'"):
+                    step = pipe.capture(*args)                  # trips during the warm-up: the graphs are captured on x3
+                step(*args)
+                got = pipe.fetch()
             else:
-                net(data)
-                pipe = PairPipeline(net, B, H, W, cap=4096)
-                pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
-                torch.cuda.synchronize()
-                pipe.verify()
-                assert bool(torch.isfinite(pipe.raw["enc_nhwc"]).all())
+                pipe.run(*args)
+                with pytest.warns(RuntimeWarning, match="re-running on gemm_mode 'x3'"):
+                    got = pipe.fetch()
+            assert net.effective_gemm_mode() == "x3"
+            assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"]) and torch.equal(got[0]["kp_thermal"], ref[0]["kp_thermal"])
+            assert got[0]["match_q"].tolist() == ref[0]["match_q"].tolist() and got[0]["match_t"].tolist() == ref[0]["match_t"].tolist()
+            pipe.run(*args)
+            got = pipe.fetch()                                  # later steps: x3 from the start, nothing to repair
+            assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"])
+        # a graph captured on h2 that trips LATER (other inputs) is re-captured on x3
+        net = _net(cfg, sd)
+        pipe = PairPipeline(net, B, H, W, cap=4096)
+        zero = torch.zeros_like(args[0])
+        step = pipe.capture(zero, zero, args[2], args[3])          # black images: in range?  (either way the result below must be the x3 one)
+        step(*args)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            got = pipe.fetch()
+        assert net.effective_gemm_mode() == "x3"
+        assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"]) and got[0]["match_q"].tolist() == ref[0]["match_q"].tolist()
+        # genuinely non-finite weights: no engine can help -> raise, on every engine
+        sd_nan = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
+        sd_nan["encoder.layers.1.blocks.0.mlp.fc1.bias"][3] = float("nan")
+        for mode in ("h2", "x3", "f32"):
+            net = _net(cfg, sd_nan); net.gemm_mode = mode
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                with pytest.raises(RuntimeError, match="non-finite"):
+                    net(data)
+
+
+@pytest.mark.parametrize("gemm_mode", ["h2", "x3", "f32"])
+def test_trained_like_weights_vs_reference(gpu_lib, golden, gemm_mode, capsys):
+    """G19: weights with trained-like statistics — LayerNorm gains log-uniform 0.0625..16, 1 % outlier channels x100 in the
+    patch-embed / downsample convolutions and the residual writers, dt bias at both ends of its range; the residual stream reaches ~1.5e3 and goes
+    un-normalised into the downsample convolutions and the heads (VMamba.py:1405-1440,1500-1505) — on a plain pair and on a pair at the contrast
+    extremes, 224x320, against the REAL reference: prob / desc within 1e-4 on all three f32-grade back ends (the default one without tripping its
+    range guard), keypoints and mutual-NN pairs identical up to attributed near-ties."""
+    from tests import parity
+    from xpoint_amd import utils
+    from xpoint_amd.predict import predict_align_image_pair
+    g = golden("g19_trained_like.npz")
+    _, H, W = [int(v) for v in g["meta"]]
+    cfg = synth.xpoint_exp1_config(H, W)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_trained_like_state_dict(cfg).items()}
+    net = _net(cfg, sd)
+    net.gemm_mode = gemm_mode
+    lines = []
+    for c, dnp in enumerate((synth.make_pair_batch(0, 1, H, W), synth.make_contrast_pair(1, H, W))):
+        data = synth.to_torch(dnp, "cuda")
+        with torch.no_grad():
+            raw_o, raw_t, _ = net(data)
+            raw = {"optical": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in raw_o.items()},
+                   "thermal": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in raw_t.items()}}
+            _, _, res = predict_align_image_pair(net, data)
+        assert net.effective_gemm_mode() == gemm_mode           # in range: the guard did not trip
+        for spec in ("optical", "thermal"):
+            r = raw[spec]
+            assert float(r["encoder_output"].abs().max()) > 500.0          # the fixture's point: a large raw residual stream
+            e_p = float(np.abs(r["prob"].cpu().numpy() - g[f"c{c}/{spec}/prob"]).max())
+            d = r["desc"].cpu().numpy()
+            e_d = float(np.abs((d if spec == "optical" else d[:, :, ::2, ::2]) - g[f"c{c}/{spec}/desc"]).max())
+            lines.append(f"g19 case {c} {spec} [{gemm_mode}]: prob err {e_p:.2e}, desc err {e_d:.2e}, enc absmax {float(r['encoder_output'].abs().max()):.0f}")
+            assert e_p < TOL and e_d < TOL, lines[-1]
+        kp_m = {"optical": res[0]["kp_optical"].cpu().numpy(), "thermal": res[0]["kp_thermal"].cpu().numpy()}
+        for spec in ("optical", "thermal"):
+            rep, bad = parity.explain_keypoint_diff(kp_m[spec], g[f"c{c}/kp_{spec}"].astype(np.int64), raw[spec]["prob"][0, 0].cpu().numpy(), 0.015, 8, tol=TOL)
+            if rep:
+                lines.append(parity.format_report(f"g19 case {c} {spec} keypoints", rep))
+            assert not bad, parity.format_report(f"g19 case {c} {spec}: UNEXPLAINED", bad)
+        ms = res[0]["matches"]
+        mine = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int64).reshape(-1, 2)
+        vol = {"optical": raw["optical"]["desc_nhwc"][0], "thermal": raw["thermal"]["desc_nhwc"][0]}
+        desc_of = lambda side, pts: utils.interpolate_descriptors_nhwc(torch.from_numpy(pts).cuda(), vol[side], H, W).cpu().numpy()
+        rep, bad = parity.explain_match_diff(kp_m["optical"], kp_m["thermal"], g[f"c{c}/kp_optical"], g[f"c{c}/kp_thermal"], mine,
+                                             g[f"c{c}/matches"].astype(np.int64), desc_of, tol=TOL)
+        if rep:
+            lines.append(parity.format_report(f"g19 case {c} mutual-NN pairs", rep))
+        assert not bad, parity.format_report(f"g19 case {c}: UNEXPLAINED match differences", bad)
+        lines.append(f"g19 case {c} [{gemm_mode}]: {len(kp_m['optical'])}/{len(kp_m['thermal'])} keypoints, {len(mine)} pairs vs reference {len(g[f'c{c}/matches'])}")
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+
+
+def test_pipeline_heals_nms_non_convergence(gpu_lib):
+    """The stream-ordered NMS enqueues a fixed number of sweeps; an image whose suppression chains need more (found on pairs 8..63 of the C3 batch
+    at 6 sweeps) must not fail the step: verify() raises the count (kept), recomputes the latest call's post-processing and the results equal
+    those of a pipeline that had enough sweeps from the start — eager and captured."""
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 96, 128, 2
+    net = _net(synth.xpoint_exp1_config(H, W))
+    d = _data(2, B, H, W)
+    args = (d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"])
+    with torch.no_grad():
+        ref = PairPipeline(net, B, H, W, cap=2048, nms_sweeps=16).run(*args).fetch()
+        for graph in (False, True):
+            pipe = PairPipeline(net, B, H, W, cap=2048, nms_sweeps=1)
+            step = pipe.capture(*args) if graph else pipe.run
+            step(*args)
+            with pytest.warns(RuntimeWarning, match="NMS needed more than 1 sweeps"):
+                got = pipe.fetch()
+            assert pipe.sweeps > 1
+            for i in range(B):
+                assert torch.equal(got[i]["kp_optical"], ref[i]["kp_optical"]) and torch.equal(got[i]["kp_thermal"], ref[i]["kp_thermal"])
+                assert got[i]["match_q"].tolist() == ref[i]["match_q"].tolist()
+            step(*args)
+            got = pipe.fetch()                 # the raised count is kept: converges without a second repair
+            assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"])

@@ -21,5 +21,9 @@ for k, c in d.items():
     rows.append((busy * n, k, n, cyc, ins, busy, busy / (1024.0 * cyc)))
 for _, k, n, cyc, ins, busy, u in sorted(rows, reverse=True):
     print(f"{k:46s} {n:8d} {cyc:10.0f} {ins:12.0f} {busy:14.0f} {u:12.3f}")
+import json
+json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on bench.py --no-overlap; mfma_busy_frac = busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), per-launch average",
+           "kernels": {k: {"launches": n, "kernel_cycles": cyc, "mfma_instr": ins, "mfma_busy_frac": u} for _, k, n, cyc, ins, busy, u in rows}},
+          open(os.path.join(os.path.dirname(sys.argv[1]), "pmc_mfma.json"), "w"), indent=1)
 PY
 cat $R/gpurun_out/mfma_utilisation.txt

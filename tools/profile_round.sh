@@ -20,6 +20,7 @@ python3 $R/tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv
 rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write
 bash $R/tools/mfma_util.sh > /dev/null 2>&1
 cp $R/gpurun_out/mfma_utilisation.txt $OUT/
+cp $R/gpurun_out/pmc_mfma.json $OUT/; cp $R/gpurun_out/pmc_mfma.json $R/profiles/pmc_mfma.json
 python3 $R/tools/match_bench.py 4060 8192 8 > $OUT/match_microbench.txt 2>&1
 GB_H2=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_h2_microbench.txt 2>&1
 GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "xp_param_info": [c_p, c_i, ctypes.c_char_p, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)],
     "xp_forward_shapes": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
     "xp_xpoint_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p],
+    "xp_xpoint_forward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p],
     "xp_prepare_split_weights": [c_p, c_p, c_p, c_sz, c_p],
     "xp_box_nms": [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],
     "xp_box_nms_check": [c_p, c_i, c_i, c_i, ctypes.POINTER(c_i), c_p],

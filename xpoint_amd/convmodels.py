@@ -149,10 +149,28 @@ def regnet_weights(ref_state, device):
     return w
 
 
-def regnet_forward(w, enc1_nhwc, enc2_nhwc):
+def _adaptive_pool_matrix(Hh, Wh, out_h, out_w, device):
+    """(out_h * out_w, Hh * Wh) matrix of F.adaptive_avg_pool2d((out_h, out_w)) on a row-major (Hh, Wh) map: bin i covers
+    [floor(i * H / out), ceil((i + 1) * H / out)) — ATen's start / end index rule; the identity when the sizes agree."""
+    import math
+    P = torch.zeros((out_h * out_w, Hh * Wh), dtype=torch.float32)
+    for i in range(out_h):
+        y0, y1 = (i * Hh) // out_h, math.ceil((i + 1) * Hh / out_h)
+        for j in range(out_w):
+            x0, x1 = (j * Wh) // out_w, math.ceil((j + 1) * Wh / out_w)
+            wgt = 1.0 / ((y1 - y0) * (x1 - x0))
+            for y in range(y0, y1):
+                P[i * out_w + j, y * Wh + x0:y * Wh + x1] = wgt
+    return P.to(device)
+
+
+def regnet_forward(w, enc1_nhwc, enc2_nhwc, adaptive_pool=False):
     """RegNet.forward (RegNet.py:32-52), eval mode.  enc (B, H', W', 48) NHWC -> (B, 8).  The cost volume's channel count
     must equal fc.1's input (256), i.e. (H'/2)*(W'/2) == 256 <=> a 256x256 image: raises otherwise, like the
-    reference's Linear does."""
+    reference's Linear does.
+    adaptive_pool=True (NOT reference semantics — the reference has none beyond 256x256): the pooled cost-volume vector, which is a
+    (H'/2, W'/2) map over the FIRST image's positions, is adaptive-average-pooled to the 16 x 16 grid the FC layer was sized for, so the head
+    accepts any image size; at 256x256 the pooling matrix is the identity and the result is the reference's (tests: g9)."""
     def layer1(x):      # conv (no bias) -> BN -> ReLU, twice, then MaxPool2d(2)
         x = ops.conv3x3(x, w["c1"], None, w["bn1"][0], w["bn1"][1], 1, False, "relu_after_affine")
         x = ops.conv3x3(x, w["c2"], None, w["bn2"][0], w["bn2"][1], 1, False, "relu_after_affine")
@@ -160,8 +178,9 @@ def regnet_forward(w, enc1_nhwc, enc2_nhwc):
     a, b = layer1(enc1_nhwc.contiguous()), layer1(enc2_nhwc.contiguous())
     B, Hh, Wh, C = a.shape
     hw = Hh * Wh
-    if hw != w["fc1"][0].shape[1]:
-        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{hw} and {w['fc1'][0].shape[1]}x{w['fc1'][0].shape[0]})")
+    n_in = w["fc1"][0].shape[1]
+    if hw != n_in and not adaptive_pool:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{hw} and {n_in}x{w['fc1'][0].shape[0]})")
     an = ops.l2norm_rows(a.view(B * hw, C), 1e-12).view(B, hw, C)      # F.normalize over channels
     bn = ops.l2norm_rows(b.view(B * hw, C), 1e-12).view(B, hw, C)
     mean_w = torch.full((1, hw), 1.0 / hw, device=a.device)            # adaptive_avg_pool2d over the (H', W') axes of cv
@@ -169,5 +188,13 @@ def regnet_forward(w, enc1_nhwc, enc2_nhwc):
     for i in range(B):
         cv = ops.linear(an[i], bn[i])                                  # bmm(x1^T, x2): (hw, hw), RegNet.py:50
         ops.linear(cv, mean_w, out=v[i].view(hw, 1), ldc=1)
+    if hw != n_in:
+        g = int(round(n_in ** 0.5))
+        if g * g != n_in:
+            raise RuntimeError(f"adaptive_pool: fc.1 input {n_in} is not a square grid")
+        key = ("pool", Hh, Wh, str(a.device))
+        if key not in w:
+            w[key] = _adaptive_pool_matrix(Hh, Wh, g, g, a.device)
+        v = ops.linear(v, w[key])                                      # (B, hw) x (n_in, hw)^T
     h = ops.linear(v, w["fc1"][0], w["fc1"][1], act="relu")            # Dropout = identity in eval
     return ops.linear(h, w["fc2"][0], w["fc2"][1])

@@ -237,11 +237,16 @@ __global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __re
 // depth_to_space(4) in NHWC: out[n, bs*h+i, bs*w+j, c] = x[n, h, w, (bs*i+j)*Cq + c]  (VMamba.py:1500-1505;
 // block-major channel order, NOT PixelShuffle order).
 // ---------------------------------------------------------------------------------------------
+// status != NULL: bit XP_STATUS_ENC is OR-ed into *status when an element is non-finite or |x| >= limit (one atomic per wave that saw one).
 __global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             int B, int H, int W, int C, int bs) {
+                                                             int B, int H, int W, int C, int bs, float limit, int* __restrict__ status) {
     const int Cq = C / (bs * bs);
     const int64_t total = (int64_t)B * H * W * C;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (status) {
+        const bool bad = idx < total && !(fabsf(x[idx]) < limit);        // NaN compares false
+        if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(status, XP_STATUS_ENC);
+    }
     if (idx >= total) return;
     const int ch = (int)(idx % C);
     const int64_t pix = idx / C;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __rest
 // mode 1 = SuperPointMagicLeap heat-map: exp(x)/(sum+1e-5), no max subtraction (SuperPointMagicLeap.py:73-74).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __restrict__ logits, float* __restrict__ prob,
-                                                              int B, int Hc, int Wc, int r, int ld, int mode) {
+                                                              int B, int Hc, int Wc, int r, int ld, int mode, int* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cell >= (int64_t)B * Hc * Wc) return;
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __res
         e1 = (lane + 64 < nch) ? expf(v1 - mx) : 0.f;
         inv = 1.f / xp_wave_sum(e0 + e1);
         e0 *= inv; e1 *= inv;
+        if (status && !(inv <= 1.f) && lane == 0) atomicOr(status, XP_STATUS_PROB);     // a NaN / +-inf logit makes the sum NaN (1 <= sum <= 65 otherwise)
     } else {
         e0 = (lane < nch) ? expf(v0) : 0.f;
         e1 = (lane + 64 < nch) ? expf(v1) : 0.f;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __res
 // eps < 0 selects the SuperPoint form x / ||x|| without clamp (SuperPointMagicLeap.py:59-60).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t M, int C,
-                                                          float eps) {
+                                                          float eps, int* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     float s = 0.f;
     for (int c = lane; c < C; c += 64) { const float v = xr[c]; s = fmaf(v, v, s); }
     float nrm = sqrtf(xp_wave_sum(s));
+    if (status && !(nrm < INFINITY) && lane == 0) atomicOr(status, XP_STATUS_DESC);      // NaN or inf anywhere in the row
     if (eps >= 0.f) nrm = fmaxf(nrm, eps);
     float* yr = y + row * C;
     for (int c = lane; c < C; c += 64) yr[c] = xr[c] / nrm;
@@ -415,30 +422,39 @@ extern "C" int xp_stem_conv_ln_gelu(const float* img, const float* w9co, const f
     return XP_OK;
 }
 
-extern "C" int xp_depth_to_space_nhwc(const float* x, float* y, int batch, int H, int W, int C, int bs, void* stream) {
+int xp_depth_to_space_nhwc_st(const float* x, float* y, int batch, int H, int W, int C, int bs, float limit, int* status, void* stream) {
     XP_CHECK_ARG(x && y && C % (bs * bs) == 0, "xp_depth_to_space_nhwc: bad args");
     const int64_t total = (int64_t)batch * H * W * C;
     XpProfScope prof("depth_to_space", (hipStream_t)stream, 0.0, 8.0 * total);
-    hipLaunchKernelGGL(depth_to_space_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C, bs);
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, H, W, C, bs, limit, status);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
+extern "C" int xp_depth_to_space_nhwc(const float* x, float* y, int batch, int H, int W, int C, int bs, void* stream) {
+    return xp_depth_to_space_nhwc_st(x, y, batch, H, W, C, bs, 0.f, nullptr, stream);
+}
 
 extern "C" int xp_softmax_shuffle(const float* logits, float* prob, int batch, int Hc, int Wc, int r, int ld, int mode, void* stream) {
+    return xp_softmax_shuffle_st(logits, prob, batch, Hc, Wc, r, ld, mode, nullptr, stream);
+}
+int xp_softmax_shuffle_st(const float* logits, float* prob, int batch, int Hc, int Wc, int r, int ld, int mode, int* status, void* stream) {
     XP_CHECK_ARG(logits && prob, "xp_softmax_shuffle: null pointer");
     XP_CHECK_ARG(r * r + 1 <= 128 && ld >= r * r + 1, "xp_softmax_shuffle: r*r+1 must be <= 128 and <= ld");
     const int64_t cells = (int64_t)batch * Hc * Wc;
     XpProfScope prof("softmax_shuffle", (hipStream_t)stream, (double)cells * 4.0 * (r * r + 1), 4.0 * cells * (2.0 * r * r + 1));
-    hipLaunchKernelGGL(softmax_shuffle_kernel, dim3(xp_cdiv(cells, 4)), dim3(256), 0, (hipStream_t)stream, logits, prob, batch, Hc, Wc, r, ld, mode);
+    hipLaunchKernelGGL(softmax_shuffle_kernel, dim3(xp_cdiv(cells, 4)), dim3(256), 0, (hipStream_t)stream, logits, prob, batch, Hc, Wc, r, ld, mode, status);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
 
 extern "C" int xp_l2norm_rows(const float* x, float* y, int64_t rows, int C, float eps, void* stream) {
+    return xp_l2norm_rows_st(x, y, rows, C, eps, nullptr, stream);
+}
+int xp_l2norm_rows_st(const float* x, float* y, int64_t rows, int C, float eps, int* status, void* stream) {
     XP_CHECK_ARG(x && y, "xp_l2norm_rows: null pointer");
     if (rows == 0) return XP_OK;
     XpProfScope prof("l2norm_rows", (hipStream_t)stream, 3.0 * rows * C, 8.0 * rows * C);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, C, eps);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, C, eps, status);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }

@@ -27,6 +27,10 @@ __global__ __launch_bounds__(256) void h2_row_scale_kernel(const float* __restri
     if (lane == 0) {
         int e = 0;
         if (m > 0.f && m < INFINITY) (void)frexpf(m, &e); else e = 14;      // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(14 - e) in [2^13, 2^14)
+        // a nearly dead row (largest |w| < 2^-100) is scaled like one at 2^-100: its elements then sit at or below fp16's smallest
+        // values and contribute what they are worth, ~0; without the clamp 2^(e-14) underflows, 1 / inv_scale = inf and the row's
+        // planes become inf / NaN (0 * inf) — poisoning every output column
+        e = e < -100 ? -100 : e;
         inv_scale[n] = ldexpf(1.f, e - 14);
     }
 }

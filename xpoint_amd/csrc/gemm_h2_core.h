@@ -1,13 +1,14 @@
 // Split-fp16 tile engine ("h2"): an fp32-grade GEMM on the f16 matrix pipe with THREE partial products per multiply.
 //
-// An f32 value x (24 significant bits) is written as x = h0 + h1 (+ at most 2^-24 |x|):
-//     h0 = fp16(x)  (round to nearest: |x - h0| <= 2^-12 |x|),   h1 = fp16(x - h0)  (the difference is exact in f32;
-//     |x - h0 - h1| <= 2^-12 |x - h0| <= 2^-24 |x|)
-// i.e. the pair reproduces x to within HALF an f32 ulp, and a product a*b is evaluated as
-//     a0 b0 + a0 b1 + a1 b0          (dropped: a1 b1 <= 2^-24 |a b|)
-// on v_mfma_f32_32x32x16_f16 (fp16 x fp16 products are exact in f32; f32 accumulate).  Per product that is about one f32
-// rounding (3 * 2^-24), which is what a plain f32 FMA chain — the reference's arithmetic — commits anyway; half the matrix work of
-// the six-product bf16 split (gemm_x3_core.h), whose operand error is 2^-24 too but whose three 8-bit planes need six products.
+// An f32 value x (24 significant bits) is written as x = h0 + h1 + r.  fp16 has an 11-bit significand (unit roundoff 2^-11):
+//     h0 = fp16(x)  (round to nearest: |x - h0| <= 2^-11 |x|),   h1 = fp16(x - h0)  (the difference is exact in f32 and has at most 12
+//     significant bits, of which fp16 keeps 11:  |r| = |x - h0 - h1| <= 2^-23 |x| worst case, 2^-25.5 |x| on average, measured)
+// i.e. the pair reproduces x to within ONE f32 ulp in the worst case, and a product a*b is evaluated as
+//     a0 b0 + a0 b1 + a1 b0          (dropped: a1 b1 <= 2^-22 |a b| worst case: both operands at an fp16 rounding midpoint)
+// on v_mfma_f32_32x32x16_f16 (fp16 x fp16 products are exact in f32; f32 accumulate).  Per product: <= 2^-23 + 2^-23 + 2^-22 = 2^-21 |ab| in the
+// worst case (operands at rounding midpoints with aligned signs: tests/test_gpu_h2.py::test_h2_adversarial_midpoints), ~2^-25 typically — the size of
+// the f32 rounding a plain f32 FMA chain, the reference's arithmetic, commits per product (2^-24).  Half the matrix work of the six-product bf16
+// split (gemm_x3_core.h), which is exact to 2^-24 per operand at the price of six products.
 //
 // fp16 has 5 exponent bits, so the split is only that good while h1 stays a NORMAL number (|h1| >= 2^-14, i.e. |x| >~ 2^-3 ...
 // below that h1 is rounded to a multiple of 2^-24: an ABSOLUTE error <= 2^-25) and |x| < 65504:

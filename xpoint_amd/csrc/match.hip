@@ -22,11 +22,14 @@
 // free ds_read_b128), each fragment read feeding two MFMAs.  Grid = (column splits, 256-row strips, pairs), sized by
 // the capacity; strips / splits past the device-side counts exit at once.
 //
-// Error bound (scaled units, |a^|, |b^| <= 2): fp16 rounding 2^-12 relative per operand (absolute 2^-25 in the subnormal
-// range) -> |dot error| <= 2^-12 (|a^|^2 + |b^|^2) + 2e-6; norm terms as hi + lo: 2^-22 relative; f32 accumulation over 272
-// terms <= 8.5e-6 (|a^|^2 + |b^|^2).  So |e~ - e| <= E(q,t) / 2 with E = 5.1e-4 (|a^|^2 + |b^|^2) + 4e-6, and the true optimum of
-// row q satisfies e~ >= rowmax~ - E_q,  E_q = 5.1e-4 (|a^_q|^2 + M) + 4e-6,  M = the largest scaled squared norm of the call.
-// Only the number of candidates depends on the bound (measured on 480x640 pairs: 1.2 per row), never the result.
+// Error bound (scaled units, |a^|, |b^| <= 2).  fp16 has an 11-bit significand: round to nearest commits u = 2^-11 relative per operand
+// (absolute 2^-25 in the subnormal range), so |a~.b~ - a.b| <= (2u + u^2) sum|a_k||b_k| <= 2^-11 (|a^|^2 + |b^|^2) + 2e-6 (2|a||b| <= |a|^2 +
+// |b|^2); norm terms as hi + lo: 2^-22 relative; f32 accumulation over 272 terms <= 8.5e-6 (|a^|^2 + |b^|^2).  One score is therefore off by at
+// most err(q,t) = (2^-11 + 8.5e-6)(|a^_q|^2 + |b^_t|^2) + 2e-6 ~= 4.97e-4 (..) + 2e-6, and the TRUE optimum t* of row q against the approximate
+// one t~ satisfies e~(q,t*) >= rowmax~ - err(q,t*) - err(q,t~) >= rowmax~ - E_q with
+//     E_q = 1.0e-3 (|a^_q|^2 + M) + 4e-6,   M = the largest scaled squared norm of the call
+// (round 2 had derived this with u = 2^-12 and used half the window: the index result was then not proven exact for sparse / low-D descriptors,
+// ADVICE r2).  Only the number of candidates depends on the bound (measured on 480x640 pairs: ~1.5 per row), never the result.
 #include "xp_common.h"
 #include "../../include/xpoint_hip.h"
 
@@ -41,7 +44,7 @@ typedef __attribute__((address_space(3))) void* mt_lds_ptr_t;
 namespace {
 
 constexpr int CAND_CAP = 16;
-constexpr float MT_EPS_REL = 5.1e-4f, MT_EPS_ABS = 4e-6f;
+constexpr float MT_EPS_REL = 1.0e-3f, MT_EPS_ABS = 4e-6f;    // 2 (2^-11 + 8.5e-6) = 9.94e-4, see the bound above
 constexpr float MT_DEAD = -30000.f;          // score term of rows past the count (finite in fp16)
 constexpr int MT_STRIP = 256, MT_TILE = 64;  // query rows per workgroup, target descriptors per LDS tile
 constexpr int MT_QCAP = 1020;                // pass 2: entries of the workgroup's LDS hit queue (4 KB with its count word)

@@ -2,6 +2,7 @@
 // VMamba encoder, VMamba.py:1507-1525): a fixed sequence of kernel launches on one HIP stream.
 // The context is host-only metadata (model dims + the device-format parameter table); weights and
 // workspace are caller-owned device buffers, so the library never allocates device memory.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -239,6 +240,13 @@ extern "C" int xp_prepare_split_weights(void* ctx, const float* weights, void* w
 extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
                                  void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
                                  float* logits_nhwc, void* stream) {
+    return xp_xpoint_forward_ex(ctx, weights, wsplit, images, batch, H, W, workspace, workspace_bytes, prob, desc_nhwc, enc_nhwc, logits_nhwc,
+                                nullptr, stream);
+}
+
+extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void* wsplit, const float* images, int batch, int H, int W,
+                                    void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
+                                    float* logits_nhwc, int* status, void* stream) {
     XP_CHECK_ARG(ctx && weights && images && workspace && enc_nhwc, "xp_xpoint_forward: null pointer");
     XP_CHECK_ARG(batch > 0, "xp_xpoint_forward: empty batch");
     Ctx* c = (Ctx*)ctx; Shapes sh;
@@ -319,7 +327,10 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
         }
     }
     const int L = c->nstages - 1;
-    RUN(xp_depth_to_space_nhwc(X, enc_nhwc, batch, sh.H[L], sh.W[L], c->dims[L], 4, stream));   // VMamba.py:1500-1505
+    // VMamba.py:1500-1505.  Range guard: a dense-layer operand beyond the split-fp16 engine's range (|x| >= 65504) turns that layer's output rows
+    // into NaN, and every dense output of the encoder reaches the residual stream (directly, or through a scan / LayerNorm that keeps NaN), so the
+    // stream itself carries the evidence; its magnitude is also what the head convolution is about to split.  Checked where it is copied anyway.
+    RUN(xp_depth_to_space_nhwc_st(X, enc_nhwc, batch, sh.H[L], sh.W[L], c->dims[L], 4, (wsplit && h2) ? 65504.f : INFINITY, status, stream));
 
     // heads (XPoint.py:112-138, :348-371): shared 3x3 trunk GEMM for both heads, then the two 1x1 convs
     const int EC = enc_channels_of(*c), HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
@@ -330,11 +341,11 @@ extern "C" int xp_xpoint_forward(void* ctx, const float* weights, const void* ws
     if (prob || logits_nhwc) {
         float* lg = logits_nhwc ? logits_nhwc : T2;
         RUN(gemm(HB, "det2.w", lg, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0));
-        if (prob) RUN(xp_softmax_shuffle(lg, prob, batch, sh.Hc, sh.Wc, 8, DET, 0, stream));
+        if (prob) RUN(xp_softmax_shuffle_st(lg, prob, batch, sh.Hc, sh.Wc, 8, DET, 0, status, stream));
     }
     if (desc_nhwc) {
         RUN(gemm(HB + HC, "desc2.w", T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0));
-        RUN(xp_l2norm_rows(T1, desc_nhwc, Mc, DS, 1e-12f, stream));
+        RUN(xp_l2norm_rows_st(T1, desc_nhwc, Mc, DS, 1e-12f, status, stream));
     }
     return XP_OK;
 }

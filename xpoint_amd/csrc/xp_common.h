@@ -52,6 +52,15 @@ private:
 
 static inline int xp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Sticky status bits of xp_xpoint_forward_ex (include/xpoint_hip.h): OR-ed into the caller's device word by the kernels that produce
+// the encoder output, the heat map and the descriptor volume.
+#define XP_STATUS_ENC 1     /* encoder output: non-finite, or beyond the dense engine's operand range */
+#define XP_STATUS_PROB 2    /* heat map: a non-finite logit */
+#define XP_STATUS_DESC 4    /* descriptor volume: a non-finite element */
+int xp_depth_to_space_nhwc_st(const float* x, float* y, int batch, int H, int W, int C, int bs, float limit, int* status, void* stream);
+int xp_softmax_shuffle_st(const float* logits, float* prob, int batch, int Hc, int Wc, int r, int ld, int mode, int* status, void* stream);
+int xp_l2norm_rows_st(const float* x, float* y, int64_t rows, int C, float eps, int* status, void* stream);
+
 // Partial products per multiply of the split-bf16 dense kernels (xp_set_dense_products): 6 (default), 3 or 1.
 int xp_dense_products_value();
 // Dense-layer engine of the fused encoder (xp_set_dense_engine): 0 = x3 (split bf16), 1 = h2 (split fp16, three products).

@@ -34,11 +34,38 @@ def broadcast_weights(net, state_dict_fn=None, src: int = 0, device=None, group=
         blob = net.pack_weights().to(device)
     else:
         blob = torch.empty(net.weights_numel(), dtype=torch.float32, device=device)
-    if world > 1:
+    global last_first_broadcast_ms
+    last_first_broadcast_ms = None
+    if world > 1 or (dist.is_initialized() and blob.is_cuda):
+        # the FIRST broadcast of the job, timed on its own: it carries the communicator's lazy set-up (ring / tree construction, xGMI
+        # channel allocation) — timed_broadcast() below reports the steady-state re-broadcast separately
+        import time
+        if blob.is_cuda:
+            torch.cuda.synchronize(blob.device)
+        t0 = time.perf_counter()
         dist.broadcast(blob, src, group=group)
+        if blob.is_cuda:
+            torch.cuda.synchronize(blob.device)
+        last_first_broadcast_ms = (time.perf_counter() - t0) * 1e3
     if blob.is_cuda:
         net.set_weight_blob(blob)
     return blob
+
+
+last_first_broadcast_ms = None       # wall time of the most recent broadcast_weights() collective on this rank (None: no collective ran)
+
+
+def gather_floats(values, device=None, group=None):
+    """All-gather of a short list of floats per rank (e.g. a rank's own timed-region seconds): returns [rank][i].  The only collectives of
+    the bench besides the weight broadcast and the result headers; never inside a timed region."""
+    import torch.distributed as dist
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                        device=torch.device(device) if device is not None else torch.device("cpu"))
+    if not dist.is_initialized():
+        return [mine.tolist()]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return [t.tolist() for t in out]
 
 
 def timed_broadcast(blob: torch.Tensor, src: int = 0, repeats: int = 5, group=None) -> float:

@@ -327,3 +327,106 @@ def compute_metrics(net, dataloader, device, config, keypoint_detection_threshol
     tw = thresh_warp if type(thresh_warp) is list else [thresh_warp]
     return {"repeatability": out_rep, "descriptor": compute_desc_dict(descriptor_metrics_dict),
             "homography": compute_homography_dict(overall_pts_dist_dict, tw)}
+
+
+# ------------------------------------------------------------------------------------------------
+# Timing harness: reference benchmark_evaluation.py:16-142 (`desc_process_and_display_sample`) — the callable benchmark.py:149-172
+# drives to print "Two forward passes / Box nms / interpolate" rates.  Same signature, same loop, same `time_dict_seconds` keys.
+# ------------------------------------------------------------------------------------------------
+class _EventSpan:
+    """One timed span on the current HIP stream: hipEvents around the enqueued work (the reference brackets with
+    torch.cuda.synchronize() + time.time(), which on a GPU also counts the host's launch latency of an idle queue)."""
+
+    def __init__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        return False
+
+    def seconds(self):
+        self.e1.synchronize()
+        return self.e0.elapsed_time(self.e1) * 1e-3
+
+
+def desc_process_and_display_sample(net, dataset, device, config, args):
+    """reference benchmark_evaluation.py:16-227.  For every index in args.index: sample -> device -> forward (both spectra) ->
+    box_nms(prob * valid_mask) -> per pair nonzero + interpolate_descriptors; returns
+        time_dict_seconds = {"two_forward": [...], "nms": [...], "interpolate": [...]}      (one entry per sample / per pair)
+    measured with HIP events on the stream the kernels run on.  With args.plot the reference goes on to match, estimate the homography
+    (cv2 MAGSAC), mask the matches by the ground-truth homography and WRITE A PNG (cv2.drawMatches / imwrite, :129-218); cv2 is not
+    part of this path, so the same quantities — keypoints, matches, H_est, the ground-truth matches mask — are computed on the device and
+    written next to where the PNG would go, as `<same stem>.npz`."""
+    import os
+    time_dict_seconds = {"two_forward": [], "nms": [], "interpolate": []}
+    pred = config['prediction']
+    thr = pred['detection_threshold']
+    for index in args.index:
+        data = dataset[index]
+        data = utils.data_to_device(data, device)
+        data = utils.data_unsqueeze(data, 0)
+        with _EventSpan() as t_fwd:
+            if not net.takes_pair():
+                out_optical = net(data['optical'])
+                out_thermal = net(data['thermal'])
+            else:
+                out_optical, out_thermal, out_hm = net(data)
+        time_dict_seconds["two_forward"].append(t_fwd.seconds())
+        with _EventSpan() as t_nms:
+            if pred['nms'] > 0:
+                out_optical['prob'] = utils.box_nms(out_optical['prob'] * data['optical']['valid_mask'], pred['nms'], thr,
+                                                    keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'])
+                out_thermal['prob'] = utils.box_nms(out_thermal['prob'] * data['thermal']['valid_mask'], pred['nms'], thr,
+                                                    keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'])
+        time_dict_seconds["nms"].append(t_nms.seconds())
+        n = data['optical']['image'].shape[0]
+        for spec in ('optical', 'thermal'):                 # add homography to data if not available (reference :88-92)
+            if 'homography' not in data[spec].keys():
+                data[spec]['homography'] = torch.eye(3, dtype=torch.float32).to(device).view(1, 3, 3).repeat(n, 1, 1)
+        H, W = data['optical']['image'].shape[2:]
+        for i in range(n):
+            prob_optical, prob_thermal = out_optical['prob'][i], out_thermal['prob'][i]
+            pred_optical = torch.nonzero((prob_optical.squeeze() > thr).float())
+            pred_thermal = torch.nonzero((prob_thermal.squeeze() > thr).float())
+            with _EventSpan() as t_int:
+                if out_optical['desc'][i].shape[1:] == prob_optical.shape[1:]:
+                    # classic descriptors, directly take values (reference :117-120)
+                    do, dt = out_optical['desc'][i], out_thermal['desc'][i]
+                    desc_optical_sampled = do[:, pred_optical[:, 0], pred_optical[:, 1]].transpose(0, 1)
+                    desc_thermal_sampled = dt[:, pred_thermal[:, 0], pred_thermal[:, 1]].transpose(0, 1)
+                elif 'desc_nhwc' in out_optical:
+                    desc_optical_sampled = utils.interpolate_descriptors_nhwc(pred_optical, out_optical['desc_nhwc'][i], H, W)
+                    desc_thermal_sampled = utils.interpolate_descriptors_nhwc(pred_thermal, out_thermal['desc_nhwc'][i], H, W)
+                else:
+                    desc_optical_sampled = utils.interpolate_descriptors(pred_optical, out_optical['desc'][i], H, W)
+                    desc_thermal_sampled = utils.interpolate_descriptors(pred_thermal, out_thermal['desc'][i], H, W)
+            time_dict_seconds["interpolate"].append(t_int.seconds())
+            if getattr(args, "plot", False):
+                matches = utils.get_matches(desc_optical_sampled, desc_thermal_sampled, pred['matching']['method'], pred['matching']['knn_matches'],
+                                            **pred['matching']['method_kwargs'])
+                kpo, kpt = pred_optical.cpu().numpy().astype(np.float32), pred_thermal.cpu().numpy().astype(np.float32)
+                optical_pts = np.float32([kpo[m.queryIdx][::-1] for m in matches]).reshape(-1, 1, 2)       # cv2.KeyPoint(c[1], c[0]).pt = (x, y)
+                thermal_pts = np.float32([kpt[m.trainIdx][::-1] for m in matches]).reshape(-1, 1, 2)
+                if optical_pts.shape[0] < 4 or thermal_pts.shape[0] < 4:
+                    H_est = np.eye(3, 3)
+                else:
+                    H_est, _ = utils.find_homography(optical_pts, thermal_pts, float(pred['reprojection_threshold']), 10000)
+                # correct matches mask (reference :189-193): matches whose ground-truth reprojection error is below the threshold
+                H_gt = np.matmul(data['thermal']['homography'][i].cpu().numpy(), np.linalg.inv(data['optical']['homography'][i].cpu().numpy()))
+                if len(matches):
+                    warped_optical = warp_keypoints(optical_pts.squeeze(1)[:, ::-1], H_gt)[:, ::-1]
+                    diff = np.linalg.norm(thermal_pts.squeeze(1) - warped_optical, axis=1)
+                    matchesMask = (diff < pred['reprojection_threshold'])
+                else:
+                    matchesMask = np.zeros((0,), bool)
+                save_dir = os.path.join(args.output_dir, 'images', 'supp', 'i' + str(index))
+                os.makedirs(save_dir, exist_ok=True)
+                stem = "{}_{}_i{}_s{}".format(os.path.join(save_dir, args.model_dir.split("/")[-1]), args.version, index, args.seed)
+                np.savez(stem + ".npz", kp_optical=kpo, kp_thermal=kpt, matches=np.array([[m.queryIdx, m.trainIdx] for m in matches], np.int32).reshape(-1, 2),
+                         H_est=np.eye(3) if H_est is None else H_est, matches_mask=matchesMask)
+    return time_dict_seconds

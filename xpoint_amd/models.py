@@ -71,16 +71,22 @@ class XPoint(torch.nn.Module):
         self._wsplit: Optional[torch.Tensor] = None      # split-bf16 copies of the GEMM weights, derived from _blob on the device
         self._blob_t: Optional[torch.Tensor] = None      # multispectral only: the THERMAL encoder + the same heads
         self._wsplit_t: Optional[torch.Tensor] = None
-        # "h2" (default): dense layers on the f16 matrix pipe, f32 operands as two fp16 planes, 3 partial products (f32-grade: an
-        # operand error of 2^-24, csrc/gemm_h2_core.h); "x3": bf16 matrix pipe, three planes, 6 partial products (f32-grade);
-        # both are pinned against the reference.  "f32": exact-f32 MFMA kernels; "x2": 3 bf16 partial products (operands to 16 bits);
-        # "bf16": 1 product = bf16 operands, f32 accumulate — the class of the reference's mixed_precision autocast (XPoint.py:182)
+        # "h2" (default): dense layers on the f16 matrix pipe, f32 operands as two fp16 planes, 3 partial products (f32-grade: operand
+        # error <= 2^-23, <= 2^-21 per product worst case, ~2^-25 typical, csrc/gemm_h2_core.h); "x3": bf16 matrix pipe, three exact planes,
+        # 6 partial products (f32-grade, no range limit); both are pinned against the reference.  "f32": exact-f32 MFMA kernels;
+        # "x2": 3 bf16 partial products (operands to 16 bits); "bf16": 1 product = bf16 operands, f32 accumulate.
+        # h2 needs dense-layer operands below 65504: every forward reports a violation through a device status word
+        # (xp_xpoint_forward_ex), and the host then re-runs on "x3" and stays there for this weight set (self._h2_off).
         self.gemm_mode = os.environ.get("XP_GEMM_MODE", "h2")
+        self._h2_off = False
+        self._status: Dict[str, torch.Tensor] = {}
+        # RegNet head beyond 256x256 (opt-in, NOT reference semantics: the reference's head only accepts 256x256 inputs, RegNet.py:38-52):
+        # adaptive-average-pool the pooled cost-volume map to the 16x16 grid its FC layer was sized for (convmodels.regnet_forward)
+        self.regnet_adaptive_pool = False
         self._device = torch.device("cpu")
         self._ws: Dict[str, torch.Tensor] = {}
         self._conv_impl = None
         self._regnet_w = None
-        self._finite_checked = set()      # gemm modes whose first forward after a weight load was checked for non-finite encoder output
         self.encoder_downsample_ratio = 8
         self.detector_head_last_dim = 65
         self.head_channels = 256
@@ -176,7 +182,7 @@ class XPoint(torch.nn.Module):
         self._wsplit_t = None
         self._conv_impl = None
         self._regnet_w = None
-        self._finite_checked = set()      # gemm modes whose first forward after a weight load was checked for non-finite encoder output
+        self._h2_off = False              # a new weight set gets the default engine back
         return _LoadResult(missing, unexpected)
 
     def _bn_affine(self, pre, eps=1e-5):
@@ -298,14 +304,58 @@ class XPoint(torch.nn.Module):
     def workspace_bytes(self, n_img, H, W) -> int:
         return int(_lib.load().xp_forward_workspace_bytes(self._ctx, n_img, H, W))
 
+    # ------------------------------------------------------------------ range guard
+    def effective_gemm_mode(self) -> str:
+        """gemm_mode, with "h2" replaced by "x3" once this weight set has tripped the split-fp16 range guard."""
+        return "x3" if (self.gemm_mode == "h2" and self._h2_off) else self.gemm_mode
+
+    def status_word(self, device) -> torch.Tensor:
+        """The device status word (int32[1]) that every forward on `device` ORs its XP_STATUS_* bits into (sticky until cleared)."""
+        key = str(device)
+        if key not in self._status:
+            self._status[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._status[key]
+
+    _STATUS_BITS = ((1, "encoder output non-finite or beyond the dense engine's operand range"), (2, "non-finite heat-map logit"),
+                    (4, "non-finite descriptor element"))
+
+    def handle_status(self, st: int, where: str) -> bool:
+        """Host policy for a non-zero status: on the split-fp16 engine switch this weight set to "x3" (warning) and return True = the
+        caller re-runs; on any other engine the outputs are genuinely non-finite: raise."""
+        if st == 0:
+            return False
+        what = "; ".join(t for b, t in self._STATUS_BITS if st & b)
+        if self.effective_gemm_mode() == "h2":
+            import warnings
+            warnings.warn(f"xpoint_amd.XPoint ({where}): {what} on the split-fp16 dense engine (operands must stay below 65504); "
+                          "re-running on gemm_mode 'x3' (split-bf16, no range limit) and keeping it for this weight set", RuntimeWarning, stacklevel=3)
+            self._h2_off = True
+            return True
+        raise RuntimeError(f"xpoint_amd.XPoint ({where}): {what} on gemm_mode {self.effective_gemm_mode()!r} — the weights or the input produce "
+                           "non-finite activations")
+
     def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
-                    is_optical=None):
+                    is_optical=None, check=True):
         """See _forward_raw.  Runs with the images' device as the current device, so every launch below goes to THAT
-        device's current stream (the model may live on cuda:N while another device is current)."""
+        device's current stream (the model may live on cuda:N while another device is current).
+        check=True (default; ignored during stream capture): read the forward's status word (one 4-byte download = a host
+        synchronisation) and, if the split-fp16 engine's range guard tripped, run the forward again on "x3" — the call never returns
+        overflowed results.  Stream-ordered callers (PairPipeline) pass check=False and test the word at their own synchronisation point."""
         if not images.is_cuda:
             raise RuntimeError("xpoint_amd.XPoint runs on the GPU only (no CPU fallback): move the data to 'cuda'")
         with torch.cuda.device(images.device):
-            return self._forward_raw(images, want_prob, want_desc, want_logits, out, workspace, is_optical)
+            res = self._forward_raw(images, want_prob, want_desc, want_logits, out, workspace, is_optical)
+            if check and not torch.cuda.is_current_stream_capturing():
+                word = self.status_word(images.device)
+                st = int(word.item())
+                if st:
+                    word.zero_()
+                    if self.handle_status(st, "forward"):
+                        res = self._forward_raw(images, want_prob, want_desc, want_logits, res if out is None else out, workspace, is_optical)
+                        st = int(word.item())
+                        word.zero_()
+                        self.handle_status(st, "forward, second run")       # raises when "x3" is non-finite as well
+            return res
 
     def _forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
                      is_optical=None):
@@ -346,8 +396,8 @@ class XPoint(torch.nn.Module):
                 thermal = True
             else:       # mixed batch: run each spectrum's images through its encoder and scatter the results back
                 idx_o = torch.nonzero(flags).reshape(-1).to(dev); idx_t = torch.nonzero(~flags).reshape(-1).to(dev)
-                ro = self.forward_raw(images[idx_o], want_prob, want_desc, want_logits, None, workspace, [True] * int(idx_o.numel()))
-                rt = self.forward_raw(images[idx_t], want_prob, want_desc, want_logits, None, workspace, [False] * int(idx_t.numel()))
+                ro = self._forward_raw(images[idx_o], want_prob, want_desc, want_logits, None, workspace, [True] * int(idx_o.numel()))
+                rt = self._forward_raw(images[idx_t], want_prob, want_desc, want_logits, None, workspace, [False] * int(idx_t.numel()))
                 res = {}
                 for k, v in ro.items():
                     if v is None:
@@ -368,7 +418,8 @@ class XPoint(torch.nn.Module):
         lib = _lib.load()
         if self.gemm_mode not in _DENSE_PRODUCTS:
             raise RuntimeError(f"XPoint.gemm_mode must be one of {sorted(_DENSE_PRODUCTS)}, got {self.gemm_mode!r}")
-        split_mode = self.gemm_mode != "f32"
+        mode = self.effective_gemm_mode()
+        split_mode = mode != "f32"
         blob = self._blob_t if thermal else self._blob
         ws_split = self._wsplit_t if thermal else self._wsplit
         if split_mode and ws_split is None:
@@ -396,8 +447,8 @@ class XPoint(torch.nn.Module):
         # the precision class is process-wide in the library and read when a kernel is launched: set for the duration of this
         # (host-synchronous) enqueue, then back to the default.  Not safe against OTHER host threads enqueueing dense kernels at the
         # same time: one enqueueing thread per process (the reference's scripts are single-threaded; multi-GPU = one process per GPU)
-        nprod = _DENSE_PRODUCTS[self.gemm_mode]
-        engine = _DENSE_ENGINE.get(self.gemm_mode, 0)
+        nprod = _DENSE_PRODUCTS[mode]
+        engine = _DENSE_ENGINE.get(mode, 0)
         prev = int(lib.xp_get_dense_products())          # whatever XP_DENSE_PRODUCTS / an earlier caller left: restored afterwards
         prev_engine = int(lib.xp_get_dense_engine())
         if nprod != prev:
@@ -405,22 +456,14 @@ class XPoint(torch.nn.Module):
         if engine != prev_engine:
             _lib.call("xp_set_dense_engine", engine)
         try:
-            _lib.check(lib.xp_xpoint_forward(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
-                                             ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
-                                             _lib.current_stream()), "xp_xpoint_forward")
+            _lib.check(lib.xp_xpoint_forward_ex(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
+                                                ptr(self.status_word(dev)), _lib.current_stream()), "xp_xpoint_forward_ex")
         finally:
             if nprod != prev:
                 _lib.call("xp_set_dense_products", prev)
             if engine != prev_engine:
                 _lib.call("xp_set_dense_engine", prev_engine)
-        if self.gemm_mode not in self._finite_checked and not torch.cuda.is_current_stream_capturing():
-            # One-time sanity check per weight load and dense back end (one host synchronisation): the split-fp16 engine overflows where
-            # an activation exceeds 65504, and the heads' ReLU (max(NaN, 0) = 0 on the GPU) would turn a NaN encoder map into finite,
-            # wrong scores.  Weights whose first forward is clean are taken as in range; PairPipeline.verify() checks every fetched step.
-            self._finite_checked.add(self.gemm_mode)
-            if not bool(torch.isfinite(out["enc_nhwc"]).all()):
-                raise RuntimeError("xpoint_amd.XPoint: non-finite encoder output"
-                                   + (" — activations beyond the fp16 range of gemm_mode 'h2' (|x| < 65504)? set gemm_mode = 'x3'" if self.gemm_mode == "h2" else ""))
         return out
 
     @staticmethod
@@ -476,7 +519,7 @@ class XPoint(torch.nn.Module):
                 raise NotImplementedError("only homography_regression_head.type 'RegNet' (XPoint-EXP1 params) is implemented")
             if self._regnet_w is None:
                 self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
-            pred_hm = regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
+            pred_hm = regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:], adaptive_pool=self.regnet_adaptive_pool)
         return pred_optical, pred_thermal, pred_hm
 
     def predict_homography(self, optical, thermal):
@@ -491,4 +534,4 @@ class XPoint(torch.nn.Module):
         raw = self.forward_raw(torch.cat([optical, thermal], 0), want_prob=False, want_desc=False, is_optical=flags)
         if self._regnet_w is None:
             self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
-        return regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:])
+        return regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:], adaptive_pool=self.regnet_adaptive_pool)

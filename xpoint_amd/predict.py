@@ -93,7 +93,7 @@ class PairPipeline:
     keypoint extraction, descriptor sampling, mutual-NN matching.  Results stay on the GPU; `fetch()`
     synchronises, checks NMS convergence / capacity and returns host lists."""
 
-    def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=6, overlap=False,
+    def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=8, overlap=False,
                  split_encoder=False, estimate_homography=False, ransac_iters=10000, alternate_encoders=False):
         """overlap=True: two HIP streams — the encoder of call i+1 runs while the detection / matching kernels of call i
         (many small, latency-bound launches) are still in flight; encoder outputs are double-buffered.  Results of a
@@ -116,6 +116,11 @@ class PairPipeline:
         self.sweeps = int(nms_sweeps)
         dev = net._device if getattr(net, "_device", None) is not None and net._device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
         self.device = dev
+        with torch.cuda.device(dev):            # streams / events below belong to the model's device, whatever device is current
+            self._init_buffers(net, H, W, estimate_homography, ransac_iters)
+
+    def _init_buffers(self, net, H, W, estimate_homography, ransac_iters):
+        dev = self.device
         n = 2 * self.B
         lib = _lib.load()
         nbuf = self.depth
@@ -160,6 +165,9 @@ class PairPipeline:
                            n_inliers=torch.zeros((P,), dtype=torch.int32, device=dev),
                            ws=torch.empty(lib.xp_find_homography_workspace_bytes(P) // 8 + 1, dtype=torch.float64, device=dev))
         self.raw = None
+        self._last = None            # (buffer set, masked) of the latest call: what verify() re-runs when the range guard trips
+        self._graphs = None
+        self._capture_masked = None
 
     def run(self, optical, thermal, mask_optical=None, mask_thermal=None):
         if (mask_optical is None) != (mask_thermal is None):
@@ -170,10 +178,12 @@ class PairPipeline:
     def _run(self, optical, thermal, mask_optical, mask_thermal):
         if not self.overlap:
             self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
+            self._last = (0, mask_optical is not None)
             self._encode(0, None, None)
             return self._post(0, mask_optical is not None, None)
         k = self._call % self.depth
         self._call += 1
+        self._last = (k, mask_optical is not None)
         cur = torch.cuda.current_stream()
         # inputs are taken over on the CALLER's stream (so the caller may reuse its tensors right after run() returns),
         # once the call before last has finished with buffer k
@@ -194,7 +204,7 @@ class PairPipeline:
                     view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
                     fl = self._flags()
                     self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
-                                         is_optical=None if fl is None else fl[sl])
+                                         is_optical=None if fl is None else fl[sl], check=False)
                     self.encs_done[k][h].record()
                 self.post_stream.wait_event(self.encs_done[k][h])
         else:
@@ -242,7 +252,9 @@ class PairPipeline:
         if optical is not None:
             self._stage_inputs(k, optical, thermal, None, None)
         ws = self.alt_ws[k] if getattr(self, "alternate", False) else None
-        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], workspace=ws, is_optical=self._flags())
+        # check=False: stream-ordered, no host synchronisation here; the forward's status word is read in verify() / fetch() / download_async()
+        self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], workspace=ws, is_optical=self._flags(),
+                                             check=False)
 
     def _post(self, k, masked=False, _unused=None):
         B, H, W, n = self.B, self.H, self.W, 2 * self.B
@@ -252,11 +264,11 @@ class PairPipeline:
         self.raw = raw
         self.images = self.images_b[k]
         prob = raw["prob"]
-        if masked:
-            _lib.check(lib.xp_mul_mask(ptr(prob), ptr(self.mask_b[k]), ptr(self.prob_masked), n * H * W, st), "xp_mul_mask")
-            prob = self.prob_masked
         thr = float(self.pred['detection_threshold'])
         if self.pred['nms'] > 0:
+            if masked:          # the mask is applied on the NMS branch only, like predict_align_image_pair.py:194-205 (and predict_align_image_pair above)
+                _lib.check(lib.xp_mul_mask(ptr(prob), ptr(self.mask_b[k]), ptr(self.prob_masked), n * H * W, st), "xp_mul_mask")
+                prob = self.prob_masked
             _lib.check(lib.xp_box_nms(ptr(prob), ptr(self.prob_nms), ptr(self.nms_ws), self.nms_ws.numel(), n, H, W,
                                       float(self.pred['nms']), thr, 0.1, int(self.pred['topk']), self.cap, self.sweeps, None, st),
                        "xp_box_nms")
@@ -299,53 +311,27 @@ class PairPipeline:
             for _ in range(self.depth):                         # warm-up outside capture: one-time allocations, every buffer set
                 self._run(optical, thermal, mask_optical, mask_thermal)
             torch.cuda.synchronize()
-            masked = mask_optical is not None
+            self._settle_engine()                               # a range-guard trip during warm-up switches the engine BEFORE anything is captured
+            self._capture_masked = mask_optical is not None
+            self._capture_graphs()
             if not self.overlap:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._encode(0, None, None)
-                    self._post(0, masked, None)
-                self._graphs = g
-
                 def replay(optical, thermal, mask_optical=None, mask_thermal=None):
                     self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
-                    g.replay()
+                    self._last = (0, mask_optical is not None)
+                    self._graphs.replay()
                     return self
                 return replay
-            S = max(self.split_encoder, 1)
-            graphs = []
-            streams_of = lambda k: self.enc_streams if self.split_encoder else [self.enc_streams[k] if self.alternate else self.enc_stream]
-            for k in range(self.depth):
-                enc_g = []
-                gsz = 2 * self.B // S
-                for h, stream in enumerate(streams_of(k)):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream):
-                        if self.split_encoder:
-                            sl = slice(h * gsz, (h + 1) * gsz)
-                            view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
-                            fl = self._flags()
-                            self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
-                                                 is_optical=None if fl is None else fl[sl])
-                        else:
-                            self._encode(k, None, None)
-                    enc_g.append(g)
-                pg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(pg, stream=self.post_stream):
-                    self._post(k, masked, None)
-                graphs.append((enc_g, pg))
-            self._graphs = graphs
-            torch.cuda.synchronize()
 
             def replay(optical, thermal, mask_optical=None, mask_thermal=None):
                 with torch.cuda.device(self.device):
                     k = self._call % self.depth
                     self._call += 1
+                    self._last = (k, mask_optical is not None)
                     cur = torch.cuda.current_stream()
                     cur.wait_event(self.post_done[k])
                     self._stage_inputs(k, optical, thermal, mask_optical, mask_thermal)
-                    enc_g, pg = graphs[k]
-                    for h, stream in enumerate(streams_of(k)):
+                    enc_g, pg = self._graphs[k]
+                    for h, stream in enumerate(self._streams_of(k)):
                         stream.wait_stream(cur)
                         with torch.cuda.stream(stream):
                             enc_g[h].replay()
@@ -359,6 +345,68 @@ class PairPipeline:
                 return self
             return replay
 
+    def _streams_of(self, k):
+        return self.enc_streams if self.split_encoder else [self.enc_streams[k] if self.alternate else self.enc_stream]
+
+    def _capture_graphs(self):
+        """(Re)capture the step's graphs with the dense engine in force now; buffers exist (warm-up done), device synchronised."""
+        masked = self._capture_masked
+        if not self.overlap:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._encode(0, None, None)
+                self._post(0, masked, None)
+            self._graphs = g
+            return
+        S = max(self.split_encoder, 1)
+        graphs = []
+        for k in range(self.depth):
+            enc_g = []
+            gsz = 2 * self.B // S
+            for h, stream in enumerate(self._streams_of(k)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    if self.split_encoder:
+                        sl = slice(h * gsz, (h + 1) * gsz)
+                        view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
+                        fl = self._flags()
+                        self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
+                                             is_optical=None if fl is None else fl[sl], check=False)
+                    else:
+                        self._encode(k, None, None)
+                enc_g.append(g)
+            pg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(pg, stream=self.post_stream):
+                self._post(k, masked, None)
+            graphs.append((enc_g, pg))
+        self._graphs = graphs
+        torch.cuda.synchronize()
+
+    def _settle_engine(self):
+        """After a device-wide synchronisation: read and clear the forward status word.  Non-zero on the split-fp16 engine = an operand left
+        the fp16 range: the model switches to "x3" for this weight set (warning), captured graphs are re-captured on it, and the latest call
+        is computed again from its staged inputs — the results the caller reads next are never the overflowed ones.  Non-zero on any other
+        engine raises (models.XPoint.handle_status).  Returns True when it re-ran."""
+        if not hasattr(self.net, "status_word"):
+            return False
+        word = self.net.status_word(self.device)
+        st = int(word.item())
+        if st == 0:
+            return False
+        word.zero_()
+        self.net.handle_status(st, "PairPipeline")          # raises unless the h2 -> x3 switch applies
+        if self._graphs is not None:
+            self._capture_graphs()
+        if self._last is not None:
+            k, masked = self._last
+            self._encode(k, None, None)
+            self._post(k, masked, None)
+            torch.cuda.synchronize()
+            st = int(word.item())
+            word.zero_()
+            self.net.handle_status(st, "PairPipeline, second run")
+        return True
+
     def download_async(self):
         """Streaming use: enqueue — right behind the detection / matching kernels of the last run() / replay — the copies of its result
         lists (keypoint counts and coordinates, match counts and index lists, distances; the homography fields when estimated) into
@@ -371,6 +419,8 @@ class PairPipeline:
                     return torch.empty(t.shape, dtype=t.dtype, device="cpu").pin_memory()
                 src = dict(counts=self.counts, kp=self.kp, match_count=self.m["match_count"], match_q=self.m["match_q"], match_t=self.m["match_t"],
                            match_d=self.m["match_d"])
+                if hasattr(self.net, "status_word"):
+                    src["status"] = self.net.status_word(self.device)      # XP_STATUS_* bits of the forwards so far: non-zero = call verify()
                 if self.estimate_homography:
                     src.update(H_est=self.hg["H"], n_inliers=self.hg["n_inliers"], matchesMask=self.hg["mask"])
                 self._host_src = src
@@ -388,22 +438,36 @@ class PairPipeline:
 
     def verify(self):
         """After a synchronisation point: the async NMS must have reached its fixed point and no list may have
-        overflowed its capacity.  Raises otherwise (the caller can re-run with more sweeps / capacity)."""
+        overflowed its capacity.  Raises otherwise (the caller can re-run with more sweeps / capacity).  Also settles the dense engine's
+        range guard (see _settle_engine): never raises for an fp16-range overflow, falls back instead."""
         lib = _lib.load()
+        # range guard of the split-fp16 dense engine (include/xpoint_hip.h, xp_xpoint_forward_ex): the forwards' status word.  A trip re-runs the
+        # latest call on "x3" (and keeps that engine), so the checks below — and the caller — see the repaired results.
+        self._settle_engine()
         if self.pred['nms'] > 0:
             left = c_i(-1)
             _lib.check(lib.xp_box_nms_check(ptr(self.nms_ws), 2 * self.B, self.H, self.W, ctypes.byref(left), _lib.current_stream()),
                        "xp_box_nms_check")
-            if left.value != 0:
-                raise RuntimeError(f"PairPipeline: NMS not converged after {self.sweeps} sweeps ({left.value} tiles undecided)")
+            while left.value != 0:
+                # The stream-ordered NMS enqueues a fixed number of sweeps (sweeps past the fixed point exit at once); an image whose suppression
+                # chains need more is NOT an error of the data: raise the count (kept for later calls), recompute the latest call's detection /
+                # matching stages from its encoder outputs, and check again — the caller never sees a half-converged heat map.
+                if self.sweeps >= 64 or self._last is None:
+                    raise RuntimeError(f"PairPipeline: NMS not converged after {self.sweeps} sweeps ({left.value} tiles undecided)")
+                import warnings
+                warnings.warn(f"PairPipeline: NMS needed more than {self.sweeps} sweeps ({left.value} tiles undecided); re-running the step's "
+                              f"post-processing with {min(64, 2 * self.sweeps)} and keeping that count", RuntimeWarning, stacklevel=2)
+                self.sweeps = min(64, 2 * self.sweeps)
+                if self._graphs is not None:
+                    self._capture_graphs()
+                k, masked = self._last
+                self._post(k, masked, None)
+                torch.cuda.synchronize()
+                _lib.check(lib.xp_box_nms_check(ptr(self.nms_ws), 2 * self.B, self.H, self.W, ctypes.byref(left), _lib.current_stream()),
+                           "xp_box_nms_check")
         mx = int(self.counts.max().item())
         if mx > self.cap:
             raise RuntimeError(f"PairPipeline: {mx} keypoints exceed capacity {self.cap}")
-        if self.raw is not None and self.raw.get("enc_nhwc") is not None and not bool(torch.isfinite(self.raw["enc_nhwc"]).all()):
-            # Checked on the ENCODER output: the heads' ReLU (max(NaN, 0) = 0 on the GPU) would wash a NaN out into finite, wrong scores.
-            # The split-fp16 dense engine needs activations below 65504 (include/xpoint_hip.h, xp_xpoint_forward); the split-bf16 one has no such limit.
-            raise RuntimeError("PairPipeline: non-finite encoder output"
-                               + (" — activations beyond the fp16 range of gemm_mode 'h2'? retry with net.gemm_mode = 'x3'" if getattr(self.net, "gemm_mode", "") == "h2" else ""))
 
     def fetch(self):
         torch.cuda.synchronize()        # device-wide: covers both streams of the overlapped mode

@@ -1,0 +1,76 @@
+"""BASELINE config C5 as a callable: the streaming, hipGraph-replayed pair step with the homography-regression head.
+
+Every step takes its B pairs from (pinned) host memory, replays the captured encode + detect + describe + match graphs of an overlapped
+`PairPipeline`, runs the reference's RegNet head (xpoint/models/RegNet.py:7-52) on the 256x256 top-left crop of every pair — the only input size
+that head is defined for (its FC layer is sized for a 32x32 encoder map, RegNet.py:38-52) — from a second captured graph, and
+enqueues the downloads of the result lists and of `hm` into pinned host buffers behind the step's last kernel.  The host consumes step i-1 while
+step i runs (two buffer sets alternate).  `bench.py --config c5` times exactly this object; tests/test_gpu_configs.py checks it against the
+reference fixtures g15 (lists) and g21 (hm)."""
+from __future__ import annotations
+
+import torch
+
+from .predict import PairPipeline
+
+CROP = 256
+
+
+class StreamingRegistrationStep:
+    def __init__(self, pipe: PairPipeline, net_hm, warm_optical, warm_thermal, mask_optical=None, mask_thermal=None):
+        """pipe: an overlapped PairPipeline (not yet captured); net_hm: models.XPoint with homography_regression_head.check on a 256x256
+        configuration (same encoder weights); warm_*: device images (B,1,H,W) used for the warm-up passes of the two captures."""
+        self.pipe, self.net_hm = pipe, net_hm
+        B, dev = pipe.B, pipe.device
+        self.B = B
+        with torch.cuda.device(dev), torch.no_grad():
+            self.replay = pipe.capture(warm_optical, warm_thermal, mask_optical, mask_thermal)
+            self.crop_o = torch.empty((B, 1, CROP, CROP), device=dev)
+            self.crop_t = torch.empty((B, 1, CROP, CROP), device=dev)
+            self._cut(warm_optical, warm_thermal)
+            for _ in range(2):                              # warm-up outside capture (allocations; a range-guard trip settles the engine here)
+                self.hm = net_hm.predict_homography(self.crop_o, self.crop_t)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.hm = net_hm.predict_homography(self.crop_o, self.crop_t)
+            self._hm_engine = net_hm.effective_gemm_mode()
+            self.hm_host = [torch.empty(self.hm.shape, dtype=self.hm.dtype).pin_memory() for _ in range(2)]
+            self.hm_ev = [torch.cuda.Event() for _ in range(2)]
+        self._i = 0
+
+    def _cut(self, o_img, t_img):
+        self.crop_o.copy_(o_img[:, :, :CROP, :CROP]); self.crop_t.copy_(t_img[:, :, :CROP, :CROP])
+
+    def __call__(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        """Enqueue one step.  Returns (bufs, event, hm_host, hm_event): pinned host buffers of THIS step, valid after the two events.
+        bufs["status"] != 0 (forward status word, see PairPipeline.download_async) means the caller must run pipe.verify()."""
+        pipe = self.pipe
+        with torch.cuda.device(pipe.device), torch.no_grad():
+            self.replay(optical, thermal, mask_optical, mask_thermal)
+            # the crops are cut outside the graph: their source alternates between the pipeline's input buffers
+            self._cut(pipe.images[:self.B], pipe.images[self.B:])
+            self.graph.replay()
+            j = self._i & 1
+            self._i += 1
+            self.hm_host[j].copy_(self.hm, non_blocking=True)
+            self.hm_ev[j].record()
+            bufs, ev = pipe.download_async()
+        return bufs, ev, self.hm_host[j], self.hm_ev[j]
+
+    def verify(self):
+        """At a synchronisation point: PairPipeline.verify() (NMS convergence, capacities, the dense engine's range guard incl. its x3
+        fallback) and the same guard for the head's forward: a trip re-captures the head graph on "x3" and recomputes `hm` for the latest crops."""
+        torch.cuda.synchronize()
+        self.pipe.verify()
+        word = self.net_hm.status_word(self.pipe.device)
+        st = int(word.item())
+        if st:
+            word.zero_()
+            if self.net_hm.handle_status(st, "StreamingRegistrationStep head"):
+                with torch.cuda.device(self.pipe.device), torch.no_grad():
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph):
+                        self.hm = self.net_hm.predict_homography(self.crop_o, self.crop_t)
+                    self.graph.replay()
+                    torch.cuda.synchronize()
+        return self

@@ -232,6 +232,63 @@ def make_torch_state_dict(cfg: dict, **kw):
 
 
 # ------------------------------------------------------------------------------------------
+# "trained-like" weight statistics: the parity fixtures above use default-init-like weights whose
+# activations stay below ~14.  Trained VMamba checkpoints have heavy-tailed LayerNorm gains and a few outlier channels in the
+# residual stream, which reach the un-normalised downsample convolutions (reference VMamba.py:1405-1440).  This profile keeps
+# the generator's exactness rules (hash uniforms, exact float32 multiply / add, powers of two by ldexp — no libm).
+# ------------------------------------------------------------------------------------------
+
+def _hash_int(name: str, n: int, lo: int, hi: int) -> np.ndarray:
+    """n integers in [lo, hi] from the name's hash stream (exact: floor of a 24-bit uniform times the range)."""
+    u = hash_uniform(name, n).astype(np.float64)
+    return (np.floor(u * (hi - lo + 1)).astype(np.int64) + lo).clip(lo, hi)
+
+
+def make_trained_like_state_dict(cfg: dict, tag: str = "xpoint-trainedlike-v1", detector_gain: float = DETECTOR_GAIN,
+                                 gain_exp=(-4, 3), outlier_frac=0.01, outlier_scale=100.0, head_in_exp=-7) -> "OrderedDict[str, np.ndarray]":
+    """make_state_dict with trained-like statistics:
+      * every LayerNorm gain log-uniform over 2^gain_exp[0] .. 2^(gain_exp[1] + 1) (default 0.0625 .. 16): (1 + u) * 2^k;
+      * outlier_frac of the OUTPUT channels (at least one) of the patch-embed and downsample convolutions scaled by outlier_scale —
+        those feed LayerNorms whose statistics they then dominate — and the same fraction of the block out_proj / fc2 rows, which write
+        straight into the residual stream the downsample convolutions read un-normalised;
+      * dt_projs_bias at both ends of its range (softplus^-1 of 1e-3 and of 0.1) instead of uniform between them;
+      * the heads' first convolutions scaled by 2^head_in_exp: the encoder output is the RAW residual stream (no final norm, VMamba.py:1500-1505),
+        here ~1e3, and trained heads are adapted to their input's scale (their BatchNorm statistics are fixed numbers, not a normalisation)."""
+    sd = make_state_dict(cfg, tag=tag, detector_gain=detector_gain)
+    spec = xpoint_state_spec(cfg)
+    for name, (shape, kind) in spec.items():
+        key = tag + "/" + name
+        if kind == "ln_w":
+            k = _hash_int(key + "/exp", shape[0], gain_exp[0], gain_exp[1])
+            sd[name] = np.ldexp(np.float32(1.0) + hash_uniform(key + "/mant", shape[0]), k).astype(np.float32)
+        elif kind == "dt_b":
+            bit = _hash_int(key + "/end", int(np.prod(shape)), 0, 1).reshape(shape)
+            sd[name] = np.where(bit == 1, np.float32(-2.25), np.float32(-6.9)).astype(np.float32)
+        elif (kind == "conv_w" and (".patch_embed." in name or ".downsample." in name)) or \
+                (kind == "lin_w" and (name.endswith("op.out_proj.weight") or name.endswith("mlp.fc2.weight"))):
+            co = shape[0]
+            n_out = max(1, int(round(outlier_frac * co)))
+            rows = _hash_int(key + "/outliers", n_out, 0, co - 1)
+            w = sd[name].copy()
+            w[rows] = (w[rows] * np.float32(outlier_scale)).astype(np.float32)
+            sd[name] = w
+    for h in ("detector_head_convolutions", "descriptor_head_convolutions"):
+        sd[h + ".1.weight"] = np.ldexp(sd[h + ".1.weight"], head_in_exp).astype(np.float32)
+    return sd
+
+
+def make_contrast_pair(pair_index: int, H: int, W: int):
+    """A pair at the contrast extremes: the optical image nearly flat (0.5 +- 2^-7, a hazy frame), the thermal one saturated (values pushed
+    to exactly 0 / 1 outside the middle band, a hot-spot frame).  Same dict layout as make_pair_batch(pair_index, 1, H, W)."""
+    d = make_pair_batch(pair_index, 1, H, W)
+    o = d["optical"]["image"]
+    d["optical"]["image"] = (np.float32(0.5) + (o - np.float32(0.5)) * np.float32(1.0 / 64.0)).astype(np.float32)
+    t = d["thermal"]["image"]
+    d["thermal"]["image"] = np.where(t < np.float32(0.25), np.float32(0.0), np.where(t > np.float32(0.75), np.float32(1.0), t)).astype(np.float32)
+    return d
+
+
+# ------------------------------------------------------------------------------------------
 # conv-encoder XPoint (BASELINE config 1, reference XPoint.py:451-466, model_weights/multipoint/params.yaml)
 # ------------------------------------------------------------------------------------------
 
