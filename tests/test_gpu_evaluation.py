@@ -250,7 +250,7 @@ def test_desc_process_and_display_sample_time_dict(gpu_lib, tmp_path):
         def __getitem__(self, i):
             d = synth.to_torch(synth.make_pair_batch(i, 1, H, W))
             return {s: {k: v[0] for k, v in d[s].items()} for s in d}
-    config = dict(CONFIG); config["prediction"] = dict(CONFIG["prediction"], nms=8, topk=0, cpu_nms=True, reprojection_threshold=3)
+    config = dict(CONFIG); config["prediction"] = dict(CONFIG["prediction"], detection_threshold=0.015, nms=8, topk=0, cpu_nms=True, reprojection_threshold=3)
     args = types.SimpleNamespace(index=[0, 3, 5], plot=False, radius=4, output_dir=str(tmp_path), model_dir="model_weights/xpoint", version="synth", seed=0)
     with torch.no_grad():
         td = ev.desc_process_and_display_sample(net, DS(), "cuda", config, args)

@@ -311,6 +311,9 @@ class XPoint(torch.nn.Module):
 
     def status_word(self, device) -> torch.Tensor:
         """The device status word (int32[1]) that every forward on `device` ORs its XP_STATUS_* bits into (sticky until cleared)."""
+        device = torch.device(device)
+        if device.index is None:                       # "cuda" and "cuda:0" must name the same word
+            device = torch.device("cuda", torch.cuda.current_device())
         key = str(device)
         if key not in self._status:
             self._status[key] = torch.zeros(1, dtype=torch.int32, device=device)
