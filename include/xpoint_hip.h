@@ -133,6 +133,21 @@ int xp_get_dense_products(void);
  * xp_prepare_split_weights holds both formats. */
 int xp_set_dense_engine(int engine);
 int xp_get_dense_engine(void);
+/* Mixed-precision class "amp16" — the arithmetic of the reference's `mixed_precision: true` deployment (XPoint.py:182: torch.cuda.amp.autocast
+ * around the forward; half is autocast's default dtype): process-wide, read at launch time.
+ *   1  every operation that autocast ends in a half tensor rounds its output to fp16 (round to nearest even; the values stay in f32 containers):
+ *      the bias add, GELU, eval-BatchNorm affine and residual add of xp_gemm_nt_h2 / xp_conv3x3_nhwc_h2, xp_layernorm, both stages of
+ *      xp_dwconv3x3_silu, the three stages of xp_stem_conv_ln_gelu (which also takes the image as half), the dt projection inside
+ *      xp_ss2d_core_fwd (rounded before its f32 bias is added, csms6s.py:47-50) and the SS2D output (VMamba.py:646 `y.to(x.dtype)`); the scan,
+ *      out_norm, softmax and normalize stay f32, as the reference's do (csms6s.py:52, XPoint.py:349,363).  xp_xpoint_forward(_ex) then runs
+ *      every block as separate launches on the split-fp16 engine; the caller passes weights whose convolution / linear tensors were rounded to
+ *      fp16 (autocast casts them; models.XPoint does this for gemm_mode "amp16"), so every product is one exact fp16 x fp16 MFMA product.
+ *   0  (default) off.
+ * Pinned against the real reference run under fp16 CPU autocast (tests/golden/g20); never the headline class. */
+int xp_set_amp_mode(int mode);
+int xp_get_amp_mode(void);
+/* y[i] = (float)(half)x[i] (round to nearest even), n floats, 16-byte aligned buffers; in place allowed.  The `.half()` of the class above. */
+int xp_round_f16(const float* x, float* y, int64_t n, void* stream);
 
 /* Fused VSS-block MLP branch, in place:  X <- X + fc2(GELU(fc1(LayerNorm(X)) + b1)) + b2   (reference
  * VMamba.py:1230-1234 VSSBlock.forward second residual, :110-128 Mlp; LayerNorm over C, biased variance, eps;

@@ -274,6 +274,59 @@ def gen_g19():
     np.savez_compressed(os.path.join(OUT, "g19_trained_like.npz"), **g)
 
 
+def gen_g20():
+    """G20 — the reference's MIXED-PRECISION deployment class (`mixed_precision: true` -> `torch.cuda.amp.autocast()` around the
+    forward, XPoint.py:182).  The reference tree is untouched: the harness points `torch.cuda.amp.autocast` at `torch.autocast("cpu", dtype=
+    torch.float16)` — float16 is the dtype CUDA autocast selects by default, and PyTorch's CPU autocast runs the same recipe shape (convolutions and
+    linear layers on half operands with half outputs, the scan in f32 on half-rounded inputs (csms6s.py:47-67), softmax / normalize in f32 behind
+    the heads' `.to(torch.float)`, XPoint.py:349,363).  It is a stand-in for the CUDA recipe, not the CUDA recipe: on CPU LayerNorm keeps its
+    half input dtype, CUDA autocast runs it in f32.  Stored: 64x96 full outputs, 224x320 prob / strided desc / end-to-end lists, 480x640 summaries —
+    each beside the same model's f32 outputs (so a test can show that a device class sits closer to this fixture than f32 does)."""
+    torch.set_num_threads(1)
+    stubs.install()
+    import torch.cuda.amp as amp
+    import xpoint.utils as ref_utils
+    real_autocast = amp.autocast
+    g = {}
+    try:
+        amp.autocast = lambda *a, **k: torch.autocast("cpu", dtype=torch.float16)
+        for tag, H, W in (("64x96", 64, 96), ("224x320", 224, 320), ("480x640", 480, 640)):
+            cfg = synth.xpoint_exp1_config(H, W)
+            assert cfg["mixed_precision"] is True
+            net = build_ref.build_reference_xpoint(cfg, synth.make_state_dict(cfg))
+            cfg32 = synth.xpoint_exp1_config(H, W); cfg32["mixed_precision"] = False
+            net32 = build_ref.build_reference_xpoint(cfg32, synth.make_state_dict(cfg32))
+            data = synth.to_torch(synth.make_pair_batch(0, 1, H, W))
+            with torch.no_grad():
+                o, t, _ = net(data)
+                o32, t32, _ = net32(data)
+            assert o["encoder_output"].dtype == torch.float16 and o["prob"].dtype == torch.float32
+            kps, descs = [], []
+            for spec, r, r32 in (("optical", o, o32), ("thermal", t, t32)):
+                if tag == "64x96":
+                    for k in ("prob", "desc", "encoder_output"):
+                        g[f"{tag}/{spec}/{k}"] = r[k].float().numpy()
+                elif tag == "224x320":
+                    g[f"{tag}/{spec}/prob"] = r["prob"].numpy()
+                    g[f"{tag}/{spec}/desc"] = r["desc"][:, :, ::2, ::2].numpy()
+                else:
+                    g[f"{tag}/{spec}/prob_rows"] = r["prob"][0, 0, ::16].numpy()
+                    g[f"{tag}/{spec}/desc_cols"] = r["desc"][0, :, ::6, ::8].numpy()
+                g[f"{tag}/{spec}/amp_vs_f32"] = np.array([float((r["prob"] - r32["prob"]).abs().max()), float((r["desc"] - r32["desc"]).abs().max()),
+                                                          float((r["encoder_output"].float() - r32["encoder_output"]).abs().max())])
+                pn = ref_utils.box_nms(r["prob"] * data[spec]["valid_mask"], 8, 0.015, keep_top_k=0, on_cpu=True)
+                kp = torch.nonzero((pn[0].squeeze() > 0.015).float())
+                kps.append(kp)
+                descs.append(ref_utils.interpolate_descriptors(kp, r["desc"][0], H, W))
+                g[f"{tag}/kp_{spec}"] = kp.numpy().astype(np.int16)
+            ms = ref_utils.get_matches(descs[0].numpy(), descs[1].numpy(), "nnmatcher", False, threshold=10.0)
+            g[f"{tag}/matches"] = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int16).reshape(-1, 2)
+            print("g20", tag, "amp vs f32 (prob, desc, enc):", g[f"{tag}/optical/amp_vs_f32"], "kpts", len(kps[0]), len(kps[1]), "matches", len(ms), flush=True)
+    finally:
+        amp.autocast = real_autocast
+    np.savez_compressed(os.path.join(OUT, "g20_mixed_precision_fp16.npz"), **g)
+
+
 def gen_g16():
     """G16 — BASELINE config C4 through the REAL reference: one synthetic 1024x1024 pair, box_nms(8, 0.015, keep_top_k=4096),
     nonzero, interpolate_descriptors, NNMatcher (strict mutual NN): the 4k x 4k x 256 match.  Keypoints, their scores, match

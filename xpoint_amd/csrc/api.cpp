@@ -112,6 +112,18 @@ extern "C" int xp_set_dense_engine(int engine) {
     g_dense_engine.store(engine);
     return XP_OK;
 }
+// Mixed-precision class ("amp16"): the arithmetic of the reference's `mixed_precision: true` deployment (XPoint.py:182, autocast):
+// convolutions / linear layers on half operands with half outputs, LayerNorm / GELU / SiLU / BatchNorm / residual adds returning half tensors,
+// the scan, out_norm, softmax and normalize in f32.  Process-wide, read at launch time by xp_gemm_nt_h2 / xp_conv3x3_nhwc_h2 (epilogue rounding),
+// xp_layernorm, xp_dwconv3x3_silu, xp_stem_conv_ln_gelu, xp_ss2d_core_fwd and xp_xpoint_forward(_ex).
+static std::atomic<int> g_amp_mode{0};
+int xp_amp_value() { return g_amp_mode.load(); }
+extern "C" int xp_get_amp_mode(void) { return g_amp_mode.load(); }
+extern "C" int xp_set_amp_mode(int mode) {
+    XP_CHECK_ARG(mode == 0 || mode == 1, "xp_set_amp_mode: 0 (off) or 1 (fp16 rounding at the autocast boundaries); got %d", mode);
+    g_amp_mode.store(mode);
+    return XP_OK;
+}
 extern "C" int xp_set_dense_products(int n) {
     XP_CHECK_ARG(n == 6 || n == 3 || n == 1, "xp_set_dense_products: 6 (f32-grade, default), 3 (two-plane operands) or 1 (plain bf16 operands); got %d", n);
     g_dense_products.store(n);

@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 // accumulates its taps in (kh, kw) order with padded taps skipped — input rows arrive in ascending order, and an input row ih
 // is tap kh = ih - oh + 1 of output row oh — so results are bit-identical to the one-row form.
 constexpr int DW_PW = 4, DW_PH = 4;
+__device__ __forceinline__ float ew_r16(float v) { return (float)(_Float16)v; }
+// AMP (xp_set_amp_mode): the convolution's output and the SiLU's output are half tensors under autocast: both rounded to fp16
+template <bool AMP>
 __global__ __launch_bounds__(256) void dwconv3x3_silu_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, int B, int H, int W, int C) {
     const int C4 = C >> 2;
@@ -169,7 +172,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_silu_kernel(const float* __rest
         for (int p = 0; p < DW_PW; ++p) {
             if (w0 + p >= W) break;
             float4 o = acc[r][p];
+            if (AMP) { o.x = ew_r16(o.x); o.y = ew_r16(o.y); o.z = ew_r16(o.z); o.w = ew_r16(o.w); }
             o.x = xp_silu(o.x); o.y = xp_silu(o.y); o.z = xp_silu(o.z); o.w = xp_silu(o.w);
+            if (AMP) { o.x = ew_r16(o.x); o.y = ew_r16(o.y); o.z = ew_r16(o.z); o.w = ew_r16(o.w); }
             reinterpret_cast<float4*>(y)[((b * H + h0 + r) * W + w0 + p) * C4 + c4] = o;
         }
     }
@@ -181,7 +186,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_silu_kernel(const float* __rest
 // + bias + LayerNorm(CO) + GELU -> NHWC (B,H/2,W/2,CO).  Reference VMamba.py:1411-1416.
 // One thread per output pixel, CO accumulators in registers; output staged through LDS for coalescing.
 // ---------------------------------------------------------------------------------------------
-template <int CO>
+// AMP: the image is cast to half by autocast's convolution, and conv, LayerNorm and GELU each return a half tensor
+template <int CO, bool AMP>
 __global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __restrict__ img, const float* __restrict__ w9,
                                                                const float* __restrict__ bias, const float* __restrict__ lnw,
                                                                const float* __restrict__ lnb, float* __restrict__ y,
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __re
             for (int kw = 0; kw < 3; ++kw) {
                 const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
                 xin[kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? img[(b * H + ih) * W + iw] : 0.f;
+                if (AMP) xin[kh * 3 + kw] = ew_r16(xin[kh * 3 + kw]);
             }
         float acc[CO];
         float s = 0.f;
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __re
 #pragma unroll
             for (int t = 0; t < 9; ++t) a = fmaf(xin[t], s_w[t * CO + c], a);
             a += s_w[9 * CO + c];
+            if (AMP) a = ew_r16(a);
             acc[c] = a; s += a;
         }
         const float mean = s / (float)CO;
@@ -222,8 +230,13 @@ __global__ __launch_bounds__(64) void stem_conv_ln_gelu_kernel(const float* __re
         for (int c = 0; c < CO; ++c) { const float d = acc[c] - mean; q = fmaf(d, d, q); }
         const float rstd = 1.f / sqrtf(q / (float)CO + eps);
 #pragma unroll
-        for (int c = 0; c < CO; ++c)
-            s_o[threadIdx.x * (CO + 1) + c] = xp_gelu_fast((acc[c] - mean) * rstd * s_w[10 * CO + c] + s_w[11 * CO + c]);
+        for (int c = 0; c < CO; ++c) {
+            float v = (acc[c] - mean) * rstd * s_w[10 * CO + c] + s_w[11 * CO + c];
+            if (AMP) v = ew_r16(v);
+            v = xp_gelu_fast(v);
+            if (AMP) v = ew_r16(v);
+            s_o[threadIdx.x * (CO + 1) + c] = v;
+        }
     }
     __syncthreads();
     const int64_t nvalid = (total - p0 < 64) ? (total - p0) : 64;
@@ -372,8 +385,37 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const uint8_t* __restric
 
 }  // namespace
 
+// y = fp16-round(x) kept in f32 containers (the mixed-precision class's inter-op tensors): n floats, 16-byte aligned when n % 4 == 0
+__global__ __launch_bounds__(256) void round_f16_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        v.x = ew_r16(v.x); v.y = ew_r16(v.y); v.z = ew_r16(v.z); v.w = ew_r16(v.w);
+        *reinterpret_cast<float4*>(y + i) = v;
+    } else {
+        for (int64_t j = i; j < n; ++j) y[j] = ew_r16(x[j]);
+    }
+}
+extern "C" int xp_round_f16(const float* x, float* y, int64_t n, void* stream) {
+    XP_CHECK_ARG(x && y && n >= 0, "xp_round_f16: bad args");
+    XP_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "xp_round_f16: buffers must be 16-byte aligned");
+    if (n == 0) return XP_OK;
+    XpProfScope prof("round_f16", (hipStream_t)stream, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(round_f16_kernel, dim3(xp_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+static int layernorm_impl(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps, int gelu, void* stream);
 extern "C" int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps,
                             int gelu, void* stream) {
+    const int rc = layernorm_impl(x, y, w, b, rows, C, eps, gelu, stream);
+    // mixed-precision class: LayerNorm of a half tensor returns a half tensor (statistics in f32, as here)
+    if (rc == XP_OK && xp_amp_value() && rows > 0 && (C % 4 == 0)) return xp_round_f16(y, y, rows * C, stream);
+    return rc;
+}
+static int layernorm_impl(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps,
+                          int gelu, void* stream) {
     XP_CHECK_ARG(x && y && w && b, "xp_layernorm: null pointer");
     XP_CHECK_ARG(C > 0 && C <= 1024, "xp_layernorm: C must be in [1,1024] (got %d)", C);
     if (rows == 0) return XP_OK;
@@ -402,7 +444,8 @@ extern "C" int xp_dwconv3x3_silu(const float* x, const float* w9c, float* y, int
     XP_CHECK_ARG(C % 4 == 0, "xp_dwconv3x3_silu: C %% 4 != 0");
     const int64_t total = (int64_t)batch * ((H + DW_PH - 1) / DW_PH) * ((W + DW_PW - 1) / DW_PW) * (C / 4);
     XpProfScope prof("dwconv3x3_silu", (hipStream_t)stream, 22.0 * batch * H * W * C, 8.0 * batch * H * W * C);
-    hipLaunchKernelGGL(dwconv3x3_silu_kernel, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w9c, y, batch, H, W, C);
+    if (xp_amp_value()) hipLaunchKernelGGL(dwconv3x3_silu_kernel<true>, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w9c, y, batch, H, W, C);
+    else hipLaunchKernelGGL(dwconv3x3_silu_kernel<false>, dim3(xp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w9c, y, batch, H, W, C);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -415,8 +458,11 @@ extern "C" int xp_stem_conv_ln_gelu(const float* img, const float* w9co, const f
     dim3 grid(xp_cdiv(total, 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     XpProfScope prof("stem_conv_ln_gelu", (hipStream_t)stream, (double)total * Co * 30.0, 4.0 * ((double)batch * H * W + (double)total * Co));
-    if (Co == 48) hipLaunchKernelGGL(stem_conv_ln_gelu_kernel<48>, grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
-    else if (Co == 16) hipLaunchKernelGGL(stem_conv_ln_gelu_kernel<16>, grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
+    const bool amp = xp_amp_value() != 0;
+    if (Co == 48 && amp) hipLaunchKernelGGL((stem_conv_ln_gelu_kernel<48, true>), grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
+    else if (Co == 16 && amp) hipLaunchKernelGGL((stem_conv_ln_gelu_kernel<16, true>), grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
+    else if (Co == 48) hipLaunchKernelGGL((stem_conv_ln_gelu_kernel<48, false>), grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
+    else if (Co == 16) hipLaunchKernelGGL((stem_conv_ln_gelu_kernel<16, false>), grid, block, 0, s, img, w9co, bias, ln_w, ln_b, y, batch, H, W, eps);
     else { xp_set_error("xp_stem_conv_ln_gelu: Co must be 48 or 16 (EMBED_DIM 96 / 32), got %d", Co); return XP_ERR_ARG; }
     XP_LAUNCH_CHECK();
     return XP_OK;

@@ -26,6 +26,8 @@ struct GemmParams {
     int ngroup;           // split-fp16 tile engine: column tiles per group of the tile order (0 = N-fastest), gemm_h2.hip
     int mode;             // 0: plain A; 1: implicit 3x3 conv over NHWC (K order = kh, kw, ci)
     int Hi, Wi, Ci, Ho, Wo, stride, reflect;
+    int r16;              // split-fp16 engine only: round the value to fp16 after every operation autocast would end in a half tensor — bias add,
+                          // GELU, the BatchNorm affine, the residual add (xp_set_amp_mode; the mixed-precision class of DESIGN.md §3e)
     int stagger_cycles;   // start-up delay of the second workgroup slot of every CU (see gemm_kernel)
     unsigned long long* stamps;   // debug (XP_GEMM_STAMPS): 4 s_memtime stamps per workgroup, else null
 };
@@ -35,17 +37,21 @@ struct GemmParams {
 template <class T, class = void> struct tile_has_row_scale : std::false_type {};
 template <class T> struct tile_has_row_scale<T, std::enable_if_t<T::kRowScale>> : std::true_type {};
 
+__device__ __forceinline__ float xp_r16(float v) { return (float)(_Float16)v; }       // round to nearest even to fp16 and back (v_cvt_f16_f32, v_cvt_f32_f16)
+
 // T: tile engine providing BM, BN, row_of(i, r), col_of(j).  acc[i][j] are the lane's 32x32 accumulator tiles.
-template <class T, int TM, int TN>
+// ALLOW_R16: also instantiate the p.r16 form (the split-fp16 kernels; the other engines never set it).
+template <class T, int TM, int TN, bool ALLOW_R16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int m0, int n0, f32x16 (&acc)[TM][TN]) {
     // Epilogue, straight-line: the activation is a compile-time tag and interior tiles skip every bounds test (per-element
     // runtime switches made hipcc emit ~3 scalar branches per element: ~190 cycles per stored value).  Absent scale /
     // shift / residual are the exact identities (x*1+0, +0).  Two phases so that every residual load is in flight before
     // the first store (C may alias res: a load-add-store chain per element would serialise the L2 round trips).
     const bool interior = (m0 + T::BM <= p.M) && (n0 + T::BN <= p.N);
-    auto epilogue = [&](auto act_tag, auto interior_tag) {
+    auto epilogue = [&](auto act_tag, auto interior_tag, auto r16_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool INTERIOR = decltype(interior_tag)::value;
+        constexpr bool R16 = decltype(r16_tag)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -72,11 +78,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int m0, int n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = tile_has_row_scale<T>::value ? acc[i][j][r] * ws + bi : acc[i][j][r] + bi;    // ws is a power of two: the product is exact
-                    if (ACT == 1) v = xp_gelu_fast(v);
+                    if (R16) v = xp_r16(v);                                     // the layer's half output
+                    if (ACT == 1) { v = xp_gelu_fast(v); if (R16) v = xp_r16(v); }
                     if (ACT == 2) v = fmaxf(v, 0.f);
                     v = v * sc + sh;
+                    if (R16) { if (p.scale) v = xp_r16(v); }                    // eval BatchNorm on a half tensor returns a half tensor
                     if (ACT == 3) v = fmaxf(v, 0.f);
                     rv[r] = rv[r] + v;
+                    if (R16) { if (resb) rv[r] = xp_r16(rv[r]); }               // half + half -> half
                 }
                 if (cok && !(XP_EPI_DBG && rv[0] != 12345.678f)) {
 #pragma unroll
@@ -88,13 +97,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, int m0, int n
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
-    auto by_act = [&](auto interior_tag) {
+    auto by_act = [&](auto interior_tag, auto r16_tag) {
         switch (p.act) {
-            case 1: epilogue(std::integral_constant<int, 1>{}, interior_tag); break;
-            case 2: epilogue(std::integral_constant<int, 2>{}, interior_tag); break;
-            case 3: epilogue(std::integral_constant<int, 3>{}, interior_tag); break;
-            default: epilogue(std::integral_constant<int, 0>{}, interior_tag); break;
+            case 1: epilogue(std::integral_constant<int, 1>{}, interior_tag, r16_tag); break;
+            case 2: epilogue(std::integral_constant<int, 2>{}, interior_tag, r16_tag); break;
+            case 3: epilogue(std::integral_constant<int, 3>{}, interior_tag, r16_tag); break;
+            default: epilogue(std::integral_constant<int, 0>{}, interior_tag, r16_tag); break;
         }
     };
-    if (interior) by_act(std::true_type{}); else by_act(std::false_type{});
+    if constexpr (ALLOW_R16) {
+        if (p.r16) {       // the rounding class is rare: the general (bounds-tested) form serves interior tiles too
+            by_act(std::false_type{}, std::true_type{});
+            return;
+        }
+    }
+    if (interior) by_act(std::true_type{}, std::false_type{}); else by_act(std::false_type{}, std::false_type{});
 }

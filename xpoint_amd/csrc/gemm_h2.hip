@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h2_kernel(GemmParams p) {
 
     f32x16 acc[TM][TN];
     T::run(lds_h2, p.K, ldA, ldB, acc);
-    gemm_epilogue<T, TM, TN>(p, m0, n0, acc);
+    gemm_epilogue<T, TM, TN, true>(p, m0, n0, acc);
 }
 
 // Row-stationary variant (GemmTileH2R): A fragments straight from global memory, only the weights in LDS.  K % 8 == 0 (conv: Ci % 8 == 0).
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_h2r_kernel(GemmParams p) {
 
     f32x16 acc[1][TN];
     T::run(lds_h2, p.K, ldA8, ldB, acc);
-    gemm_epilogue<T, 1, TN>(p, m0, n0, acc);
+    gemm_epilogue<T, 1, TN, true>(p, m0, n0, acc);
 }
 
 template <int TN>
@@ -325,6 +325,7 @@ extern "C" int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const fl
     GemmParams p{};
     p.A = A; p.Wt = (const float*)Wh2; p.C = C; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.wscale = h2_scales(Wh2, N, K);
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.act = act; p.mode = 0;
+    p.r16 = xp_amp_value();
     return dispatch(p, (hipStream_t)stream);
 }
 
@@ -340,5 +341,6 @@ extern "C" int xp_conv3x3_nhwc_h2(const float* x, const void* Wh2, float* y, con
     p.Hi = Hi; p.Wi = Wi; p.Ci = Ci; p.stride = stride; p.reflect = reflect_pad;
     p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = (Wi + 2 - 3) / stride + 1;
     p.M = batch * p.Ho * p.Wo; p.N = Co; p.K = 9 * Ci; p.lda = 0; p.ldc = Co; p.ldres = 0; p.act = act; p.mode = 1;
+    p.r16 = xp_amp_value();
     return dispatch(p, (hipStream_t)stream);
 }

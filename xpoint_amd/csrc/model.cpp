@@ -277,7 +277,12 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
     const int E = c->cfg.embed_dim;
     // split-bf16 back end only; XP_NO_FUSED_MLP=1 keeps the three-launch form (A/B timing, tests)
     static const bool no_fused_mlp = getenv("XP_NO_FUSED_MLP") != nullptr && atoi(getenv("XP_NO_FUSED_MLP")) != 0;
-    const bool fuse_mlp = wsplit != nullptr && !no_fused_mlp;
+    // Mixed-precision class (xp_set_amp_mode(1)): needs the split-fp16 engine (its kernels carry the fp16 output rounding); every block
+    // runs as separate launches, because the rounding points of the reference's autocast recipe sit BETWEEN the operations the fused kernels merge
+    const bool amp = xp_amp_value() != 0;
+    XP_CHECK_ARG(!amp || (wsplit && h2), "xp_xpoint_forward: the mixed-precision class (xp_set_amp_mode) runs on the split-fp16 engine: pass wsplit and "
+                 "select xp_set_dense_engine(1) with xp_set_dense_products(6)");
+    const bool fuse_mlp = wsplit != nullptr && !no_fused_mlp && !amp;
     static const int fuse_max_c = getenv("XP_FUSE_MAXC") ? atoi(getenv("XP_FUSE_MAXC")) : 1 << 30;      // A/B: blocks wider than this run unfused
     static const bool fused_x3 = getenv("XP_FUSED_X3") != nullptr && atoi(getenv("XP_FUSED_X3")) != 0;     // A/B: fused block kernels on the x3 planes under the h2 engine
 
@@ -305,6 +310,7 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
             RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
             RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
                                  T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
+            if (amp) RUN(xp_round_f16(T1, T1, (int64_t)M * C, stream));      // forward_corev2 returns y.to(x.dtype): out_norm's f32 result as a half tensor (VMamba.py:646)
             if (fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1) {
                 // out_proj + first residual + LN + MLP + second residual in one launch; the (M, 4C) hidden activation stays in
                 // registers (csrc/mlp_fused.hip)

@@ -59,7 +59,9 @@ __device__ __forceinline__ int pixel_of(int l, int L, int H, int W, bool colmajo
 
 // One scan step's operands for one route: xr = [dt_rank values, B, C] (R + 2 floats, 8-byte aligned in LDS; 16-byte
 // aligned when (R + 2) % 4 == 0).  Read with the widest aligned LDS loads (b128 / b64 broadcasts), not R + 2 b32 reads.
-template <int R>
+// AMP (mixed-precision class, xp_set_amp_mode): the dt projection is a half convolution under autocast — its output is rounded to fp16 BEFORE
+// the f32 bias is added (csms6s.py:47-50 adds delta_bias to the half tensor in f32) — so w and bias arrive WITHOUT the log2(e) factor
+template <int R, bool AMP = false>
 __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const float (&w)[R], float bias, float A,
                                           float u, float& a, float& b, float& Cv) {
     float xv[R + 2];
@@ -78,9 +80,17 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
     }
     if (XP_SS2D_DBG & 4) { a = 0.5f; b = xv[R] * u; Cv = xv[R + 1]; return; }
     // w, bias and A arrive pre-multiplied by log2(e) (XP_L2E at their loads): the chain below is x * log2(e) directly
-    float dt = fmaf(w[0], xv[0], bias);
+    float dt;
+    if constexpr (!AMP) {
+        dt = fmaf(w[0], xv[0], bias);
 #pragma unroll
-    for (int r = 1; r < R; ++r) dt = fmaf(w[r], xv[r], dt);
+        for (int r = 1; r < R; ++r) dt = fmaf(w[r], xv[r], dt);
+    } else {
+        dt = w[0] * xv[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) dt = fmaf(w[r], xv[r], dt);
+        dt = ((float)(_Float16)dt + bias) * XP_L2E;
+    }
     float delta;
     xp_softplus_decay_l2(dt, A, delta, a);          // softplus + exp(delta * A): xp_common.h
     b = delta * xv[R] * u;
@@ -191,8 +201,9 @@ __device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair
 
 // FULL: every chunk of every block is complete (L % T == 0 and nc % cpb == 0 — all shapes of the 480 x 640 model): the per-step
 // validity selects (compare + two cndmask per step) are compiled out
-template <int R, bool FULL>
+template <int R, bool FULL, bool AMP = false>
 __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
+    constexpr float WL2E = AMP ? 1.f : XP_L2E;        // factor folded into the dt weights and bias where they are loaded (see step_vals)
     extern __shared__ __align__(16) char smem[];
     const int npx = p.cpb * p.T;
     int* s_pix = reinterpret_cast<int*>(smem);
@@ -212,10 +223,10 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
         float w0[R], w1[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            w0[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
-            w1[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
+            w0[r] = WL2E * p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
+            w1[r] = WL2E * p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
         }
-        const float b0 = XP_L2E * p.dtb[(pair * 2 + 0) * p.C + c], b1 = XP_L2E * p.dtb[(pair * 2 + 1) * p.C + c];
+        const float b0 = WL2E * p.dtb[(pair * 2 + 0) * p.C + c], b1 = WL2E * p.dtb[(pair * 2 + 1) * p.C + c];
         const float A0 = XP_L2E * p.A[(pair * 2 + 0) * p.C + c], A1 = XP_L2E * p.A[(pair * 2 + 1) * p.C + c];
         for (int i0 = 0; i0 < p.T; i0 += 4) {
             float uv[4];
@@ -233,9 +244,9 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
                 // into the zero initial state), so no branch is needed.
                 const float* xr = s_x + (cl * p.T + i0 + k) * XW;
                 float a, bb, cv;
-                step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
+                step_vals<R, AMP>(xr, w0, b0, A0, uv[k], a, bb, cv);
                 S0 = a * S0 + bb; P0 *= a;
-                step_vals<R>(xr + (R + 2), w1, b1, A1, uv[k], a, bb, cv);
+                step_vals<R, AMP>(xr + (R + 2), w1, b1, A1, uv[k], a, bb, cv);
                 S1 = fmaf(Q1, bb, S1); Q1 *= a;     // backward route accumulated in forward order
             }
         }
@@ -247,8 +258,8 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     for (int route = 0; route < 2; ++route) {
         float w[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + route) * R + r) * p.C + c];
-        const float bias = XP_L2E * p.dtb[(pair * 2 + route) * p.C + c], Av = XP_L2E * p.A[(pair * 2 + route) * p.C + c];
+        for (int r = 0; r < R; ++r) w[r] = WL2E * p.wdt[((int64_t)(pair * 2 + route) * R + r) * p.C + c];
+        const float bias = WL2E * p.dtb[(pair * 2 + route) * p.C + c], Av = XP_L2E * p.A[(pair * 2 + route) * p.C + c];
         float Pr = 1.f, Sr = 0.f;
         for (int i0 = 0; i0 < p.T; i0 += 4) {
             float uv[4];
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
                 // into the zero initial state), so no branch is needed.
                 const float* xr = s_x + (cl * p.T + i0 + k) * XW + route * (R + 2);
                 float a, bb, cv;
-                step_vals<R>(xr, w, bias, Av, uv[k], a, bb, cv);
+                step_vals<R, AMP>(xr, w, bias, Av, uv[k], a, bb, cv);
                 if (route == 0) Sr = a * Sr + bb;
                 else Sr = fmaf(Pr, bb, Sr);                 // backward route accumulated in forward order
                 Pr *= a;
@@ -325,8 +336,9 @@ __global__ __launch_bounds__(64 * P2_G) void ss2d_pass2(SS2DParams p) {
     for (; jj < j1; ++jj) { const int64_t o = off(jj); const float Pj = p.wsP[o], Sj = p.wsS[o]; p.wsS[o] = h; h = fmaf(Pj, h, Sj); }
 }
 
-template <int R, bool COLPAIR, bool FULL>
+template <int R, bool COLPAIR, bool FULL, bool AMP = false>
 __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
+    constexpr float WL2E = AMP ? 1.f : XP_L2E;
     extern __shared__ __align__(16) char smem[];
     const int npx = p.cpb * p.T;
     int* s_pix = reinterpret_cast<int*>(smem);
@@ -345,8 +357,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
         // one route's projection weights live at a time (see pass 1)
         float w0[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w0[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
-        const float b0 = XP_L2E * p.dtb[(pair * 2 + 0) * p.C + c];
+        for (int r = 0; r < R; ++r) w0[r] = WL2E * p.wdt[((int64_t)(pair * 2 + 0) * R + r) * p.C + c];
+        const float b0 = WL2E * p.dtb[(pair * 2 + 0) * p.C + c];
         const float A0 = XP_L2E * p.A[(pair * 2 + 0) * p.C + c];
         const float D0 = p.Dp[(pair * 2 + 0) * p.C + c];
         const float* ub = p.u + (int64_t)b * L * p.C + c;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 const int pi = cl * p.T + i0 + k;
                 const float* xr = s_x + pi * XW;
                 float a, bb, cv;
-                step_vals<R>(xr, w0, b0, A0, uv[k], a, bb, cv);
+                step_vals<R, AMP>(xr, w0, b0, A0, uv[k], a, bb, cv);
                 h = a * h + bb;
                 s_y[pi * SY + c] = cv * h + D0 * uv[k];   // y = C*h + D*u (csms6s.py:61,67); rows past the end are never read
             }
@@ -376,8 +388,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
         asm volatile("" ::: "memory");      // keep the second route's weight loads below the forward loop
         float w1[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w1[r] = XP_L2E * p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
-        const float b1 = XP_L2E * p.dtb[(pair * 2 + 1) * p.C + c];
+        for (int r = 0; r < R; ++r) w1[r] = WL2E * p.wdt[((int64_t)(pair * 2 + 1) * R + r) * p.C + c];
+        const float b1 = WL2E * p.dtb[(pair * 2 + 1) * p.C + c];
         const float A1 = XP_L2E * p.A[(pair * 2 + 1) * p.C + c];
         const float D1 = p.Dp[(pair * 2 + 1) * p.C + c];
         h = p.wsS[o + p.C];
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 const int pi = cl * p.T + i0 + k;
                 const float* xr = s_x + pi * XW + (R + 2);
                 float a, bb, cv;
-                step_vals<R>(xr, w1, b1, A1, uv[k], a, bb, cv);
+                step_vals<R, AMP>(xr, w1, b1, A1, uv[k], a, bb, cv);
                 h = a * h + bb;                                      // u = 0 steps before the image's last pixel keep h = 0
                 const float y2 = cv * h + D1 * uv[k];
                 const float tot = s_y[pi * SY + c] + y2;           // y_fwd + flip(y_bwd)
@@ -754,6 +766,7 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const int npx = p.cpb * p.T;
     const int threads = p.cpb * p.C;
     const bool full = (p.H * p.W) % p.T == 0 && p.nc % p.cpb == 0;
+    const bool amp = xp_amp_value() != 0;           // mixed-precision class: the general (bounds-tested) instances with the dt rounding of step_vals
     const size_t sm1 = sizeof(int) * 2 * npx + sizeof(float) * npx * XW;
     const size_t sm3 = sm1 + sizeof(float) * (size_t)npx * (p.C + 8);
     dim3 grid1(xp_cdiv(p.nc, p.cpb), p.Bn, 2), grid3(xp_cdiv(p.nc, p.cpb), p.Bn, 1);
@@ -763,7 +776,8 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const double el = 4.0 * MC;   // (pixel, channel, direction) scan elements of the whole core
     {   // reads u + its half of xdbl for each of the two route pairs
         XpProfScope prof(("ss2d_pass1" + sfx).c_str(), s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
-        if (full) hipLaunchKernelGGL((ss2d_pass1<R, true>), grid1, dim3(threads), sm1, s, p);
+        if (amp) hipLaunchKernelGGL((ss2d_pass1<R, false, true>), grid1, dim3(threads), sm1, s, p);
+        else if (full) hipLaunchKernelGGL((ss2d_pass1<R, true>), grid1, dim3(threads), sm1, s, p);
         else hipLaunchKernelGGL((ss2d_pass1<R, false>), grid1, dim3(threads), sm1, s, p);
     }
     {
@@ -772,12 +786,14 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     }
     {   // read u, xdbl half; write ya
         XpProfScope prof(("ss2d_pass3_row" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
-        if (full) hipLaunchKernelGGL((ss2d_pass3<R, false, true>), grid3, dim3(threads), sm3, s, p);
+        if (amp) hipLaunchKernelGGL((ss2d_pass3<R, false, false, true>), grid3, dim3(threads), sm3, s, p);
+        else if (full) hipLaunchKernelGGL((ss2d_pass3<R, false, true>), grid3, dim3(threads), sm3, s, p);
         else hipLaunchKernelGGL((ss2d_pass3<R, false, false>), grid3, dim3(threads), sm3, s, p);
     }
     {   // read u, ya, xdbl half; write out (after out_norm)
         XpProfScope prof(("ss2d_pass3_col_ln" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (3.0 * MC + MX));
-        if (full) hipLaunchKernelGGL((ss2d_pass3<R, true, true>), grid3, dim3(threads), sm3, s, p);
+        if (amp) hipLaunchKernelGGL((ss2d_pass3<R, true, false, true>), grid3, dim3(threads), sm3, s, p);
+        else if (full) hipLaunchKernelGGL((ss2d_pass3<R, true, true>), grid3, dim3(threads), sm3, s, p);
         else hipLaunchKernelGGL((ss2d_pass3<R, true, false>), grid3, dim3(threads), sm3, s, p);
     }
     XP_LAUNCH_CHECK();
@@ -841,7 +857,8 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
     const int mode = g_ss2d_mode.load();
     static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
     const bool seq2 = seq_scan2_applies(R, H, W, C);
-    const bool seq = mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512)));
+    // (the mixed-precision class always takes the chunked form: its dt rounding lives in step_vals)
+    const bool seq = xp_amp_value() ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512))));
     if (seq && C <= 768 && C % 64 == 0) {
         switch (R) {
             case 2: return launch_ss2d_seq<2>(p, workspace, s);

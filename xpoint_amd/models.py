@@ -31,8 +31,10 @@ class _ModelCfg(ctypes.Structure):
 _LoadResult = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 _DIR_ORDER = [0, 2, 1, 3]   # device order of the four scan routes (row pair, then column pair)
-_DENSE_PRODUCTS = {"h2": 6, "x3": 6, "x2": 3, "bf16": 1, "f32": 6}   # gemm_mode -> partial products of the split-bf16 kernels
-_DENSE_ENGINE = {"h2": 1}                                             # gemm_mode -> xp_set_dense_engine (default 0 = x3)
+_DENSE_PRODUCTS = {"h2": 6, "x3": 6, "x2": 3, "bf16": 1, "f32": 6, "amp16": 6}   # gemm_mode -> partial products of the split-bf16 kernels
+_DENSE_ENGINE = {"h2": 1, "amp16": 1}                                 # gemm_mode -> xp_set_dense_engine (default 0 = x3)
+# "amp16": the reference's mixed_precision deployment class (XPoint.py:182, autocast; half is its default dtype) — xp_set_amp_mode(1): fp16 rounding
+# at every autocast boundary on the split-fp16 engine, weights of the convolutions / linear layers rounded to fp16 (what autocast casts).
 
 
 class XPoint(torch.nn.Module):
@@ -71,6 +73,7 @@ class XPoint(torch.nn.Module):
         self._wsplit: Optional[torch.Tensor] = None      # split-bf16 copies of the GEMM weights, derived from _blob on the device
         self._blob_t: Optional[torch.Tensor] = None      # multispectral only: the THERMAL encoder + the same heads
         self._wsplit_t: Optional[torch.Tensor] = None
+        self._amp_w: Dict[str, tuple] = {}               # gemm_mode "amp16": spectrum -> (blob with the autocast-cast tensors rounded to fp16, its split copies)
         # "h2" (default): dense layers on the f16 matrix pipe, f32 operands as two fp16 planes, 3 partial products (f32-grade: operand
         # error <= 2^-23, <= 2^-21 per product worst case, ~2^-25 typical, csrc/gemm_h2_core.h); "x3": bf16 matrix pipe, three exact planes,
         # 6 partial products (f32-grade, no range limit); both are pinned against the reference.  "f32": exact-f32 MFMA kernels;
@@ -180,6 +183,7 @@ class XPoint(torch.nn.Module):
         self._wsplit = None
         self._blob_t = None
         self._wsplit_t = None
+        self._amp_w = {}
         self._conv_impl = None
         self._regnet_w = None
         self._h2_off = False              # a new weight set gets the default engine back
@@ -191,10 +195,19 @@ class XPoint(torch.nn.Module):
         shift = s[pre + "bias"].double() - s[pre + "running_mean"].double() * scale
         return scale.float(), shift.float()
 
-    def _device_params(self, e="encoder."):
+    # tensors autocast casts to half: the weight and bias arguments of every convolution / linear layer (incl. the conv1d forms of x_proj and
+    # dt_projs, VMamba.py:605-610).  LayerNorm / BatchNorm parameters, dt_projs_bias, A_logs and Ds stay f32 (csms6s.py:47-52).
+    _AMP_CAST = ("patch_embed.0.", "patch_embed.5.", "op.in_proj.weight", "op.conv2d.weight", "op.x_proj_weight", "op.dt_projs_weight",
+                 "op.out_proj.weight", "mlp.fc1.", "mlp.fc2.", "downsample.1.", "_head_convolutions.1.", "_head_convolutions.4.")
+
+    def _device_params(self, e="encoder.", amp=False):
         """reference state dict -> device-format tensors (names of csrc/model.cpp build_layout) for the encoder whose
-        state_dict prefix is `e` ("encoder.", or "encoder_optical." / "encoder_thermal." when multispectral)."""
+        state_dict prefix is `e` ("encoder.", or "encoder_optical." / "encoder_thermal." when multispectral).
+        amp: the tensors of _AMP_CAST rounded to fp16 first (the mixed-precision class: what autocast feeds the kernels)."""
         s = self._ref_state
+        if amp:
+            s = collections.OrderedDict((k, (v.to(torch.float16).to(torch.float32) if (v.is_floating_point() and any(t in k for t in self._AMP_CAST)) else v))
+                                        for k, v in s.items())
         missing = [k for k, (_, kind) in self.expected_keys().items() if k not in s and kind != "bn_count"
                    and not k.startswith("hm_regressor.")]
         if missing:
@@ -242,17 +255,18 @@ class XPoint(torch.nn.Module):
         out["desc2.scale"], out["desc2.shift"] = self._bn_affine(dsc + "5.")
         return out
 
-    def pack_weights(self, spectrum: Optional[str] = None) -> torch.Tensor:
+    def pack_weights(self, spectrum: Optional[str] = None, amp: bool = False) -> torch.Tensor:
         """The device-format blob on the CPU (one float32 vector); what rank 0 broadcasts over RCCL.
-        multispectral models have two (spectrum = "optical" / "thermal": that encoder + the shared heads)."""
+        multispectral models have two (spectrum = "optical" / "thermal": that encoder + the shared heads).
+        amp=True: the blob of the mixed-precision class (see _device_params)."""
         total = _lib.load().xp_weights_numel(self._ctx)
         blob = torch.zeros(total, dtype=torch.float32)
         if self.config['multispectral']:
             if spectrum not in ("optical", "thermal"):
                 raise RuntimeError("multispectral XPoint: pack_weights(spectrum='optical' | 'thermal')")
-            dp = self._device_params(f"encoder_{spectrum}.")
+            dp = self._device_params(f"encoder_{spectrum}.", amp=amp)
         else:
-            dp = self._device_params()
+            dp = self._device_params(amp=amp)
         for name, (off, num) in self._layout.items():
             t = dp[name].contiguous().float().reshape(-1)
             if t.numel() != num:
@@ -423,14 +437,26 @@ class XPoint(torch.nn.Module):
             raise RuntimeError(f"XPoint.gemm_mode must be one of {sorted(_DENSE_PRODUCTS)}, got {self.gemm_mode!r}")
         mode = self.effective_gemm_mode()
         split_mode = mode != "f32"
+        amp = mode == "amp16"
         blob = self._blob_t if thermal else self._blob
         ws_split = self._wsplit_t if thermal else self._wsplit
+        if amp:
+            key = ("thermal" if thermal else "optical") + str(dev)
+            if key not in self._amp_w:
+                if not self._ref_state:
+                    raise RuntimeError("gemm_mode 'amp16' needs the reference state dict (load_state_dict): the fp16 rounding of the weights is applied to "
+                                       "the reference tensors, not to the packed blob")
+                b16 = self.pack_weights(("thermal" if thermal else "optical") if self.config['multispectral'] else None, amp=True).to(dev)
+                self._amp_w[key] = (b16, None)
+            blob, ws_split = self._amp_w[key]
         if split_mode and ws_split is None:
             nb = lib.xp_split_weights_bytes(self._ctx)
             ws_split = torch.empty(nb, dtype=torch.uint8, device=dev)
             _lib.check(lib.xp_prepare_split_weights(self._ctx, ptr(blob), ptr(ws_split), ctypes.c_size_t(nb),
                                                     _lib.current_stream()), "xp_prepare_split_weights")
-            if thermal:
+            if amp:
+                self._amp_w[key] = (blob, ws_split)
+            elif thermal:
                 self._wsplit_t = ws_split
             else:
                 self._wsplit = ws_split
@@ -458,11 +484,16 @@ class XPoint(torch.nn.Module):
             _lib.call("xp_set_dense_products", nprod)
         if engine != prev_engine:
             _lib.call("xp_set_dense_engine", engine)
+        prev_amp = int(lib.xp_get_amp_mode())
+        if int(amp) != prev_amp:
+            _lib.call("xp_set_amp_mode", int(amp))
         try:
             _lib.check(lib.xp_xpoint_forward_ex(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                                 ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
                                                 ptr(self.status_word(dev)), _lib.current_stream()), "xp_xpoint_forward_ex")
         finally:
+            if int(amp) != prev_amp:
+                _lib.call("xp_set_amp_mode", prev_amp)
             if nprod != prev:
                 _lib.call("xp_set_dense_products", prev)
             if engine != prev_engine:
