@@ -104,6 +104,19 @@ def cross_merge(ys):
 # ---------------------------------------------------------------------------------------------------------------------
 DENSE_PRODUCTS = 6
 
+# AMP16 = True: the reference's mixed-precision recipe (XPoint.py:182 autocast; pinned by tests/golden/g20 = the real reference under float16 CPU
+# autocast) restated on f32 tensors: every convolution / linear layer takes its input, weight and bias rounded to fp16 and returns a value rounded
+# to fp16; LayerNorm, GELU, SiLU, eval BatchNorm and the residual adds return fp16-rounded values (half in -> half out; statistics and arithmetic
+# in f32, which is what PyTorch's CPU kernels do internally); the dt projection (a half conv1d, VMamba.py:608) is rounded BEFORE the f32 delta_bias
+# is added inside the scan (csms6s.py:47-50); the scan, cross merge and out_norm run in f32 and forward_corev2 returns y.to(x.dtype) (VMamba.py:646);
+# softmax / normalize run in f32 on the heads' `.to(torch.float)` (XPoint.py:349,363).
+AMP16 = False
+
+
+def _h(x):
+    """fp16 rounding of a value kept in f32 (identity unless AMP16)."""
+    return x.to(torch.float16).to(torch.float32) if (AMP16 and x is not None) else x
+
 
 def _planes(x, n):
     out, r = [], x
@@ -115,6 +128,8 @@ def _planes(x, n):
 
 
 def _dense(op, x, w, b, **kw):
+    if AMP16:
+        return _h(op(_h(x), _h(w), _h(b), **kw))
     if DENSE_PRODUCTS == 6:
         return op(x, w, b, **kw)
     terms = [(0, 0)] if DENSE_PRODUCTS == 1 else [(1, 0), (0, 1), (0, 0)]
@@ -149,7 +164,7 @@ def ss2d_core(x, sd, pre, return_parts=False):
     xs = cross_scan(x)
     x_dbl = _dense(F.conv1d, xs.view(B, -1, L), xw.reshape(-1, D, 1), None, groups=K)           # :605
     dts, Bs, Cs = torch.split(x_dbl.view(B, K, -1, L), [R, N, N], dim=2)                      # :606
-    dts = F.conv1d(dts.contiguous().view(B, -1, L), dtw.reshape(K * D, -1, 1), groups=K)      # :608
+    dts = _h(F.conv1d(dts.contiguous().view(B, -1, L), _h(dtw).reshape(K * D, -1, 1), groups=K))      # :608
     xs = xs.view(B, -1, L)
     As = -sd[pre + "A_logs"].float().exp()                                                    # :619
     Ds = sd[pre + "Ds"].float()
@@ -161,15 +176,15 @@ def ss2d_core(x, sd, pre, return_parts=False):
     yn = F.layer_norm(y, (D,), sd[pre + "out_norm.weight"], sd[pre + "out_norm.bias"], 1e-5)  # :644
     if return_parts:
         return yn, dict(xs=xs, dts=dts, Bs=Bs, Cs=Cs, ys=ys, y_merged=y)
-    return yn
+    return _h(yn)                                                                             # :646 y.to(x.dtype)
 
 
 def ss2d(x, sd, pre):
     """x (B,H,W,C) -> (B,H,W,C).  VMamba.py:648-664 with disable_z (noz)."""
     t = _lin(x, sd[pre + "in_proj.weight"])                       # :649 (no bias)
     t = t.permute(0, 3, 1, 2).contiguous()                        # :654-655
-    t = F.conv2d(t, sd[pre + "conv2d.weight"], None, padding=1, groups=t.shape[1])   # :657
-    t = F.silu(t)                                                 # :658
+    t = _h(F.conv2d(t, _h(sd[pre + "conv2d.weight"]), None, padding=1, groups=t.shape[1]))   # :657
+    t = _h(F.silu(t))                                             # :658
     y = ss2d_core(t, sd, pre)                                     # :659
     return _lin(y, sd[pre + "out_proj.weight"])                   # :663
 
@@ -177,31 +192,31 @@ def ss2d(x, sd, pre):
 def vss_block(x, sd, pre):
     """VMamba.py:1222-1234 (post_norm False, DropPath identity in eval) + Mlp :110-128."""
     C = x.shape[-1]
-    x = x + ss2d(F.layer_norm(x, (C,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-5), sd, pre + "op.")
-    h = F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
+    x = _h(x + ss2d(_h(F.layer_norm(x, (C,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-5)), sd, pre + "op."))
+    h = _h(F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5))
     h = _lin(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
-    h = F.gelu(h)                                                 # exact erf GELU
+    h = _h(F.gelu(h))                                             # exact erf GELU
     h = _lin(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
-    return x + h
+    return _h(x + h)
 
 
 def patch_embed(img, sd, pre):
     """VMamba.py:1405-1420 (_make_patch_embed_v2), after the gray->3ch cat of :1509-1510."""
     x = torch.cat((img, img, img), dim=1) if img.shape[1] == 1 else img
-    x = F.conv2d(x, sd[pre + "0.weight"], sd[pre + "0.bias"], stride=2, padding=1)
+    x = _h(F.conv2d(_h(x), _h(sd[pre + "0.weight"]), _h(sd[pre + "0.bias"]), stride=2, padding=1))
     x = x.permute(0, 2, 3, 1)
-    x = F.layer_norm(x, (x.shape[-1],), sd[pre + "2.weight"], sd[pre + "2.bias"], 1e-5)
-    x = F.gelu(x.permute(0, 3, 1, 2))
+    x = _h(F.layer_norm(x, (x.shape[-1],), sd[pre + "2.weight"], sd[pre + "2.bias"], 1e-5))
+    x = _h(F.gelu(x.permute(0, 3, 1, 2)))
     x = _conv(x, sd[pre + "5.weight"], sd[pre + "5.bias"], stride=2, padding=1)
     x = x.permute(0, 2, 3, 1)
-    return F.layer_norm(x, (x.shape[-1],), sd[pre + "7.weight"], sd[pre + "7.bias"], 1e-5)
+    return _h(F.layer_norm(x, (x.shape[-1],), sd[pre + "7.weight"], sd[pre + "7.bias"], 1e-5))
 
 
 def downsample(x, sd, pre):
     """VMamba.py:1432-1440 (_make_downsample_v3)."""
     x = _conv(x.permute(0, 3, 1, 2), sd[pre + "1.weight"], sd[pre + "1.bias"], stride=2, padding=1)
     x = x.permute(0, 2, 3, 1)
-    return F.layer_norm(x, (x.shape[-1],), sd[pre + "3.weight"], sd[pre + "3.bias"], 1e-5)
+    return _h(F.layer_norm(x, (x.shape[-1],), sd[pre + "3.weight"], sd[pre + "3.bias"], 1e-5))
 
 
 def depth_to_space(x, bs):
@@ -245,8 +260,8 @@ def vssm_forward(img, sd, pre="encoder.", taps: Optional[dict] = None):
 # ------------------------------------------------------------------------------------------
 
 def _bn(x, sd, pre):
-    return F.batch_norm(x, sd[pre + "running_mean"], sd[pre + "running_var"], sd[pre + "weight"], sd[pre + "bias"],
-                        False, 0.0, 1e-5)
+    return _h(F.batch_norm(x, sd[pre + "running_mean"], sd[pre + "running_var"], sd[pre + "weight"], sd[pre + "bias"],
+                           False, 0.0, 1e-5))
 
 
 def _head_trunk(x, sd, pre):

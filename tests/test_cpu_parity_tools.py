@@ -162,3 +162,47 @@ def test_oracle_vs_round3_reference_fixtures(golden):
         with torch.no_grad():
             _, _, hm = xo.xpoint_forward(data, sd, hm_head=True)
         assert float(np.abs(hm.numpy().reshape(-1) - g21["hm"][i]).max()) < 1e-5
+
+
+def test_oracle_amp16_recipe_vs_reference_taps(golden):
+    """The oracle's AMP16 switch (the mixed-precision recipe restated on f32 tensors: every autocast op = f32 arithmetic on half-rounded inputs, half-
+    rounded output) against g20 = the REAL reference under float16 CPU autocast.  Op by op — each op fed the reference's input tap — the restatement is
+    bit-equal to the reference in >= 99.9 % of the elements and within one fp16 ulp elsewhere; end to end the two sit as far apart as g20 sits from the
+    f32 forward (the fp16 recipe is chaotic at the output level), which is what the GPU test's noise bounds are sized by."""
+    import torch.nn.functional as F
+    g = golden("g20_mixed_precision_fp16.npz")
+    tp = lambda k: torch.from_numpy(g[f"64x96/tap/{k}"].astype(np.float32))
+    H, W = 64, 96
+    cfg = synth.xpoint_exp1_config(H, W)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg).items()}
+    p = "encoder.layers.0.blocks.0."
+
+    def check(name, mine, ref, frac=0.999, ulps=1.01):
+        eq = float((mine == ref).float().mean())
+        ulp = torch.clamp(ref.abs(), min=float(ref.pow(2).mean().sqrt())) * 2.0 ** -10      # fp16 spacing at the value, floored at the tensor's rms
+        worst = float(((mine - ref).abs() / ulp).max())
+        assert eq >= frac and worst <= ulps, (name, eq, worst)
+    xo.AMP16 = True
+    try:
+        with torch.no_grad():
+            check("patch_embed", xo.patch_embed(tp("patch_embed/in")[:, :1], sd, "encoder.patch_embed."), tp("patch_embed/out"), frac=0.995, ulps=2.01)
+            check("norm", xo._h(F.layer_norm(tp("b0.norm/in"), (96,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)), tp("b0.norm/out"))
+            check("ss2d (in_proj .. out_proj)", xo.ss2d(tp("b0.op/in"), sd, p + "op."), tp("b0.op/out"), frac=0.98, ulps=2.01)
+            check("block 0", xo.vss_block(tp("b0/in"), sd, p), tp("b0/out"), frac=0.97, ulps=3.01)
+            check("block 1", xo.vss_block(tp("b1/in"), sd, "encoder.layers.0.blocks.1."), tp("b1/out"), frac=0.97, ulps=3.01)
+            check("downsample 0", xo.downsample(tp("ds0/in"), sd, "encoder.layers.0.downsample."), tp("ds0/out"), frac=0.995, ulps=2.01)
+            d = "detector_head_convolutions."
+            x = xo._conv(tp("head_det.1/in"), sd[d + "1.weight"], sd[d + "1.bias"])
+            check("head conv", x, tp("head_det.1/out"), frac=0.995, ulps=1.01)
+            check("head relu + bn", xo._bn(F.relu(tp("head_det.3/in")), sd, d + "3."), tp("head_det.3/out"))
+            data = synth.to_torch(synth.make_pair_batch(0, 1, H, W))
+            o, t, _ = xo.xpoint_forward(data, sd)
+    finally:
+        xo.AMP16 = False
+    with torch.no_grad():
+        o32, _, _ = xo.xpoint_forward(data, sd)
+    for k in ("prob", "desc", "encoder_output"):
+        ref = g[f"64x96/optical/{k}"]
+        e_amp = float(np.abs(o[k].numpy() - ref).max()); e_f32 = float(np.abs(o32[k].numpy() - ref).max())
+        assert e_amp < 3.0 * e_f32 + 1e-3, (k, e_amp, e_f32)          # same noise level as the recipe's own distance from f32
+    assert torch.equal(o["encoder_output"], o["encoder_output"].half().float())

