@@ -362,20 +362,27 @@ def test_pipeline_edge_cases(gpu_lib):
 
 
 def test_async_nms_reports_non_convergence(gpu_lib):
+    """Two forms of xp_box_nms.  Images whose bit masks fit one workgroup's LDS (every model size up to ~1000 x 700) take the round-3 form: local maxima,
+    one suppression pass, then a per-image finisher that iterates to the fixed point INSIDE its launch — no sweep count, always converged, also on a
+    640-long suppression chain.  Larger images keep the sweep form: a fixed number of stream-ordered sweeps whose convergence is checked afterwards."""
     import ctypes
     from xpoint_amd import _lib as L
-    H, W = 64, 640
-    p = torch.zeros(1, H, W)
-    p[0, 30:34, :] = 0.5 + 0.4 * torch.arange(W) / W          # monotone ridge: needs many sweeps
-    pd = p.cuda(); out = torch.empty_like(pd)
     lib = L.load()
-    ws = torch.empty(lib.xp_box_nms_workspace_bytes(1, H, W, 1), dtype=torch.uint8, device="cuda")
-    left = ctypes.c_int(-1)
-    L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 1, None, L.current_stream()), "nms")
-    L.check(lib.xp_box_nms_check(L.ptr(ws), 1, H, W, ctypes.byref(left), L.current_stream()), "check")
-    assert left.value > 0                                        # one sweep cannot finish a 640-long chain
-    L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 0, ctypes.byref(left), L.current_stream()), "nms")
-    assert torch.equal(out.cpu(), xo.box_nms(p.unsqueeze(1), 8, 0.015)[:, 0])      # the synchronous form iterates to the fixed point
+    for (H, W, sweeps_needed) in ((64, 640, False), (2048, 640, True)):
+        p = torch.zeros(1, H, W)
+        p[0, 30:34, :] = 0.5 + 0.4 * torch.arange(W) / W          # monotone ridge: a 640-long chain of decisions
+        pd = p.cuda(); out = torch.empty_like(pd)
+        ws = torch.empty(lib.xp_box_nms_workspace_bytes(1, H, W, 1), dtype=torch.uint8, device="cuda")
+        left = ctypes.c_int(-1)
+        L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 1, None, L.current_stream()), "nms")
+        L.check(lib.xp_box_nms_check(L.ptr(ws), 1, H, W, ctypes.byref(left), L.current_stream()), "check")
+        ref = xo.box_nms(p.unsqueeze(1), 8, 0.015)[:, 0]
+        if sweeps_needed:
+            assert left.value > 0                                    # one sweep cannot finish the chain, and says so
+            L.check(lib.xp_box_nms(L.ptr(pd), L.ptr(out), L.ptr(ws), ws.numel(), 1, H, W, 8.0, 0.015, 0.1, 0, 1, 0, ctypes.byref(left), L.current_stream()), "nms")
+        else:
+            assert left.value == 0
+        assert torch.equal(out.cpu(), ref)
 
 
 def test_multispectral_two_encoder_routing(gpu_lib, golden):
@@ -690,18 +697,18 @@ def test_trained_like_weights_vs_reference(gpu_lib, golden, gemm_mode, capsys):
 
 
 def test_pipeline_heals_nms_non_convergence(gpu_lib):
-    """The stream-ordered NMS enqueues a fixed number of sweeps; an image whose suppression chains need more (found on pairs 8..63 of the C3 batch
-    at 6 sweeps) must not fail the step: verify() raises the count (kept), recomputes the latest call's post-processing and the results equal
-    those of a pipeline that had enough sweeps from the start — eager and captured."""
+    """Images too large for the in-launch finisher (1024 x 1024: BASELINE config C4) keep the stream-ordered sweep form, which enqueues a fixed number
+    of sweeps; an image whose suppression chains need more must not fail the step: verify() raises the count (kept), recomputes the latest call's
+    post-processing and the results equal those of a pipeline that had enough sweeps from the start — eager and captured."""
     from xpoint_amd.predict import PairPipeline
-    H, W, B = 96, 128, 2
+    H, W, B = 1024, 1024, 1
     net = _net(synth.xpoint_exp1_config(H, W))
     d = _data(2, B, H, W)
     args = (d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"])
     with torch.no_grad():
-        ref = PairPipeline(net, B, H, W, cap=2048, nms_sweeps=16).run(*args).fetch()
+        ref = PairPipeline(net, B, H, W, cap=32768, nms_sweeps=16).run(*args).fetch()
         for graph in (False, True):
-            pipe = PairPipeline(net, B, H, W, cap=2048, nms_sweeps=1)
+            pipe = PairPipeline(net, B, H, W, cap=32768, nms_sweeps=1)
             step = pipe.capture(*args) if graph else pipe.run
             step(*args)
             with pytest.warns(RuntimeWarning, match="NMS needed more than 1 sweeps"):

@@ -146,6 +146,344 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Box NMS, round-3 form: TWO launches, exact, convergence guaranteed inside the second one.
+// Measured on a 480 x 640 heat map of this model (tools/nms_rounds.py): 31 k of 307 k pixels are candidates; the candidates that are
+// maxima of their own overlap window (2.5 k) decide 22.5 k more in one step, and the remaining 6.4 k settle in three more keep rounds.
+//   A  nms_localmax_kernel: one pass over the image in 32 x 64 tiles + halo — candidate mask, "kept in round 1" mask (a candidate with no
+//      higher-priority candidate in its window; needs only the raw scores, so no tile ever waits for another) and the provisional output
+//      (score where kept, 0 elsewhere).  Bit masks go to global memory as one uint32 per (row, 32 columns): a tile owns its words.
+//   B  nms_finish_kernel: ONE workgroup per image holds the image's two bit masks in LDS (480 x 640: 87 KB), drops every candidate that a
+//      round-1 keeper suppresses, ranks what is left (row-major rank = row base + word prefix + popcount) into a score table in LDS and runs
+//      the keep / suppress fixed point as Jacobi rounds separated by workgroup barriers until nothing is undecided — no other workgroup, no
+//      host round trip, no sweep count.  Later keepers patch the output sparsely.
+// Images whose masks do not fit LDS (1024 x 1024) keep the sweep form above.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restrict__ prob, float* __restrict__ out, unsigned* __restrict__ cand32,
+                                                           unsigned* __restrict__ kept32, int H, int W, int wpr, NmsTable tab, float min_prob) {
+    constexpr int TWMAX = NMS_TILE + 2 * NMS_MAXR, THMAX = NMS_TH + 2 * NMS_MAXR;
+    __shared__ float s_sc[TWMAX * THMAX];
+    __shared__ unsigned long long m_cand[THMAX], m_kept[THMAX];
+    __shared__ unsigned short s_list[NMS_TILE * NMS_TH];
+    __shared__ int s_n;
+    const int R = tab.reach;
+    const int TW = NMS_TILE + 2 * R, TH = NMS_TH + 2 * R;
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * NMS_TH - R, x0 = blockIdx.x * NMS_TILE - R;
+    const float* pb = prob + (int64_t)b * H * W;
+    float* ob = out + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < TH; i += 256) { m_cand[i] = 0ull; m_kept[i] = 0ull; }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // tile + halo, a wave per tile row (lane = column, TW <= 62): the row's candidate mask is one ballot — no LDS atomics on the masks — and the
+    // owned candidates of the row take their list slots from ONE atomicAdd per wave and row (popcount prefix inside the wave).  Batches of 8 rows per
+    // wave: the loads of a batch are issued before the first is used.
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int x = x0 + lane;
+        const bool xin = lane < TW && x >= 0 && x < W;
+        const unsigned long long own_cols = ((1ull << NMS_TILE) - 1ull) << R;
+        for (int r0 = wave; r0 < TH; r0 += 4 * 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ty = r0 + 4 * k, y = y0 + ty;
+                v[k] = (ty < TH && xin && y >= 0 && y < H) ? pb[(int64_t)y * W + x] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ty = r0 + 4 * k;
+                if (ty >= TH) continue;                              // wave-uniform
+                if (lane < TW) s_sc[ty * TW + lane] = v[k];
+                const unsigned long long m = __ballot(v[k] > min_prob);      // (elements outside the image were loaded as 0 <= min_prob)
+                if (lane == 0) m_cand[ty] = m;
+                const unsigned long long own = (ty >= R && ty < R + NMS_TH) ? (m & own_cols) : 0ull;
+                if (own) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n, __popcll(own));
+                    base = __shfl(base, 0, 64);
+                    if ((own >> lane) & 1ull) s_list[base + __popcll(own & ((1ull << lane) - 1ull))] = (unsigned short)(ty * 64 + lane);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int li = threadIdx.x; li < n; li += 256) {
+        const int ty = s_list[li] >> 6, tx = s_list[li] & 63;
+        const float sc = s_sc[ty * TW + tx];
+        const int sh = tx - R;
+        bool top = true;
+        if (R >= 1) {
+            // quick reject: the 8 immediate neighbours are inside every overlap window (non-candidates score <= min_prob < sc: harmless); eight
+            // independent LDS reads settle ~8 of 9 candidates before the window walk
+            const float* c = s_sc + ty * TW + tx;
+            const float n0 = c[-TW - 1], n1 = c[-TW], n2 = c[-TW + 1], n3 = c[-1], n4 = c[1], n5 = c[TW - 1], n6 = c[TW], n7 = c[TW + 1];
+            top = !(n0 >= sc || n1 >= sc || n2 >= sc || n3 >= sc || n4 > sc || n5 > sc || n6 > sc || n7 > sc);
+        }
+        for (int dy = -R; dy <= R && top; ++dy) {
+            unsigned long long u = m_cand[ty + dy] & (tab.win[dy < 0 ? -dy : dy] << sh);
+            if (dy == 0) u &= ~(1ull << tx);
+            while (u) {
+                const int bx = __ffsll((long long)u) - 1;
+                u &= u - 1;
+                const float sq = s_sc[(ty + dy) * TW + bx];
+                if (sq > sc || (sq == sc && (dy < 0 || (dy == 0 && bx < tx)))) { top = false; break; }    // q has higher priority (score, then row-major index)
+            }
+        }
+        if (top) atomicOr(&m_kept[ty], 1ull << tx);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < NMS_TILE * NMS_TH; o += 256) {      // NMS_TILE = 32: a wave instruction writes two full 128-byte row segments
+        const int ty = R + o / NMS_TILE, tx = R + o % NMS_TILE;
+        const int y = y0 + ty, x = x0 + tx;
+        if (y < H && x < W) ob[(int64_t)y * W + x] = ((m_kept[ty] >> tx) & 1ull) ? s_sc[ty * TW + tx] : 0.f;
+    }
+    for (int r = threadIdx.x; r < NMS_TH; r += 256) {
+        const int y = y0 + R + r;
+        if (y < H) {
+            const int64_t wo = ((int64_t)b * H + y) * wpr + blockIdx.x;
+            cand32[wo] = (unsigned)((m_cand[R + r] & ~m_kept[R + r]) >> R);     // the undecided set after round 1
+            kept32[wo] = (unsigned)(m_kept[R + r] >> R);
+        }
+    }
+}
+
+// ---- pass A2: candidates that a round-1 keeper suppresses leave the undecided set.  Bit-mask work only; one workgroup per band of 32 rows.
+constexpr int NMS_S1_ROWS = 32;
+__host__ __device__ inline int rw_of(int W) { return (W + 31) / 32 + 2; }
+__device__ __forceinline__ unsigned long long nms_window(const unsigned* __restrict__ row, int x, int R) {
+    // bits [x - R, x - R + 63] of a padded mask row (one zero word on the left): bit j <-> column x - R + j
+    const int xp = x - R + 32;
+    const int wi = xp >> 5, sh = xp & 31;
+    return (((unsigned long long)row[wi + 1] << 32) | row[wi]) >> sh;
+}
+// "does any bit of the padded mask M (row r of the image at M + (r + pad_rows) * rw) fall into the window of (y, x)"; RT > 0: compile-time reach,
+// the 2 RT + 1 row reads are unrolled and issued together (one LDS round trip instead of 2 RT + 1 dependent ones)
+template <int RT>
+__device__ __forceinline__ bool nms_any_in_window(const unsigned* __restrict__ M, int rw, int yrow, int x, int R, const NmsTable& tab) {
+    constexpr int NW = RT > 0 ? 2 * RT + 1 : 2 * NMS_MAXR + 1;
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int dy = k - (NW >> 1);
+        if (RT > 0 || (dy >= -R && dy <= R)) acc |= nms_window(M + (yrow + dy) * rw, x, R) & tab.win[dy < 0 ? -dy : dy];
+    }
+    return acc != 0ull;
+}
+
+// One Jacobi round over the whole batch (all CUs): every undecided candidate reads the masks as the previous round left them —
+//   a kept box in its window      -> suppressed (leaves the undecided set);
+//   no undecided box of higher priority in its window -> kept (score written to `out`);
+// and the band's rows of the next masks are written.  Round 1 after the local-maximum pass is pure suppression (22.5 k of 28.9 k candidates on a
+// 480 x 640 map), rounds 2 and 3 leave ~700 of 6.4 k: what remains goes to the finisher.  A workgroup owns a band of 32 rows and keeps the band's
+// rows + reach of both masks in LDS; neighbour scores come from the L2-resident heat map.
+// SUP_ONLY: the suppression half alone (no neighbour-score reads) — round 1 after the local-maximum pass, where no candidate can become a keeper yet
+// (its higher-priority neighbours are still undecided until this very round suppresses them).  The full form distributes candidates by mask word,
+// which serialises dense blobs (32 undecided pixels in one word = 32 dependent chains in one lane: 95 us for round 2 on the model's maps against 11 us
+// for the suppression half); the finisher's compacted list balances them, so by default only the suppression half runs wide (XP_NMS_WIDE_ROUNDS adds
+// full rounds for experiments).
+template <int RT, bool SUP_ONLY>
+__global__ __launch_bounds__(256) void nms_round_kernel(const float* __restrict__ prob, float* __restrict__ out, const unsigned* __restrict__ und_in,
+                                                        const unsigned* __restrict__ kept_in, unsigned* __restrict__ und_out, unsigned* __restrict__ kept_out,
+                                                        int H, int W, int wpr, NmsTable tab) {
+    __shared__ unsigned s_k[(NMS_S1_ROWS + 2 * NMS_MAXR) * (2 + 64)];      // kept rows of the band + reach, padded (wpr <= 64: host)
+    __shared__ unsigned s_u[(NMS_S1_ROWS + 2 * NMS_MAXR) * (2 + 64)];      // undecided rows
+    const int R = RT > 0 ? RT : tab.reach;
+    constexpr int NW = RT > 0 ? 2 * RT + 1 : 2 * NMS_MAXR + 1;
+    const int rw = wpr + 2, b = blockIdx.y, y0 = blockIdx.x * NMS_S1_ROWS;
+    const int nrows = NMS_S1_ROWS + 2 * R;
+    const float* pb = prob + (int64_t)b * H * W;
+    float* ob = out + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < nrows * rw; i += 256) {
+        const int r = i / rw, wi = i - r * rw - 1, y = y0 - R + r;
+        const bool in = y >= 0 && y < H && wi >= 0 && wi < wpr;
+        s_k[i] = in ? kept_in[((int64_t)b * H + y) * wpr + wi] : 0u;
+        s_u[i] = in ? und_in[((int64_t)b * H + y) * wpr + wi] : 0u;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NMS_S1_ROWS * wpr; i += 256) {
+        const int r = i / wpr, wi = i - r * wpr, y = y0 + r;
+        if (y >= H) continue;
+        const int64_t wo = ((int64_t)b * H + y) * wpr + wi;
+        unsigned u = s_u[(r + R) * rw + wi + 1], stay = 0u, keep = 0u;
+        while (u) {
+            const int bit = __ffs((int)u) - 1;
+            u &= u - 1;
+            const int x = wi * 32 + bit;
+            if (nms_any_in_window<RT>(s_k, rw, r + R, x, R, tab)) continue;          // suppressed
+            if (SUP_ONLY) { stay |= 1u << bit; continue; }
+            const float sc = pb[(int64_t)y * W + x];
+            bool blocked = false;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int dy = k - (NW >> 1);
+                unsigned long long v = (RT > 0 || (dy >= -R && dy <= R)) ? (nms_window(s_u + (r + R + dy) * rw, x, R) & tab.win[dy < 0 ? -dy : dy]) : 0ull;
+                if (dy == 0) v &= ~(1ull << R);
+                if (blocked) v = 0ull;
+                while (v) {
+                    const int j = __ffsll((long long)v) - 1;
+                    v &= v - 1;
+                    const int xx = x - R + j;
+                    const float sq = pb[(int64_t)(y + dy) * W + xx];
+                    if (sq > sc || (sq == sc && (dy < 0 || (dy == 0 && xx < x)))) { blocked = true; break; }
+                }
+            }
+            if (blocked) stay |= 1u << bit;
+            else { keep |= 1u << bit; ob[(int64_t)y * W + x] = sc; }
+        }
+        und_out[wo] = stay;
+        kept_out[wo] = s_k[(r + R) * rw + wi + 1] | keep;
+    }
+}
+
+// ---- pass B: the finisher.  LDS: two padded bit masks ((H + 2R) rows of wpr + 2 words) and the list of undecided positions in what is left.
+struct NmsFinishPlan { int wpr, rows, rw; size_t mask_bytes, list_off; int list_cap; };
+__host__ __device__ inline NmsFinishPlan nms_finish_plan(int H, int W, int R, size_t lds_budget) {
+    NmsFinishPlan p;
+    p.wpr = (W + 31) / 32; p.rows = H + 2 * R; p.rw = p.wpr + 2;
+    p.mask_bytes = (size_t)p.rows * p.rw * 4;
+    p.list_off = (2 * p.mask_bytes + 15) / 16 * 16;
+    p.list_cap = lds_budget > p.list_off ? (int)((lds_budget - p.list_off) / 8) : 0;        // (position, score) per undecided candidate
+    return p;
+}
+constexpr int NMS_FIN_THREADS = 1024;
+constexpr size_t NMS_FIN_LDS = 158 * 1024;
+
+template <int RT>
+__global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float* __restrict__ prob, float* __restrict__ out,
+                                                                       const unsigned* __restrict__ und32, const unsigned* __restrict__ kept32,
+                                                                       int* __restrict__ glist, int H, int W, NmsTable tab, int* __restrict__ counters,
+                                                                       int* __restrict__ info) {
+    extern __shared__ __align__(16) unsigned char fin_lds[];
+    __shared__ int s_n;
+    const int R = RT > 0 ? RT : tab.reach;
+    constexpr int NW = RT > 0 ? 2 * RT + 1 : 2 * NMS_MAXR + 1;
+    const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS);
+    unsigned* mU = reinterpret_cast<unsigned*>(fin_lds);                          // undecided (bits cleared as decisions fall)
+    unsigned* mK = reinterpret_cast<unsigned*>(fin_lds + pl.mask_bytes);          // kept
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pb = prob + (int64_t)b * H * W;
+    float* ob = out + (int64_t)b * H * W;
+    const int wpr = pl.wpr, rw = pl.rw, nwords = H * wpr;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    auto stamp = [&](int slot) { if (tid == 0 && info) info[8 * b + slot] = (int)(__builtin_amdgcn_s_memrealtime() - t_start); };     // 100 MHz ticks (diagnostics)
+    if (b == 0 && tid < NMS_MAX_SWEEPS) counters[tid] = 0;                        // xp_box_nms_check: this form always converges
+    for (int i = tid; i < pl.rows * rw; i += NMS_FIN_THREADS) { mU[i] = 0u; mK[i] = 0u; }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // masks in; undecided positions into the list (LDS when it fits, else the caller's workspace — same code through a flat pointer)
+    int my_count = 0;
+    for (int i = tid; i < nwords; i += NMS_FIN_THREADS) {
+        const int y = i / wpr, wi = i - y * wpr;
+        const unsigned u = und32[(int64_t)b * nwords + i];
+        mU[(y + R) * rw + wi + 1] = u;
+        mK[(y + R) * rw + wi + 1] = kept32[(int64_t)b * nwords + i];
+        my_count += __popc(u);
+    }
+    int my_base = my_count ? atomicAdd(&s_n, my_count) : 0;
+    __syncthreads();
+    const int total = s_n;
+    const int cap = total <= pl.list_cap ? pl.list_cap : H * W;
+    int* list = total <= pl.list_cap ? reinterpret_cast<int*>(fin_lds + pl.list_off) : glist + (int64_t)b * H * W * 2;
+    float* lscore = reinterpret_cast<float*>(list + cap);
+    for (int i = tid; i < nwords; i += NMS_FIN_THREADS) {
+        const int y = i / wpr, wi = i - y * wpr;
+        unsigned u = mU[(y + R) * rw + wi + 1];
+        while (u) {
+            const int bit = __ffs((int)u) - 1;
+            u &= u - 1;
+            lscore[my_base] = pb[(int64_t)y * W + wi * 32 + bit];
+            list[my_base++] = (y << 16) | (wi * 32 + bit);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && info) { info[8 * b] = total; info[8 * b + 1] = total <= pl.list_cap ? 0 : 1; }
+    stamp(3);
+    // Fixed point, asynchronous inside the workgroup.  Races between lanes are harmless by ordering: a lane that keeps q sets q's KEPT bit BEFORE
+    // clearing its UNDECIDED bit, and a reader looks at UNDECIDED first and at KEPT afterwards, so it can never miss q in both.
+    // The whole image runs on ONE CU, so instructions — not latency — are the budget (16 waves share 4 SIMDs): after every round the list is
+    // compacted to the still-undecided entries (a wave is then busy with 64 live candidates, not with one), and a candidate's work is a loop over
+    // the few undecided neighbours it really has, not an unrolled worst case.
+    volatile unsigned* vU = mU;
+    __shared__ int s_cnt[NMS_FIN_THREADS / 64];
+    int n_live = total;
+    for (int round = 0; round < 1000000; ++round) {
+        // entries [0, n_live) are live; this thread's slice is contiguous within the round: e = tid + k * 1024
+        int nkeep = 0;
+        int kpos[8]; float ksc[8];                                   // survivors of this thread (at most 8 per round: slices beyond that stay in place, see below)
+        const bool small = n_live <= 8 * NMS_FIN_THREADS;
+        for (int e = tid; e < n_live; e += NMS_FIN_THREADS) {
+            const int pos = list[e];
+            const float sc = lscore[e];
+            const int y = pos >> 16, x = pos & 0xffff;
+            const int wofs = (y + R) * rw + (x >> 5) + 1;
+            const unsigned mybit = 1u << (x & 31);
+            bool live = (vU[wofs] & mybit) != 0u;
+            if (live && nms_any_in_window<RT>(mK, rw, y + R, x, R, tab)) { atomicAnd(&mU[wofs], ~mybit); live = false; }
+            if (live) {
+                bool blocked = false;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const int dy = k - (NW >> 1);
+                    unsigned long long v = (RT > 0 || (dy >= -R && dy <= R)) ? (nms_window(mU + (y + R + dy) * rw, x, R) & tab.win[dy < 0 ? -dy : dy]) : 0ull;
+                    if (dy == 0) v &= ~(1ull << R);
+                    if (blocked) v = 0ull;
+                    while (v) {
+                        const int j = __ffsll((long long)v) - 1;
+                        v &= v - 1;
+                        const int xx = x - R + j;
+                        const float sq = pb[(int64_t)(y + dy) * W + xx];            // L2-resident heat map (1.2 MB per image)
+                        if (sq > sc || (sq == sc && (dy < 0 || (dy == 0 && xx < x)))) { blocked = true; break; }
+                    }
+                }
+                if (!blocked) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (nms_any_in_window<RT>(mK, rw, y + R, x, R, tab)) { atomicAnd(&mU[wofs], ~mybit); }      // the authoritative read
+                    else {
+                        atomicOr(&mK[wofs], mybit);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        atomicAnd(&mU[wofs], ~mybit);
+                        ob[(int64_t)y * W + x] = sc;
+                    }
+                    live = false;
+                }
+            }
+            if (live && small) {
+                // static register slots: select chain instead of a dynamically indexed array
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q == nkeep) { kpos[q] = pos; ksc[q] = sc; }
+                ++nkeep;
+            } else if (live) {
+                nkeep = 1;                                           // large lists are not compacted (they shrink below the limit within a round or two)
+            }
+        }
+        if (!small) {
+            if (!__syncthreads_or(nkeep)) { n_live = 0; break; }
+            continue;
+        }
+        // compaction: exclusive scan of the per-thread survivor counts (wave ballots + a scan of the 16 wave totals)
+        const int lane = tid & 63, wave = tid >> 6;
+        int incl = nkeep;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_cnt[wave] = incl;
+        __syncthreads();                                             // (also: every read of list / lscore of this round is done)
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < NMS_FIN_THREADS / 64; ++wv) { const int c = s_cnt[wv]; if (wv < wave) base += c; tot += c; }
+        base += incl - nkeep;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < nkeep) { list[base + q] = kpos[q]; lscore[base + q] = ksc[q]; }
+        __syncthreads();
+        n_live = tot;
+        if (tid == 0 && info) info[8 * b + 2] = round + 1;
+        if (n_live == 0) break;
+    }
+    stamp(7);
+}
+
 // Counter housekeeping as kernels, not hipMemsetAsync / hipMemcpyAsync: replayed from several hipGraphs on several streams
 // (PairPipeline.capture with overlap) the API memset / copy nodes left the counters holding stale bytes on ROCm 7.2, kernel
 // nodes do not.
@@ -373,8 +711,9 @@ bool make_nms_table(float size, float iou, NmsTable* t) {
 }  // namespace
 
 namespace {
-struct NmsWs { uint8_t* state; uint8_t* tile_active; int* counters; int* kp; };
-NmsWs nms_ws(void* workspace, int batch, int H, int W) {
+struct NmsWs { uint8_t* state; uint8_t* tile_active; int* counters; int* kp; float* gtab; int* info; unsigned* cand32; unsigned* kept32; };
+size_t nms_ws_tail_offset(int batch, int H, int W, int cap);
+NmsWs nms_ws(void* workspace, int batch, int H, int W, int cap = 0) {
     const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
     const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TH) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
     NmsWs w;
@@ -382,18 +721,71 @@ NmsWs nms_ws(void* workspace, int batch, int H, int W) {
     w.tile_active = w.state + n;
     w.counters = (int*)(w.tile_active + nt);
     w.kp = w.counters + NMS_MAX_SWEEPS;
+    // round-3 form: the bit masks live in the (otherwise unused) state bytes: 2 * H * ceil(W / 32) words per image <= H * W bytes for W >= 32
+    w.cand32 = (unsigned*)w.state;                          // four mask arrays of batch * H * ceil(W / 32) words: (undecided, kept) x ping-pong
+    w.kept32 = w.cand32 + (size_t)batch * H * xp_cdiv(W, 32);
+    char* tail = (char*)workspace + nms_ws_tail_offset(batch, H, W, cap);
+    w.gtab = (float*)tail;                                  // undecided-list overflow area: (position, score) per pixel (used only when an image's list outgrows LDS)
+    w.info = (int*)(tail + 2 * sizeof(float) * (size_t)batch * H * W);
     return w;
 }
 }  // namespace
 
-extern "C" size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap) {
-    // state bytes + tile flags + counters + (top-k) keypoint list, counts, ranks
+namespace {
+size_t nms_ws_tail_offset(int batch, int H, int W, int cap) {
     const size_t n = ((size_t)batch * H * W + 255) / 256 * 256;
     const size_t nt = ((size_t)batch * xp_cdiv(H, NMS_TH) * xp_cdiv(W, NMS_TILE) + 255) / 256 * 256;
-    return n + nt + sizeof(int) * (NMS_MAX_SWEEPS + (size_t)batch * cap * 3 + batch + 64) + xp_extract_keypoints_workspace_bytes(batch, H, W);
+    const size_t head = n + nt + sizeof(int) * (NMS_MAX_SWEEPS + (size_t)batch * cap * 3 + batch + 64) + xp_extract_keypoints_workspace_bytes(batch, H, W);
+    return (head + 255) / 256 * 256;
+}
+// the two-launch form applies when an image's padded masks, rank prefix and a minimal score table fit one workgroup's LDS, a thread owns at
+// most NMS_FIN_MAXW mask words and the mask words fit the state bytes
+bool nms_two_launch_applies(int H, int W, int R) {
+    static const bool force_sweeps = getenv("XP_NMS_SWEEP") != nullptr && atoi(getenv("XP_NMS_SWEEP")) != 0;     // A/B: the round-1/2 sweep form
+    if (force_sweeps || W < 32) return false;
+    const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS);
+    return pl.wpr <= 64 && H < 65536 && W < 65536 && pl.list_cap >= 4096;
+}
+}  // namespace
+
+extern "C" size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap) {
+    // state bytes (sweep form) / bit masks (two-launch form) + tile flags + counters + (top-k) keypoint list, counts, ranks + score-table overflow + info
+    return nms_ws_tail_offset(batch, H, W, cap) + 2 * sizeof(float) * (size_t)batch * H * W + sizeof(int) * (8 * (size_t)batch + 64);
 }
 
 // Enqueue `sweeps` sweep launches (each exits at once when the previous one left nothing undecided).
+static int box_nms_two_launch(const float* prob, float* out, void* workspace, int batch, int H, int W, int cap, const NmsTable& tab, float min_prob,
+                              hipStream_t s) {
+    const NmsWs w = nms_ws(workspace, batch, H, W, cap);
+    XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
+    static bool attr_set = false;
+    if (!attr_set) {
+        XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_FIN_LDS));
+        XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_FIN_LDS));
+        attr_set = true;
+    }
+    const int wpr = xp_cdiv(W, 32);
+    hipLaunchKernelGGL(nms_localmax_kernel, dim3(wpr, xp_cdiv(H, NMS_TH), batch), dim3(256), 0, s, prob, out, w.cand32, w.kept32, H, W, wpr, tab, min_prob);
+    // wide Jacobi rounds (ping-pong masks), then the per-image finisher for what is left; the count only moves work between the two, never the result
+    static const int wide_rounds = getenv("XP_NMS_WIDE_ROUNDS") ? atoi(getenv("XP_NMS_WIDE_ROUNDS")) : 0;
+    const size_t mw = (size_t)batch * H * wpr;
+    unsigned* um[2] = {w.cand32, w.cand32 + 2 * mw};
+    unsigned* km[2] = {w.kept32, w.kept32 + 2 * mw};
+    int cur = 0;
+    const dim3 rgrid(xp_cdiv(H, NMS_S1_ROWS), batch);
+    if (tab.reach == 6) hipLaunchKernelGGL((nms_round_kernel<6, true>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
+    else hipLaunchKernelGGL((nms_round_kernel<0, true>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
+    cur ^= 1;
+    for (int r = 0; r < wide_rounds; ++r, cur ^= 1) {
+        if (tab.reach == 6) hipLaunchKernelGGL((nms_round_kernel<6, false>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
+        else hipLaunchKernelGGL((nms_round_kernel<0, false>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
+    }
+    if (tab.reach == 6) hipLaunchKernelGGL(nms_finish_kernel<6>, dim3(batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], (int*)w.gtab, H, W, tab, w.counters, w.info);
+    else hipLaunchKernelGGL(nms_finish_kernel<0>, dim3(batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], (int*)w.gtab, H, W, tab, w.counters, w.info);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
 static int box_nms_enqueue(const float* prob, float* out, void* workspace, int batch, int H, int W, const NmsTable& tab,
                            float min_prob, int sweeps, bool first_round, hipStream_t s) {
     const NmsWs w = nms_ws(workspace, batch, H, W);
@@ -436,8 +828,16 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
     XP_CHECK_ARG(make_nms_table(size, iou, &tab), "xp_box_nms: size must be a positive multiple of 0.5 and <= %d (got %f)", NMS_MAXR + 1, size);
     hipStream_t s = (hipStream_t)stream;
     XP_CHECK_ARG(max_sweeps_async <= NMS_MAX_SWEEPS, "xp_box_nms: at most %d async sweeps", NMS_MAX_SWEEPS);
-    const NmsWs w = nms_ws(workspace, batch, H, W);
-    if (max_sweeps_async > 0) {
+    const NmsWs w = nms_ws(workspace, batch, H, W, cap);
+    if (nms_two_launch_applies(H, W, tab.reach)) {
+        // two launches, exact, no sweep count (see nms_localmax_kernel): the same in the stream-ordered and in the synchronous mode
+        int rc = box_nms_two_launch(prob, out, workspace, batch, H, W, cap, tab, min_prob, s);
+        if (rc) return rc;
+        if (max_sweeps_async <= 0) {
+            XP_HIP(hipStreamSynchronize(s));
+            if (converged_host) *converged_host = 1;
+        }
+    } else if (max_sweeps_async > 0) {
         // fire-and-forget: the caller checks the last counter later (xp_box_nms_check)
         int rc = box_nms_enqueue(prob, out, workspace, batch, H, W, tab, min_prob, max_sweeps_async, true, s);
         if (rc) return rc;
