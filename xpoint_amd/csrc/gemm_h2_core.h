@@ -40,13 +40,19 @@ constexpr int H2_SLAB_UNITS = 8;    // 16-byte units per (weight row, slab) in t
 
 __device__ __forceinline__ void h2_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// exact-to-2^-24 two-way fp16 split of four floats: planes as packed fp16 quads
+// Two-way fp16 split of four floats: planes as packed fp16 quads.  Two vector instructions per value (round 2 had four: the compiler turned
+// `(float)h0` + subtract into v_cvt_f32_f16 + v_sub_f32 and converted h0 twice): h0 pair = one v_cvt_pk_f16_f32 (round to nearest even), the residual
+// x - h0 = ONE v_fma_mix_f32 per value reading the packed half in place (fma(h0, -1, x): the difference is exactly representable, so the single rounding
+// is exact), h1 pair = one v_cvt_pk_f16_f32.  The K loop of the tile engine went from 4.0 to 2.x vector instructions per MFMA (profiles/r3_gemm_h2_stalls.txt:
+// the waves were waiting to ISSUE, not for LDS).
+__device__ __forceinline__ float h2_resid_lo(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
+__device__ __forceinline__ float h2_resid_hi(unsigned h, float x) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x)); return r; }
 __device__ __forceinline__ void h2_split4(const float4& v, uint2& p0, uint2& p1) {
     union { f16x2_t h; unsigned u; } a, b, c, d;
     a.h = f16x2_t{(_Float16)v.x, (_Float16)v.y};
     b.h = f16x2_t{(_Float16)v.z, (_Float16)v.w};
-    c.h = f16x2_t{(_Float16)(v.x - (float)a.h[0]), (_Float16)(v.y - (float)a.h[1])};
-    d.h = f16x2_t{(_Float16)(v.z - (float)b.h[0]), (_Float16)(v.w - (float)b.h[1])};
+    c.h = f16x2_t{(_Float16)h2_resid_lo(a.u, v.x), (_Float16)h2_resid_hi(a.u, v.y)};
+    d.h = f16x2_t{(_Float16)h2_resid_lo(b.u, v.z), (_Float16)h2_resid_hi(b.u, v.w)};
     p0 = make_uint2(a.u, b.u);
     p1 = make_uint2(c.u, d.u);
 }
