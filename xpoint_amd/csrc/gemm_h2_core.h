@@ -34,11 +34,17 @@
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
+#ifndef XP_H2_DBG
+#define XP_H2_DBG 0   /* timing experiments only (wrong results), tile engine: 1 no split VALU, 2 no global loads after the prologue, 4 no MFMA, 8 no LDS stores, 16 no barrier, 32 no fragment reads after the first slab */
+#endif
 constexpr int H2_BK = 32;           // k per slab
 constexpr int H2_ROWB = 144;        // LDS bytes per tile row
 constexpr int H2_SLAB_UNITS = 8;    // 16-byte units per (weight row, slab) in the offline layout: 2 planes x 4 octets
 
-__device__ __forceinline__ void h2_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void h2_lds_barrier() {
+    if (XP_H2_DBG & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Two-way fp16 split of four floats: planes as packed fp16 quads.  Two vector instructions per value (round 2 had four: the compiler turned
 // `(float)h0` + subtract into v_cvt_f32_f16 + v_sub_f32 and converted h0 twice): h0 pair = one v_cvt_pk_f16_f32 (round to nearest even), the residual
@@ -98,14 +104,21 @@ struct GemmTileH2 {
         const int wm = wave / WN, wn = wave % WN;
         const int fr = lane & 31, fh = lane >> 5;
         auto gloadA = [&](RawA& r, int t) {
+            if ((XP_H2_DBG & 2) && t > 3) return;
 #pragma unroll
             for (int s = 0; s < A_LD; ++s) r.ok[s] = ldA(s, t * H2_BK + a_quad(s) * 4, r.a[s]);
         };
         auto gloadB = [&](RawB& r, int t) {
+            if ((XP_H2_DBG & 2) && t > 3) return;
 #pragma unroll
             for (int s = 0; s < B_LD; ++s) r.b[s] = ldB(s, t);
         };
         auto split = [&](const RawA& r, SplitA& o) {
+            if (XP_H2_DBG & 1) {
+#pragma unroll
+                for (int s = 0; s < A_LD; ++s) { o.p[s][0] = make_uint2(__float_as_uint(r.a[s].x), __float_as_uint(r.a[s].y)); o.p[s][1] = make_uint2(__float_as_uint(r.a[s].z), __float_as_uint(r.a[s].w)); }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < A_LD; ++s) {
                 const unsigned m = r.ok[s] ? 0xffffffffu : 0u;       // not-real slots become zeros by masking the input bits
@@ -119,6 +132,7 @@ struct GemmTileH2 {
 #pragma unroll
         for (int s = 0; s < B_LD; ++s) b_dst[s] = BM * H2_ROWB + b_row(s) * H2_ROWB + b_unit(s) * 16;   // a straight copy of the offline layout
         auto lstore = [&](const SplitA& sa, const RawB& rb, unsigned char* buf) {
+            if ((XP_H2_DBG & 8) && buf != lds) return;
 #pragma unroll
             for (int s = 0; s < A_LD; ++s) {
                 *reinterpret_cast<uint2*>(buf + a_dst[s]) = sa.p[s][0];
@@ -130,7 +144,10 @@ struct GemmTileH2 {
         const int a_frag = (wm * TM * 32 + fr) * H2_ROWB + 16 * fh;
         const int b_frag = BM * H2_ROWB + (wn * TN * 32 + fr) * H2_ROWB + 16 * fh;
         f16x8_t af[2][TM], bf[2][TN];
+        bool frag_first = true;
         auto frags = [&](const unsigned char* buf, int ks) {
+            if ((XP_H2_DBG & 32) && !frag_first) return;
+            frag_first = false;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -146,8 +163,10 @@ struct GemmTileH2 {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[pp]][i], bf[PB[pp]][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if (XP_H2_DBG & 4) { if (pp == 0) acc[i][j][0] += (float)af[0][i][0] * (float)bf[0][j][0] + (float)af[1][i][1] * (float)bf[1][j][1]; }
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[pp]][i], bf[PB[pp]][j], acc[i][j], 0, 0, 0);
+                    }
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i)
