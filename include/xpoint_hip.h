@@ -117,6 +117,10 @@ int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const float* bias, 
                   const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
 int xp_conv3x3_nhwc_h2(const float* x, const void* Wh2, float* y, const float* bias, const float* scale, const float* shift,
                        int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
+/* xp_gemm_nt_h2 runs long plain GEMMs (K a multiple of 64, >= 256; N >= 96) on a wave-specialised kernel (csrc/gemm_h2w.hip: producer waves
+ * fill an LDS ring, consumer waves multiply; hand-offs through counters in LDS with BOUNDED waits).  A wait that runs out sets a device word instead
+ * of hanging; this returns it (0 = never happened, 1 = some launch of this process produced wrong numbers, -1 = query failed).  Synchronises. */
+int xp_gemm_h2w_error(void);
 /* Precision class of the "x3" kernels (xp_gemm_nt_x3, xp_conv3x3_nhwc_x3, xp_mlp_fused_x3 and every dense layer of
  * xp_xpoint_forward with wsplit != NULL), process-wide, read at launch time:
  *   6 (default)  all six partial products of weight >= 2^-16: f32-grade (the class pinned against the reference, 1e-4 bar)

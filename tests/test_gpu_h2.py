@@ -239,3 +239,30 @@ def test_h2_adversarial_midpoints(gpu_lib, case, capsys):
     if case == "midpoints":
         assert out["h2"] >= 2.0 ** -24                                 # the systematic dropped term is really there (~2^-22 .. 2^-24): the test bites
     assert out["x3"] <= 2.0 ** -23 + out["f32"], out                  # six products on exact planes: accumulation error only
+
+
+def test_gemm_h2w_wave_specialised_opt_in(gpu_lib):
+    """csrc/gemm_h2w.hip — the wave-specialised schedule of the same split-fp16 GEMM (producer waves fill an LDS ring, consumer waves multiply; hand-offs
+    through LDS counters with BOUNDED waits) — is opt-in (XP_H2W=1: it is slower than the tile kernel).  Run in a child process with the
+    switch on: results within the engine's bar on the shapes it takes, and no hand-off ever timed out (xp_gemm_h2w_error() == 0)."""
+    import os, subprocess, sys
+    code = r'''
+import ctypes, sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from xpoint_amd import _lib as L, synth
+for (M, N, K, res) in [(130, 768, 768, False), (4800, 3072, 768, False), (19200, 384, 1536, True), (200, 200, 768, False), (777, 130, 256, True)]:
+    A = torch.from_numpy(synth.uniform(f"wA{M}{N}{K}", (M, K), -1, 1)); W = torch.from_numpy(synth.uniform(f"wW{M}{N}{K}", (N, K), -0.1, 0.1))
+    b = torch.from_numpy(synth.uniform(f"wb{M}{N}{K}", (N,), -1, 1)); R = torch.from_numpy(synth.uniform(f"wr{M}{N}{K}", (M, N), -1, 1)) if res else None
+    ref = F.linear(A.double(), W.double(), b.double()) + (R.double() if res else 0)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda(); Rd = R.cuda() if res else None
+    Wx = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device="cuda")
+    L.call("xp_split_weights_h2", L.ptr(Wd), ctypes.c_void_p(Wx.data_ptr()), N, K, L.current_stream())
+    C = torch.empty((M, N), device="cuda")
+    L.call("xp_gemm_nt_h2", L.ptr(Ad), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C), L.ptr(bd), None, None, L.ptr(Rd), M, N, K, K, N, N, 0, L.current_stream())
+    err = float((C.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), (M, N, K, err)
+assert L.load().xp_gemm_h2w_error() == 0
+print("h2w ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XP_H2W="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "h2w ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -95,6 +95,7 @@ _SIZE_QUERIES = {
     "xp_get_dense_products": (c_i, []),
     "xp_get_dense_engine": (c_i, []),
     "xp_get_amp_mode": (c_i, []),
+    "xp_gemm_h2w_error": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_mlp_fused_h2_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_ln_proj_h2_pack_bytes": (c_sz, [c_i, c_i]),

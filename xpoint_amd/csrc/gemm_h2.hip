@@ -14,6 +14,10 @@
 
 #include "gemm_h2_core.h"
 
+// wave-specialised form for long plain GEMMs (gemm_h2w.hip)
+bool xp_gemm_h2w_applies(const GemmParams& p);
+int xp_gemm_h2w_launch(const GemmParams& p, hipStream_t s);
+
 namespace {
 
 // one wave per weight row: 2^-k_n with max|W[n, :]| * 2^k_n in [2^13, 2^14) (1 for an all-zero row)
@@ -279,6 +283,7 @@ int dispatch(const GemmParams& p_in, hipStream_t s) {
         XP_LAUNCH_CHECK();
         return XP_OK;
     }
+    if (sel >= 3 && xp_gemm_h2w_applies(p)) return xp_gemm_h2w_launch(p, s);
     switch (sel) {
         case 0: launch<4, 1, 1, 1>(p, s); break;       // 128 x 32
         case 1: launch<4, 1, 1, 2>(p, s); break;       // 128 x 64
