@@ -265,7 +265,7 @@ def main():
     pred = dict(topk=conf["topk"])
     sweeps = conf.get("nms_sweeps", 8)       # sweeps past the fixed point exit at once; 1024x1024 needs more than 480x640 (longer suppression chains)
     pipe = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, overlap=overlap, split_encoder=args.split_encoder,
-                        estimate_homography=args.register, alternate_encoders=(int(os.environ.get("XP_BENCH_DEPTH", "2")) if not args.no_alternate and args.split_encoder in (0, 1) else 0))
+                        estimate_homography=args.register, alternate_encoders=(int(os.environ.get("XP_BENCH_DEPTH", "3")) if not args.no_alternate and args.split_encoder in (0, 1) else 0))
     # single-stream twin for the per-kernel measurements: with several streams in flight a launch's HIP-event duration
     # includes the time it shares the GPU with other kernels, which says nothing about the kernel itself
     pipe1 = PairPipeline(net, B, H, W, cap=CAP, cfg_prediction=pred, nms_sweeps=sweeps, estimate_homography=args.register) if overlap else pipe
@@ -516,8 +516,8 @@ def main():
             "config": {"workload": conf["label"] + f" (pairs/GPU/step = {B}): encode+detect(NMS 8, thr 0.015" + (f", keep_top_k {conf['topk']}" if conf["topk"] else "") +
                                    ")+describe+match(strict mutual NN)" + (", step replayed from hipGraphs" if args.graph else ""),
                        "pairs_per_gpu_per_step": B, "height": H, "width": W, "parallelism": f"pair-sharded x{world}, RCCL weight bcast",
-                       "stream_overlap": ("3 HIP streams: the whole-batch encoders of steps i+1 and i+2 (one stream each, alternating) overlap step i's detection / matching "
-                                          "kernels; all K steps complete inside the timed region") if (overlap and pipe.alternate) else
+                       "stream_overlap": (f"{pipe.depth + 1} HIP streams: the whole-batch encoders of {pipe.depth} consecutive steps (one stream each, taken in turn) overlap each "
+                                          "other and the detection / matching kernels of the step before; all K steps complete inside the timed region") if (overlap and pipe.alternate) else
                                          (f"{1 + max(pipe.split_encoder, 1)} HIP streams: step i+1's encoder ({max(pipe.split_encoder, 1)} image group(s)) overlaps "
                                           "step i's detection / matching kernels; all K steps complete inside the timed region") if overlap else "none (one stream)",
                        "keypoints_per_image_mean": round(sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res) / (2 * len(res)), 1),
