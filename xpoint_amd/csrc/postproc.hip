@@ -339,10 +339,19 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float* __restrict_
 }
 
 // ---- pass B: the finisher.  LDS: two padded bit masks ((H + 2R) rows of wpr + 2 words) and the list of undecided positions in what is left.
-struct NmsFinishPlan { int wpr, rows, rw; size_t mask_bytes, list_off; int list_cap; };
+// An image is handled by `bands` workgroups of `brows` rows each (1 band = the whole image: the fixed point completes inside the launch).  With more
+// bands a workgroup sees the rows of its neighbours (reach R above and below) as they were when the launch started and cannot decide a candidate that
+// waits on one of them: such launches are repeated (ping-pong masks) until a launch leaves nothing undecided — rare chains across a band border.
+struct NmsFinishPlan { int wpr, rows, rw, bands, brows; size_t mask_bytes, list_off; int list_cap; };
 __host__ __device__ inline NmsFinishPlan nms_finish_plan(int H, int W, int R, size_t lds_budget) {
     NmsFinishPlan p;
-    p.wpr = (W + 31) / 32; p.rows = H + 2 * R; p.rw = p.wpr + 2;
+    p.wpr = (W + 31) / 32; p.rw = p.wpr + 2;
+    const size_t per_row = (size_t)p.rw * 4 * 2;                         // both masks
+    const size_t want = lds_budget * 5 / 8;                               // keep 3/8 of the budget for the (position, score) list
+    int bands = 1;
+    while (bands < 64 && (size_t)((H + bands - 1) / bands + 2 * R) * per_row > want) ++bands;
+    p.bands = bands; p.brows = (H + bands - 1) / bands;
+    p.rows = p.brows + 2 * R;
     p.mask_bytes = (size_t)p.rows * p.rw * 4;
     p.list_off = (2 * p.mask_bytes + 15) / 16 * 16;
     p.list_cap = lds_budget > p.list_off ? (int)((lds_budget - p.list_off) / 8) : 0;        // (position, score) per undecided candidate
@@ -354,8 +363,9 @@ constexpr size_t NMS_FIN_LDS = 158 * 1024;
 template <int RT>
 __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float* __restrict__ prob, float* __restrict__ out,
                                                                        const unsigned* __restrict__ und32, const unsigned* __restrict__ kept32,
+                                                                       unsigned* __restrict__ und_out, unsigned* __restrict__ kept_out,
                                                                        int* __restrict__ glist, int H, int W, NmsTable tab, int* __restrict__ counters,
-                                                                       int* __restrict__ info) {
+                                                                       int sweep, int* __restrict__ info) {
     extern __shared__ __align__(16) unsigned char fin_lds[];
     __shared__ int s_n;
     const int R = RT > 0 ? RT : tab.reach;
@@ -363,39 +373,54 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
     const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS);
     unsigned* mU = reinterpret_cast<unsigned*>(fin_lds);                          // undecided (bits cleared as decisions fall)
     unsigned* mK = reinterpret_cast<unsigned*>(fin_lds + pl.mask_bytes);          // kept
-    const int b = blockIdx.x, tid = threadIdx.x;
+    if (sweep > 0 && counters[sweep - 1] == 0) return;                            // banded form: an earlier launch already left nothing undecided
+    const int b = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
     const float* pb = prob + (int64_t)b * H * W;
     float* ob = out + (int64_t)b * H * W;
-    const int wpr = pl.wpr, rw = pl.rw, nwords = H * wpr;
+    const int wpr = pl.wpr, rw = pl.rw;
+    const int yb0 = band * pl.brows, yb1 = min(H, yb0 + pl.brows);                // owned rows; LDS row r <-> image row yb0 - R + r
+    const int nwords = (yb1 - yb0) * wpr;
+    const int64_t img_words = (int64_t)b * H * wpr;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    auto stamp = [&](int slot) { if (tid == 0 && info) info[8 * b + slot] = (int)(__builtin_amdgcn_s_memrealtime() - t_start); };     // 100 MHz ticks (diagnostics)
-    if (b == 0 && tid < NMS_MAX_SWEEPS) counters[tid] = 0;                        // xp_box_nms_check: this form always converges
+    auto stamp = [&](int slot) { if (tid == 0 && info && band == 0) info[8 * b + slot] = (int)(__builtin_amdgcn_s_memrealtime() - t_start); };     // 100 MHz ticks (diagnostics)
     for (int i = tid; i < pl.rows * rw; i += NMS_FIN_THREADS) { mU[i] = 0u; mK[i] = 0u; }
     if (tid == 0) s_n = 0;
     __syncthreads();
+    // halo rows (reach R above and below the band, as the launch found them): read-only neighbours
+    if (pl.bands > 1) {
+        for (int i = tid; i < 2 * R * wpr; i += NMS_FIN_THREADS) {
+            const int h = i / wpr, wi = i - h * wpr;
+            const int r = h < R ? h : (pl.rows - 2 * R + h);                      // LDS rows 0..R-1 and rows-R..rows-1
+            const int y = yb0 - R + r;
+            if (y >= 0 && y < H && !(y >= yb0 && y < yb1)) {
+                mU[r * rw + wi + 1] = und32[img_words + (int64_t)y * wpr + wi];
+                mK[r * rw + wi + 1] = kept32[img_words + (int64_t)y * wpr + wi];
+            }
+        }
+    }
     // masks in; undecided positions into the list (LDS when it fits, else the caller's workspace — same code through a flat pointer)
     int my_count = 0;
     for (int i = tid; i < nwords; i += NMS_FIN_THREADS) {
-        const int y = i / wpr, wi = i - y * wpr;
-        const unsigned u = und32[(int64_t)b * nwords + i];
-        mU[(y + R) * rw + wi + 1] = u;
-        mK[(y + R) * rw + wi + 1] = kept32[(int64_t)b * nwords + i];
+        const int yl = i / wpr, wi = i - yl * wpr;
+        const unsigned u = und32[img_words + (int64_t)(yb0 + yl) * wpr + wi];
+        mU[(yl + R) * rw + wi + 1] = u;
+        mK[(yl + R) * rw + wi + 1] = kept32[img_words + (int64_t)(yb0 + yl) * wpr + wi];
         my_count += __popc(u);
     }
     int my_base = my_count ? atomicAdd(&s_n, my_count) : 0;
     __syncthreads();
     const int total = s_n;
-    const int cap = total <= pl.list_cap ? pl.list_cap : H * W;
-    int* list = total <= pl.list_cap ? reinterpret_cast<int*>(fin_lds + pl.list_off) : glist + (int64_t)b * H * W * 2;
+    const int cap = total <= pl.list_cap ? pl.list_cap : pl.brows * W;
+    int* list = total <= pl.list_cap ? reinterpret_cast<int*>(fin_lds + pl.list_off) : glist + ((int64_t)b * H + yb0) * W * 2;
     float* lscore = reinterpret_cast<float*>(list + cap);
     for (int i = tid; i < nwords; i += NMS_FIN_THREADS) {
-        const int y = i / wpr, wi = i - y * wpr;
-        unsigned u = mU[(y + R) * rw + wi + 1];
+        const int yl = i / wpr, wi = i - yl * wpr;
+        unsigned u = mU[(yl + R) * rw + wi + 1];
         while (u) {
             const int bit = __ffs((int)u) - 1;
             u &= u - 1;
-            lscore[my_base] = pb[(int64_t)y * W + wi * 32 + bit];
-            list[my_base++] = (y << 16) | (wi * 32 + bit);
+            lscore[my_base] = pb[(int64_t)(yb0 + yl) * W + wi * 32 + bit];
+            list[my_base++] = (yl << 16) | (wi * 32 + bit);                     // band-local row
         }
     }
     __syncthreads();
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
     int n_live = total;
     for (int round = 0; round < 1000000; ++round) {
         // entries [0, n_live) are live; this thread's slice is contiguous within the round: e = tid + k * 1024
-        int nkeep = 0;
+        int nkeep = 0, progress = 0;
         int kpos[8]; float ksc[8];                                   // survivors of this thread (at most 8 per round: slices beyond that stay in place, see below)
         const bool small = n_live <= 8 * NMS_FIN_THREADS;
         for (int e = tid; e < n_live; e += NMS_FIN_THREADS) {
@@ -421,7 +446,7 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
             const int wofs = (y + R) * rw + (x >> 5) + 1;
             const unsigned mybit = 1u << (x & 31);
             bool live = (vU[wofs] & mybit) != 0u;
-            if (live && nms_any_in_window<RT>(mK, rw, y + R, x, R, tab)) { atomicAnd(&mU[wofs], ~mybit); live = false; }
+            if (live && nms_any_in_window<RT>(mK, rw, y + R, x, R, tab)) { atomicAnd(&mU[wofs], ~mybit); live = false; progress = 1; }
             if (live) {
                 bool blocked = false;
 #pragma unroll
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
                         const int j = __ffsll((long long)v) - 1;
                         v &= v - 1;
                         const int xx = x - R + j;
-                        const float sq = pb[(int64_t)(y + dy) * W + xx];            // L2-resident heat map (1.2 MB per image)
+                        const float sq = pb[(int64_t)(yb0 + y + dy) * W + xx];      // L2-resident heat map (1.2 MB per image)
                         if (sq > sc || (sq == sc && (dy < 0 || (dy == 0 && xx < x)))) { blocked = true; break; }
                     }
                 }
@@ -445,9 +470,10 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
                         atomicOr(&mK[wofs], mybit);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         atomicAnd(&mU[wofs], ~mybit);
-                        ob[(int64_t)y * W + x] = sc;
+                        ob[(int64_t)(yb0 + y) * W + x] = sc;
                     }
                     live = false;
+                    progress = 1;
                 }
             }
             if (live && small) {
@@ -459,8 +485,12 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
                 nkeep = 1;                                           // large lists are not compacted (they shrink below the limit within a round or two)
             }
         }
+        // banded form: a round without any decision means the rest waits on a neighbouring band — leave it to the next launch.  (One band: the
+        // undecided candidate of highest priority always decides, so every round makes progress.)
+        const int any_progress = __syncthreads_or(progress);
         if (!small) {
             if (!__syncthreads_or(nkeep)) { n_live = 0; break; }
+            if (!any_progress) break;
             continue;
         }
         // compaction: exclusive scan of the per-thread survivor counts (wave ballots + a scan of the 16 wave totals)
@@ -478,9 +508,25 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
         for (int q = 0; q < 8; ++q) if (q < nkeep) { list[base + q] = kpos[q]; lscore[base + q] = ksc[q]; }
         __syncthreads();
         n_live = tot;
-        if (tid == 0 && info) info[8 * b + 2] = round + 1;
-        if (n_live == 0) break;
+        if (tid == 0 && info && band == 0) info[8 * b + 2] = round + 1;
+        if (n_live == 0 || !any_progress) break;
     }
+    if (pl.bands > 1) {
+        // the band's rows of the next masks; a band that leaves something undecided asks for another launch
+        __syncthreads();
+        int left = 0;
+        for (int i = tid; i < nwords; i += NMS_FIN_THREADS) {
+            const int yl = i / wpr, wi = i - yl * wpr;
+            const unsigned u = mU[(yl + R) * rw + wi + 1];
+            und_out[img_words + (int64_t)(yb0 + yl) * wpr + wi] = u;
+            kept_out[img_words + (int64_t)(yb0 + yl) * wpr + wi] = mK[(yl + R) * rw + wi + 1];
+            left |= (u != 0u);
+        }
+        if (__syncthreads_or(left) && tid == 0) atomicAdd(&counters[sweep], 1);
+    } else if (tid < NMS_MAX_SWEEPS && b == 0) {
+        counters[tid] = 0;                                           // xp_box_nms_check: one band always converges inside the launch
+    }
+
     stamp(7);
 }
 
@@ -744,7 +790,7 @@ bool nms_two_launch_applies(int H, int W, int R) {
     static const bool force_sweeps = getenv("XP_NMS_SWEEP") != nullptr && atoi(getenv("XP_NMS_SWEEP")) != 0;     // A/B: the round-1/2 sweep form
     if (force_sweeps || W < 32) return false;
     const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS);
-    return pl.wpr <= 64 && H < 65536 && W < 65536 && pl.list_cap >= 4096;
+    return pl.wpr <= 64 && H < 65536 && W < 65536 && pl.list_cap >= 2048 && pl.bands <= 32;
 }
 }  // namespace
 
@@ -754,8 +800,9 @@ extern "C" size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap) {
 }
 
 // Enqueue `sweeps` sweep launches (each exits at once when the previous one left nothing undecided).
+// band_sweeps: launches of the finisher when an image is split into row bands (ignored for one band)
 static int box_nms_two_launch(const float* prob, float* out, void* workspace, int batch, int H, int W, int cap, const NmsTable& tab, float min_prob,
-                              hipStream_t s) {
+                              int band_sweeps, hipStream_t s) {
     const NmsWs w = nms_ws(workspace, batch, H, W, cap);
     XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
     static bool attr_set = false;
@@ -780,8 +827,14 @@ static int box_nms_two_launch(const float* prob, float* out, void* workspace, in
         if (tab.reach == 6) hipLaunchKernelGGL((nms_round_kernel<6, false>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
         else hipLaunchKernelGGL((nms_round_kernel<0, false>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
     }
-    if (tab.reach == 6) hipLaunchKernelGGL(nms_finish_kernel<6>, dim3(batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], (int*)w.gtab, H, W, tab, w.counters, w.info);
-    else hipLaunchKernelGGL(nms_finish_kernel<0>, dim3(batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], (int*)w.gtab, H, W, tab, w.counters, w.info);
+    const NmsFinishPlan pl = nms_finish_plan(H, W, tab.reach, NMS_FIN_LDS);
+    const int launches = pl.bands > 1 ? (band_sweeps > 0 ? band_sweeps : 1) : 1;
+    if (pl.bands > 1) hipLaunchKernelGGL(nms_reset_counters_kernel, dim3(1), dim3(64), 0, s, w.counters);
+    for (int sw = 0; sw < launches; ++sw, cur ^= 1) {
+        if (tab.reach == 6) hipLaunchKernelGGL(nms_finish_kernel<6>, dim3(pl.bands, batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], (int*)w.gtab, H, W, tab, w.counters, sw, w.info);
+        else hipLaunchKernelGGL(nms_finish_kernel<0>, dim3(pl.bands, batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], (int*)w.gtab, H, W, tab, w.counters, sw, w.info);
+    }
+    if (pl.bands > 1 && launches != NMS_MAX_SWEEPS) hipLaunchKernelGGL(nms_publish_counter_kernel, dim3(1), dim3(64), 0, s, w.counters, launches - 1);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -830,11 +883,16 @@ extern "C" int xp_box_nms(const float* prob, float* out, void* workspace, size_t
     XP_CHECK_ARG(max_sweeps_async <= NMS_MAX_SWEEPS, "xp_box_nms: at most %d async sweeps", NMS_MAX_SWEEPS);
     const NmsWs w = nms_ws(workspace, batch, H, W, cap);
     if (nms_two_launch_applies(H, W, tab.reach)) {
-        // two launches, exact, no sweep count (see nms_localmax_kernel): the same in the stream-ordered and in the synchronous mode
-        int rc = box_nms_two_launch(prob, out, workspace, batch, H, W, cap, tab, min_prob, s);
+        // exact, no sweep count when the image is one band (see nms_localmax_kernel): the same in the stream-ordered and in the synchronous mode.
+        // Images split into row bands repeat the finisher (launches past convergence exit at once): max_sweeps_async of them stream-ordered, or —
+        // synchronous mode — as many as there are counter slots, checked here.
+        int rc = box_nms_two_launch(prob, out, workspace, batch, H, W, cap, tab, min_prob, max_sweeps_async > 0 ? max_sweeps_async : NMS_MAX_SWEEPS, s);
         if (rc) return rc;
         if (max_sweeps_async <= 0) {
+            int left = 0;
+            XP_HIP(hipMemcpyAsync(&left, w.counters + NMS_MAX_SWEEPS - 1, sizeof(int), hipMemcpyDeviceToHost, s));
             XP_HIP(hipStreamSynchronize(s));
+            if (left != 0) { xp_set_error("xp_box_nms: %d row bands still undecided after %d finisher launches", left, NMS_MAX_SWEEPS); return XP_ERR_STATE; }
             if (converged_host) *converged_host = 1;
         }
     } else if (max_sweeps_async > 0) {
