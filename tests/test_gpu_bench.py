@@ -37,6 +37,14 @@ def test_bench_launcher_rccl_world():
     assert all(h["keypoints"] > 8 * 2 * 3000 and h["matches"] > 8 * 500 for h in hdr), hdr
     assert out["value"] > 0 and out["scaling"] == "weak" and out["roofline"]["frac"] > 0
     assert "pcie_inclusive_pairs_per_s" in out
+    # round 3: the K-step region is timed five times and the median reported; every rank's own rate; first vs steady-state weight broadcast
+    tr = out["timed_regions"]
+    assert tr["count"] == 5 and tr["reported"] == "median" and len(tr["pairs_per_s"]) == 5
+    assert sorted(tr["pairs_per_s"])[2] == pytest.approx(out["value"], rel=1e-3)
+    pr = out["per_rank_pairs_per_s"]
+    assert 0 < pr["min"] <= pr["max"] and pr["max"] * world >= out["value"] * 0.99
+    assert out["weight_bcast_first_ms"] > 0
+    assert out["roofline"].get("traffic") or out["roofline"].get("traffic_error")        # a PMC lookup failure is reported, never swallowed
 
 
 def test_bench_launcher_refuses_more_gpus_than_visible():
