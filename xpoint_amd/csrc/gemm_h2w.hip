@@ -67,6 +67,16 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(WParams wp) {
     const int nslab = p.K / H2_BK;                                    // K % 32 == 0 (host)
     const int ntiles = wp.ntiles;
     bool dead = false;
+    // Tile schedule of this (persistent) workgroup.  Workgroup ids go round-robin to the 8 XCDs (one L2 each): every XCD takes ONE contiguous range
+    // of the logical tiles (N-tiles of an M-tile adjacent), and its workgroups walk that range side by side — the column tiles that share a block of
+    // activation rows are in flight together on the same L2.  (With tile = workgroup id + k * grid every workgroup streamed its rows from HBM on its
+    // own: 691 MB per launch at 4.2 TB/s — that, not the producers' instruction count, is what starved the consumers in the first builds.)
+    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;       // gridDim.x is a multiple of 8 (host)
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int t_base = xcd * tq + (xcd < tr ? xcd : tr), t_cnt = tq + (xcd < tr ? 1 : 0);
+    const int my_tiles = wslot < t_cnt ? (t_cnt - wslot + per_xcd - 1) / per_xcd : 0;
+    if (my_tiles == 0) return;
+    auto tile_at = [&](int k) { return t_base + wslot + k * per_xcd; };                        // k-th tile of this workgroup
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
@@ -88,11 +98,10 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(WParams wp) {
         // 5.7 k cycles per slab.)
         constexpr int PFA = 6, PFB = 2;
         float4 ra[PFA][4]; uint4 rb[PFB][4];
-        const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
         const int total = my_tiles * nslab;
         auto tile_of = [&](int q, int& m0, int& n0, int& t) {
             const int k = q / nslab; t = q - k * nslab;
-            const int tile = (int)blockIdx.x + k * (int)gridDim.x;
+            const int tile = tile_at(k);
             const int mt = tile / wp.ntn, nt = tile - mt * wp.ntn;
             m0 = mt * W_BM; n0 = nt * W_BN;
         };
@@ -197,9 +206,10 @@ __global__ __launch_bounds__(512) void gemm_h2w_kernel(WParams wp) {
     wait_full(q);
     read_frags(slot_of(q), 0, f0);
     lds_done();
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int kt = 0; kt < my_tiles; ++kt) {
+        const int tile = tile_at(kt);
         const int mt = tile / wp.ntn, nt = tile - mt * wp.ntn;
-        const bool last_tile = tile + (int)gridDim.x >= ntiles;
+        const bool last_tile = kt + 1 >= my_tiles;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -274,7 +284,8 @@ int xp_gemm_h2w_launch(const GemmParams& p, hipStream_t s) {
     wp.err = err_word;
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; hipDeviceProp_t prop; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev); n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
-    const int grid = wp.ntiles < n_cu ? wp.ntiles : n_cu;
+    int grid = wp.ntiles < n_cu ? (wp.ntiles + 7) / 8 * 8 : n_cu / 8 * 8;     // a multiple of 8: the same number of workgroups on every XCD
+    if (grid < 8) grid = 8;
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     std::string tag = "gemm_h2w_mfma_128x128";
     if (by_shape) tag += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + (p.act == 1 ? "_gelu" : "");
