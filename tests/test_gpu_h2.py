@@ -266,3 +266,34 @@ print("h2w ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XP_H2W="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "h2w ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_gemm_h2p_ping_pong_opt_in(gpu_lib):
+    """csrc/gemm_h2p.hip — the ping-pong schedule of the same split-fp16 GEMM (the two waves of a SIMD alternate between an MFMA-only phase and a
+    fragment-read / split / LDS-store phase; each half of the workgroup accumulates the slabs of one parity) — is opt-in (XP_H2P: faster alone at long K,
+    neutral in the pair step).  Child process with XP_H2P=2 (every K >= 128 it accepts): results within the engine's bar, including ragged
+    M / N edges, an odd number of turns per group (K = 192, 320), GELU and residual epilogues."""
+    import os, subprocess, sys
+    code = r'''
+import ctypes, sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from xpoint_amd import _lib as L, synth
+for (M, N, K, act, res) in [(130, 768, 768, 0, False), (4800, 3072, 768, 1, False), (19200, 384, 1536, 0, True), (200, 200, 768, 0, False), (777, 130, 256, 0, True),
+                            (517, 96, 192, 0, False), (260, 384, 320, 1, True), (129, 129, 128, 0, False)]:
+    A = torch.from_numpy(synth.uniform(f"pA{M}{N}{K}", (M, K), -1, 1)); W = torch.from_numpy(synth.uniform(f"pW{M}{N}{K}", (N, K), -0.1, 0.1))
+    b = torch.from_numpy(synth.uniform(f"pb{M}{N}{K}", (N,), -1, 1)); R = torch.from_numpy(synth.uniform(f"pr{M}{N}{K}", (M, N), -1, 1)) if res else None
+    ref = F.linear(A.double(), W.double(), b.double())
+    if act == 1: ref = F.gelu(ref)
+    if res: ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda(); Rd = R.cuda() if res else None
+    Wx = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device="cuda")
+    L.call("xp_split_weights_h2", L.ptr(Wd), ctypes.c_void_p(Wx.data_ptr()), N, K, L.current_stream())
+    C = torch.full((M + 1, N), 777.0, device="cuda")
+    L.call("xp_gemm_nt_h2", L.ptr(Ad), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C), L.ptr(bd), None, None, L.ptr(Rd), M, N, K, K, N, N, act, L.current_stream())
+    err = float((C[:M].cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), (M, N, K, err)
+    assert bool((C[M] == 777.0).all()), "row past M written"
+print("h2p ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XP_H2P="2"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "h2p ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

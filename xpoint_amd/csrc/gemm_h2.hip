@@ -17,6 +17,8 @@
 // wave-specialised form for long plain GEMMs (gemm_h2w.hip)
 bool xp_gemm_h2w_applies(const GemmParams& p);
 int xp_gemm_h2w_launch(const GemmParams& p, hipStream_t s);
+bool xp_gemm_h2p_applies(const GemmParams& p);      // gemm_h2p.hip: ping-pong schedule of the 128 x 128 tile
+int xp_gemm_h2p_launch(const GemmParams& p, hipStream_t s);
 
 namespace {
 
@@ -284,6 +286,7 @@ int dispatch(const GemmParams& p_in, hipStream_t s) {
         return XP_OK;
     }
     if (sel >= 3 && xp_gemm_h2w_applies(p)) return xp_gemm_h2w_launch(p, s);
+    if (sel >= 3 && xp_gemm_h2p_applies(p)) return xp_gemm_h2p_launch(p, s);
     switch (sel) {
         case 0: launch<4, 1, 1, 1>(p, s); break;       // 128 x 32
         case 1: launch<4, 1, 1, 2>(p, s); break;       // 128 x 64
