@@ -425,7 +425,13 @@ static int layernorm_impl(const float* x, float* y, const float* w, const float*
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
     const int C4 = C / 4;
 #define XP_LN_LAUNCH(LPR, NV) hipLaunchKernelGGL((layernorm_vec_kernel<LPR, NV>), dim3(xp_cdiv(rows, 4 * (64 / LPR))), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu)
+    // the network's widths (96 / 192 / 384 / 768 channels = 24 / 48 / 96 / 192 float4s): LPR x 3 covers the row exactly — every lane active and three
+    // 16-byte loads in flight per lane (C = 96 as 32 lanes x 1 left a quarter of the lanes idle with one load each)
+    static const bool ln3 = !(getenv("XP_LN_OLD") && atoi(getenv("XP_LN_OLD")));
     if (!vec) hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu);
+    else if (ln3 && C4 == 24) XP_LN_LAUNCH(8, 3);
+    else if (ln3 && C4 == 48) XP_LN_LAUNCH(16, 3);
+    else if (ln3 && C4 == 96) XP_LN_LAUNCH(32, 3);
     else if (C4 <= 4) XP_LN_LAUNCH(4, 1);
     else if (C4 <= 8) XP_LN_LAUNCH(8, 1);
     else if (C4 <= 16) XP_LN_LAUNCH(16, 1);
