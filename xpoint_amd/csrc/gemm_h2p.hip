@@ -27,17 +27,10 @@ constexpr int P_ALD = 4, P_BLD = 4;                      // staging slots per th
 #define XP_H2P_DBG 0   /* timing experiments only (wrong results): 1 no MFMA, 2 no staging (split, stores, loads), 4 no fragment reads, 8 no split VALU, 16 no LDS stores after the prologue, 32 no global loads after the prologue */
 #endif
 
-#ifndef XP_H2P_PAIR
-#define XP_H2P_PAIR 0   /* which waves share a SIMD: 0 = w and w + 4, 1 = w and w ^ 1 */
-#endif
-#ifndef XP_H2P_UNI
-#define XP_H2P_UNI 0   /* 1: group index through readfirstlane (provably uniform branch).  Measured 1.5x SLOWER (124 vs 84 us): the register allocation it leads to starves group 0 in both roles */
-#endif
-#ifndef XP_H2P_BUF
-#define XP_H2P_BUF 0   /* 1: buffer loads (descriptor + scalar slab offset) instead of global loads: 93 vs 84 us */
-#endif
-__device__ __forceinline__ int p_grp() { const int wave = XP_H2P_UNI ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6); return XP_H2P_PAIR ? (wave & 1) : (wave >> 2); }     // which group a wave is in
-__device__ __forceinline__ int p_w4() { const int wave = XP_H2P_UNI ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6); return XP_H2P_PAIR ? (wave >> 1) : (wave & 3); }      // its index inside the group
+// Waves w and w + 4 of a workgroup share a SIMD (measured: pairing w with w ^ 1 doubles the MFMA-only time), so group = wave >> 2.  The group index is
+// deliberately NOT passed through readfirstlane: with a provably uniform branch hipcc's register allocation starved group 0 in both roles (124 vs 84 us).
+__device__ __forceinline__ int p_grp() { return (int)(threadIdx.x >> 8); }            // which half of the workgroup a wave is in
+__device__ __forceinline__ int p_w4() { return (int)(threadIdx.x >> 6) & 3; }         // its index inside the half
 
 // what the shared epilogue needs to know: after the exchange every wave holds ONE 32-row block x 64 columns of the tile
 struct PEpiTile {
@@ -99,13 +92,8 @@ __global__ __launch_bounds__(512) void gemm_h2p_kernel(GemmParams p) {
     auto a_quad = [&](int s) { return (t256 + s * 256) & 7; };
     auto b_row = [&](int s) { return (t256 + s * 256) >> 3; };
     auto b_unit = [&](int s) { return (t256 + s * 256) & 7; };
-    // Staging slot s of a thread is slot 0 moved down 32 tile rows (256 threads x 8 quads): ONE lane offset per operand, the slot's displacement is a scalar
-    // (global side: buffer-load soffset) or an immediate (LDS side).  Rows past M / N are not clamped: the descriptor's range check returns zeros past the
-    // end of A, and weight rows past N (the next slab's first rows: finite numbers) only reach output columns that are never stored.
-    const unsigned a_off0 = (unsigned)((m0 + a_row(0)) * p.lda + a_quad(0) * 4) * 4u;          // bytes from p.A (slab 0)
-    const unsigned w_off0 = (unsigned)((n0 + b_row(0)) * H2_SLAB_UNITS + b_unit(0)) * 16u;     // bytes from p.Wt (slab 0)
-    const unsigned a_slot = 32u * (unsigned)p.lda * 4u, w_slot = 32u * H2_SLAB_UNITS * 16u;
-    // plain global loads (the default, XP_H2P_BUF = 0) have no range check: per-slot offsets with rows past M / N clamped to row 0
+    // byte offsets of this thread's staging slots from p.A / p.Wt at slab 0 (rows past M / N clamped to row 0: they only reach outputs that are never stored);
+    // slot s is slot 0 moved down 32 tile rows, so the LDS side needs one address per operand plus immediates
     unsigned a_offc[P_ALD], w_offc[P_BLD];
 #pragma unroll
     for (int s = 0; s < P_ALD; ++s) {
@@ -118,23 +106,14 @@ __global__ __launch_bounds__(512) void gemm_h2p_kernel(GemmParams p) {
     constexpr int kSlotLds = 32 * H2_ROWB;
     const int nslab = p.K / H2_BK;                                                  // K % 64 == 0 (host): whole slabs, an even number of them
     const unsigned w_slab_bytes = (unsigned)p.N * (H2_SLAB_UNITS * 16u);
-    // buffer loads: address = descriptor base + lane offset (one VGPR) + scalar slab offset — no 64-bit address arithmetic, no address registers
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (unsigned)((int64_t)p.M * p.lda * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wt), 0, w_slab_bytes * (unsigned)nslab, 0x00020000);
     auto gload = [&](PRawA& ra, PRawB& rb, int t) {           // slab t; the look-ahead past the last slab re-reads the last one (staged, never multiplied)
         if ((XP_H2P_DBG & (2 | 32)) && t > 5) return;
         const int tc = t < nslab ? t : nslab - 1;
         const unsigned sa = (unsigned)tc * (H2_BK * 4u), sw = (unsigned)tc * w_slab_bytes;      // scalar slab offsets
 #pragma unroll
-        for (int s = 0; s < P_ALD; ++s) {
-            if (XP_H2P_BUF) ra.a[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off0, sa + s * a_slot, 0);
-            else ra.a[s] = *reinterpret_cast<const p_u32x4*>(reinterpret_cast<const char*>(p.A) + ((size_t)a_offc[s] + sa));
-        }
+        for (int s = 0; s < P_ALD; ++s) ra.a[s] = *reinterpret_cast<const p_u32x4*>(reinterpret_cast<const char*>(p.A) + ((size_t)a_offc[s] + sa));
 #pragma unroll
-        for (int s = 0; s < P_BLD; ++s) {
-            if (XP_H2P_BUF) rb.b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off0, sw + s * w_slot, 0);
-            else rb.b[s] = *reinterpret_cast<const p_u32x4*>(reinterpret_cast<const char*>(p.Wt) + ((size_t)w_offc[s] + sw));
-        }
+        for (int s = 0; s < P_BLD; ++s) rb.b[s] = *reinterpret_cast<const p_u32x4*>(reinterpret_cast<const char*>(p.Wt) + ((size_t)w_offc[s] + sw));
     };
     auto stage = [&](const PRawA& ra, const PRawB& rb, unsigned char* buf, bool first = false) {     // split + ds_write of one slab
 #pragma unroll
@@ -172,12 +151,6 @@ __global__ __launch_bounds__(512) void gemm_h2p_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#ifndef XP_H2P_PRIO
-#define XP_H2P_PRIO 1     /* 1: compute phase at s_setprio 1, 2: memory phase at s_setprio 1, 0: none */
-#endif
-#ifndef XP_H2P_ILV
-#define XP_H2P_ILV 0      /* 1: the compute phase's global loads are issued one per MFMA, after the first MFMAs (sched_group_barrier pipeline); 0: all loads first */
-#endif
     auto mfmas = [&](const PFrags& f) {
         if (XP_H2P_DBG & 1) { acc[0][0][0] += (float)f.a[0][0][0][0] * (float)f.b[1][1][1][1]; return; }
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};              // smallest partial products first
@@ -209,25 +182,15 @@ __global__ __launch_bounds__(512) void gemm_h2p_kernel(GemmParams p) {
     if (grp == 0) read_frags(rbuf, fr_);                                 // slab 0
     p_barrier();                                                         // ... before group 1 overwrites buffer 0 with slab 2
     auto memory_phase = [&](PRawA& ra, PRawB& rb) {                      // fragments of this group's next slab, then one staging turn
-        if (XP_H2P_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         if (!(XP_H2P_DBG & 4)) read_frags(rbuf, fr_);
         if (!(XP_H2P_DBG & 2)) stage(ra, rb, wbuf);
-        if (XP_H2P_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     };
-    auto compute_phase = [&](PRawA& ra, PRawB& rb, int t) {              // the 24 MFMAs of the slab in registers; the global loads of slab t ride along
+    // the 24 MFMAs of the slab in registers, the global loads of slab t issued ahead of them.  Measured neutral and left out: s_setprio 1 here (79.6 us) or in
+    // the memory phase (82.1), the loads interleaved one per two MFMAs (80.4), buffer loads with a scalar slab offset (93.2).
+    auto compute_phase = [&](PRawA& ra, PRawB& rb, int t) {
         __builtin_amdgcn_sched_barrier(0);
-        if (XP_H2P_PRIO == 1) __builtin_amdgcn_s_setprio(1);
         gload(ra, rb, t);
         mfmas(fr_);
-        if (XP_H2P_ILV && !(XP_H2P_DBG & (1 | 2 | 32))) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);           // 2 MFMA
-#pragma unroll
-            for (int k = 0; k < P_ALD + P_BLD; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // 1 VMEM read
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // 2 MFMA
-            }
-        }
-        if (XP_H2P_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
     if (grp == 0) {
