@@ -508,7 +508,7 @@ def main():
             "value": round(world * B * args.steps / dt, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (dense layers: f32 operands as 2 fp16 terms = 2^-24 operand error, 3 fp16-MFMA partial products, f32 accumulate — GEMMs, implicit-GEMM "
+            "dtype": ("f32 (dense layers: f32 operands as 2 fp16 terms (operand error <= 2^-23, dropped cross term <= 2^-22: per product <= 2^-21 worst case, ~2^-25 typical), 3 fp16-MFMA partial products, f32 accumulate — GEMMs, implicit-GEMM "
                       "convolutions and the fused block kernels alike; the deep-stage scan's dt projection on the same scheme; all other kernels f32)") if args.gemm == "h2" else
                      ("f32 (dense layers: f32 operands split exactly into 3 bf16 terms, 6 bf16-MFMA partial products, f32 accumulate; "
                       "all other kernels f32)") if args.gemm == "x3" else "f32",

@@ -148,7 +148,7 @@ __device__ __forceinline__ f32x16 mlp_mfma(frag_bits a, frag_bits b, f32x16 c) {
     if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// eight f32 -> operand planes (x3: three exact bf16 planes; h2: two fp16 planes, 2^-24 operand error)
+// eight f32 -> operand planes (x3: three exact bf16 planes; h2: two fp16 planes, operand error <= 2^-23)
 template <bool H2>
 __device__ __forceinline__ void mlp_split8(const float4& lo, const float4& hi, frag_bits (&pl)[3]) {
     if constexpr (H2) {

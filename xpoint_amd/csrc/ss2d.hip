@@ -99,7 +99,7 @@ __device__ __forceinline__ void step_vals(const float* __restrict__ xr, const fl
 
 // ---- dt projection of a 32-pixel tile on the matrix pipe (dt_rank >= 12: the deep stages) ------------------------------------------
 //   dt[pixel][channel] = bias[channel] + sum_r x[pixel][r] Wdt[channel][r]   for the wave's 64 channels: two 32x32 MFMA tiles x ceil(R / 16)
-// slabs, both operands split into two fp16 planes, three products per slab (gemm_h2_core.h: operand error 2^-24 — f32-grade) instead of R
+// slabs, both operands split into two fp16 planes, three products per slab (gemm_h2_core.h: operand error <= 2^-23, per product <= 2^-21 worst / ~2^-25 typical — f32-grade) instead of R
 // FMAs per step and lane.  The weight fragments stay in registers (as many as the R scalar weights they replace), the pixel rows are split
 // from the LDS tile.  The accumulator layout (lane = column = channel, 16 registers = rows {0-3, 8-11, 16-19, 24-27} + 4 (lane >> 5))
 // becomes "lane = channel, 32 registers = the tile's 32 pixels" with one v_permlane32_swap per register pair of the two tiles — the
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan(SS2DParams p, float* __restr
 // tile (64-bit scalar address chains per access, a branchy scalar walk of the pixel order, R FMAs per step).  Here
 //  * the dt projection of a tile runs on the matrix pipe:  dt[pixel][channel] = bias[channel] + sum_r x[pixel][r] Wdt[channel][r]  as two
 //    32x32 MFMA tiles (64 channels) x ceil(R / 16) slabs, both operands split into two fp16 planes, three products per slab
-//    (gemm_h2_core.h: operand error 2^-24 — f32-grade); the weight fragments stay in registers (as many as the R scalar weights they
+//    (gemm_h2_core.h: operand error <= 2^-23 — f32-grade); the weight fragments stay in registers (as many as the R scalar weights they
 //    replace), the pixel rows are split from the LDS tile.  The accumulator layout (lane = column = channel, 16 registers = rows
 //    {0-3, 8-11, 16-19, 24-27} + 4 (lane >> 5)) becomes "lane = channel, 32 registers = the tile's 32 pixels" with one
 //    v_permlane32_swap per register pair of the two tiles — the scan's own layout;
