@@ -171,4 +171,7 @@ def test_c3_shard_rehearsal_ranks_0_to_7(gpu_lib, golden, capsys):
               f"pairs, {tot[3]} differ (explained); {crc_equal} / 56 pairs of ranks 1..7 CRC-identical in all three lists")
         print("\n".join(lines))
     assert tot[1] <= tot[0] // 200 and tot[3] <= tot[2] // 50
+    # hard pins of today's numbers (519 595 keypoints: 6 differ; 79 848 pairs: 8 differ; 50 of 56 pairs CRC-identical): a kernel change that moves a
+    # rounding moves these (an exact-cover LayerNorm lane mapping took the CRC count to 49)
+    assert tot[1] <= 6 and tot[3] <= 8, tot
     assert crc_equal >= 50
