@@ -275,9 +275,13 @@ int xp_xpoint_forward_ex(void* ctx, const float* weights, const void* wsplit, co
  * xp_box_nms replaces xpoint.utils.box_nms (xpoint/utils/utils.py:148-192; torchvision.ops.nms /
  * batched_nms): prob (batch,H,W) -> out (batch,H,W) with surviving scores, zeros elsewhere.
  *   size: box side (multiple of 0.5, <= 16); keep_top_k > 0 keeps the k best survivors per image (needs cap >=
- *   survivors).  max_sweeps_async == 0: iterate to the fixed point, synchronising the stream (like the
- *   reference, which returns a finished tensor); > 0: enqueue that many sweeps and return without
- *   synchronising — verify later with xp_box_nms_check (0 undecided tiles = exact result). */
+ *   survivors).  Exact greedy NMS as a fixed point (round 3): a local-maximum pass, one suppression round and an in-launch finisher per
+ *   image (three launches, NO sweep count) whenever an image fits the finisher's LDS as one band (480 x 640 and smaller); larger images
+ *   (1024 x 1024) are finished band by band and the finisher launch is repeated — launches past convergence exit at once.
+ *   max_sweeps_async == 0: synchronous like the reference (returns a finished tensor; banded images: XP_ERR_STATE if bands are still
+ *   undecided after all counter slots); > 0: stream-ordered, at most that many finisher launches for banded images, no host
+ *   synchronisation — verify later with xp_box_nms_check (0 undecided = exact result; one-band images always are).  Box sizes the
+ *   fixed-point form does not cover fall back to tile sweeps with the same two modes. */
 size_t xp_box_nms_workspace_bytes(int batch, int H, int W, int cap);
 int xp_box_nms(const float* prob, float* out, void* workspace, size_t workspace_bytes, int batch, int H, int W,
                float size, float min_prob, float iou, int keep_top_k, int cap, int max_sweeps_async,
