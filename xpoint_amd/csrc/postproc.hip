@@ -160,21 +160,25 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
 //      host round trip, no sweep count.  Later keepers patch the output sparsely.
 // Images whose masks do not fit LDS (1024 x 1024) keep the sweep form above.
 // ---------------------------------------------------------------------------------------------
+#ifndef XP_NMS_DBG
+#define XP_NMS_DBG 0   /* timing experiments only (wrong results), nms_localmax_kernel: 1 no candidate tests, 2 no out store, 4 no list building, 8 no loads, 16 no window walk */
+#endif
+template <int RT>
 __global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restrict__ prob, float* __restrict__ out, unsigned* __restrict__ cand32,
                                                            unsigned* __restrict__ kept32, int H, int W, int wpr, NmsTable tab, float min_prob) {
     constexpr int TWMAX = NMS_TILE + 2 * NMS_MAXR, THMAX = NMS_TH + 2 * NMS_MAXR;
     __shared__ float s_sc[TWMAX * THMAX];
     __shared__ unsigned long long m_cand[THMAX], m_kept[THMAX];
-    __shared__ unsigned short s_list[NMS_TILE * NMS_TH];
-    __shared__ int s_n;
-    const int R = tab.reach;
+    __shared__ unsigned short s_list[NMS_TILE * NMS_TH], s_surv[NMS_TILE * NMS_TH];
+    __shared__ int s_n, s_m;
+    const int R = RT > 0 ? RT : tab.reach;          // RT > 0: compile-time reach (the window reads below unroll into straight-line code)
     const int TW = NMS_TILE + 2 * R, TH = NMS_TH + 2 * R;
     const int b = blockIdx.z;
     const int y0 = blockIdx.y * NMS_TH - R, x0 = blockIdx.x * NMS_TILE - R;
     const float* pb = prob + (int64_t)b * H * W;
     float* ob = out + (int64_t)b * H * W;
     for (int i = threadIdx.x; i < TH; i += 256) { m_cand[i] = 0ull; m_kept[i] = 0ull; }
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
     __syncthreads();
     // tile + halo, a wave per tile row (lane = column, TW <= 62): the row's candidate mask is one ballot — no LDS atomics on the masks — and the
     // owned candidates of the row take their list slots from ONE atomicAdd per wave and row (popcount prefix inside the wave).  Batches of 8 rows per
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int ty = r0 + 4 * k, y = y0 + ty;
-                v[k] = (ty < TH && xin && y >= 0 && y < H) ? pb[(int64_t)y * W + x] : 0.f;
+                v[k] = (ty < TH && xin && y >= 0 && y < H && !((XP_NMS_DBG & 8) && ty > 2)) ? pb[(int64_t)y * W + x] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restri
                 const unsigned long long m = __ballot(v[k] > min_prob);      // (elements outside the image were loaded as 0 <= min_prob)
                 if (lane == 0) m_cand[ty] = m;
                 const unsigned long long own = (ty >= R && ty < R + NMS_TH) ? (m & own_cols) : 0ull;
-                if (own) {
+                if (own && !(XP_NMS_DBG & 4)) {
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&s_n, __popcll(own));
                     base = __shfl(base, 0, 64);
@@ -209,19 +213,95 @@ __global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restri
         }
     }
     __syncthreads();
-    const int n = s_n;
-    for (int li = threadIdx.x; li < n; li += 256) {
-        const int ty = s_list[li] >> 6, tx = s_list[li] & 63;
+    const int n = (XP_NMS_DBG & 1) ? 0 : s_n;
+    // Phase 1, every candidate: quick reject — the 8 immediate neighbours are inside every overlap window (non-candidates score <= min_prob < sc:
+    // harmless); eight independent LDS reads settle ~8 of 9 candidates.  The survivors are COMPACTED into a second list (one LDS atomic per wave and
+    // batch) before the window walk: walking inside this loop, nearly every wave had a surviving lane and ran the whole data-dependent walk with
+    // one lane in nine active (16 walk batches per tile on the bench's dense maps; now 2).
+    for (int l0 = 0; l0 < n; l0 += 256) {
+        const int li = l0 + threadIdx.x;
+        bool top = li < n;
+        unsigned short item = 0;
+        if (top) {
+            item = s_list[li];
+            if (R >= 1) {
+                const int ty = item >> 6, tx = item & 63;
+                const float sc = s_sc[ty * TW + tx];
+                const float* c = s_sc + ty * TW + tx;
+                const float n0 = c[-TW - 1], n1 = c[-TW], n2 = c[-TW + 1], n3 = c[-1], n4 = c[1], n5 = c[TW - 1], n6 = c[TW], n7 = c[TW + 1];
+                top = !(n0 >= sc || n1 >= sc || n2 >= sc || n3 >= sc || n4 > sc || n5 > sc || n6 > sc || n7 > sc);
+            }
+        }
+        const unsigned long long sv = __ballot(top);
+        if (sv) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_m, __popcll(sv));
+            base = __shfl(base, 0, 64);
+            if (top) s_surv[base + __popcll(sv & ((1ull << lane) - 1ull))] = item;
+        }
+    }
+    __syncthreads();
+    const int m = (XP_NMS_DBG & 16) ? 0 : s_m;
+    // Phases 2 and 3, survivors only: is any pixel of the overlap window AHEAD of this one (higher score, or the same score earlier in row-major order)?
+    if constexpr (RT > 0) {
+        // Compile-time reach: every position of the (2 RT + 1)^2 square is read as a plain score at an immediate offset — straight-line code, all LDS
+        // reads independent and in flight together; whether a position belongs to the overlap window is a uniform bit that masks the comparison, and a
+        // non-candidate can never be ahead (its score <= min_prob < sc).  Phase 2 looks at the 7 x 7 neighbourhood (minus the 3 x 3 already seen) and
+        // compacts again; phase 3 reads the rest of the square for what is left (the true maxima and a few more: about one wave per tile).  The
+        // bit walk below (runtime reach) is a chain of ffs -> dependent LDS read -> compare -> branch, ~130 links for a true maximum, and every wave
+        // holds one: 40 of the kernel's 65 us on the bench's dense maps.
+        auto ahead_in = [&](int ty, int tx, float sc, auto rin_tag, auto rout_tag) {          // positions with RIN < max(|dy|, |dx|) <= ROUT
+            constexpr int RIN = decltype(rin_tag)::value, ROUT = decltype(rout_tag)::value;
+            const float* c = s_sc + ty * (NMS_TILE + 2 * RT) + tx;
+            bool ahead = false;
+#pragma unroll
+            for (int dy = -ROUT; dy <= ROUT; ++dy) {
+                const unsigned long long w = tab.win[dy < 0 ? -dy : dy] >> (RT - ROUT);
+#pragma unroll
+                for (int dx = -ROUT; dx <= ROUT; ++dx) {
+                    if ((dy < 0 ? -dy : dy) <= RIN && (dx < 0 ? -dx : dx) <= RIN) continue;          // compile time
+                    const float sq = c[dy * (NMS_TILE + 2 * RT) + dx];
+                    const bool in = (w >> (dx + ROUT)) & 1ull;                                      // uniform
+                    ahead |= in && ((dy < 0 || (dy == 0 && dx < 0)) ? sq >= sc : sq > sc);
+                }
+            }
+            return ahead;
+        };
+        constexpr int R2 = RT < 3 ? RT : 3;
+        if (threadIdx.x == 0) s_n = 0;                  // reused as the length of the second survivor list (s_list is free again)
+        __syncthreads();
+        for (int l0 = 0; l0 < m; l0 += 256) {
+            const int li = l0 + threadIdx.x;
+            bool top = li < m;
+            unsigned short item = 0;
+            if (top) {
+                item = s_surv[li];
+                const int ty = item >> 6, tx = item & 63;
+                top = !ahead_in(ty, tx, s_sc[ty * TW + tx], std::integral_constant<int, 1>{}, std::integral_constant<int, R2>{});
+            }
+            const unsigned long long sv = __ballot(top);
+            if (sv) {
+                const int lane = threadIdx.x & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_n, __popcll(sv));
+                base = __shfl(base, 0, 64);
+                if (top) s_list[base + __popcll(sv & ((1ull << lane) - 1ull))] = item;
+            }
+        }
+        __syncthreads();
+        const int m2 = s_n;
+        for (int li = threadIdx.x; li < m2; li += 256) {
+            const int ty = s_list[li] >> 6, tx = s_list[li] & 63;
+            if (!ahead_in(ty, tx, s_sc[ty * TW + tx], std::integral_constant<int, R2>{}, std::integral_constant<int, RT>{})) atomicOr(&m_kept[ty], 1ull << tx);
+        }
+    } else {
+    // runtime reach: walk over the candidate bits of the overlap window, early exit
+    for (int li = threadIdx.x; li < m; li += 256) {
+        const int ty = s_surv[li] >> 6, tx = s_surv[li] & 63;
         const float sc = s_sc[ty * TW + tx];
         const int sh = tx - R;
         bool top = true;
-        if (R >= 1) {
-            // quick reject: the 8 immediate neighbours are inside every overlap window (non-candidates score <= min_prob < sc: harmless); eight
-            // independent LDS reads settle ~8 of 9 candidates before the window walk
-            const float* c = s_sc + ty * TW + tx;
-            const float n0 = c[-TW - 1], n1 = c[-TW], n2 = c[-TW + 1], n3 = c[-1], n4 = c[1], n5 = c[TW - 1], n6 = c[TW], n7 = c[TW + 1];
-            top = !(n0 >= sc || n1 >= sc || n2 >= sc || n3 >= sc || n4 > sc || n5 > sc || n6 > sc || n7 > sc);
-        }
         for (int dy = -R; dy <= R && top; ++dy) {
             unsigned long long u = m_cand[ty + dy] & (tab.win[dy < 0 ? -dy : dy] << sh);
             if (dy == 0) u &= ~(1ull << tx);
@@ -234,11 +314,12 @@ __global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restri
         }
         if (top) atomicOr(&m_kept[ty], 1ull << tx);
     }
+    }
     __syncthreads();
     for (int o = threadIdx.x; o < NMS_TILE * NMS_TH; o += 256) {      // NMS_TILE = 32: a wave instruction writes two full 128-byte row segments
         const int ty = R + o / NMS_TILE, tx = R + o % NMS_TILE;
         const int y = y0 + ty, x = x0 + tx;
-        if (y < H && x < W) ob[(int64_t)y * W + x] = ((m_kept[ty] >> tx) & 1ull) ? s_sc[ty * TW + tx] : 0.f;
+        if (y < H && x < W && !((XP_NMS_DBG & 2) && o > 3)) ob[(int64_t)y * W + x] = ((m_kept[ty] >> tx) & 1ull) ? s_sc[ty * TW + tx] : 0.f;
     }
     for (int r = threadIdx.x; r < NMS_TH; r += 256) {
         const int y = y0 + R + r;
@@ -812,7 +893,8 @@ static int box_nms_two_launch(const float* prob, float* out, void* workspace, in
         attr_set = true;
     }
     const int wpr = xp_cdiv(W, 32);
-    hipLaunchKernelGGL(nms_localmax_kernel, dim3(wpr, xp_cdiv(H, NMS_TH), batch), dim3(256), 0, s, prob, out, w.cand32, w.kept32, H, W, wpr, tab, min_prob);
+    if (tab.reach == 6) hipLaunchKernelGGL(nms_localmax_kernel<6>, dim3(wpr, xp_cdiv(H, NMS_TH), batch), dim3(256), 0, s, prob, out, w.cand32, w.kept32, H, W, wpr, tab, min_prob);
+    else hipLaunchKernelGGL(nms_localmax_kernel<0>, dim3(wpr, xp_cdiv(H, NMS_TH), batch), dim3(256), 0, s, prob, out, w.cand32, w.kept32, H, W, wpr, tab, min_prob);
     // wide Jacobi rounds (ping-pong masks), then the per-image finisher for what is left; the count only moves work between the two, never the result
     static const int wide_rounds = getenv("XP_NMS_WIDE_ROUNDS") ? atoi(getenv("XP_NMS_WIDE_ROUNDS")) : 0;
     const size_t mw = (size_t)batch * H * wpr;
