@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const float* __restrict_
 template <int RT>
 __global__ __launch_bounds__(256) void nms_localmax_kernel(const float* __restrict__ prob, float* __restrict__ out, unsigned* __restrict__ cand32,
                                                            unsigned* __restrict__ kept32, int H, int W, int wpr, NmsTable tab, float min_prob) {
-    constexpr int TWMAX = NMS_TILE + 2 * NMS_MAXR, THMAX = NMS_TH + 2 * NMS_MAXR;
+    constexpr int RMAX = RT > 0 ? RT : NMS_MAXR;                     // compile-time reach: the tile image is sized for it (13.4 instead of 15.4 KB at reach 6: 7 instead of 4 workgroups per CU with the lists)
+    constexpr int TWMAX = NMS_TILE + 2 * RMAX, THMAX = NMS_TH + 2 * RMAX;
     __shared__ float s_sc[TWMAX * THMAX];
     __shared__ unsigned long long m_cand[THMAX], m_kept[THMAX];
     __shared__ unsigned short s_list[NMS_TILE * NMS_TH], s_surv[NMS_TILE * NMS_TH];
