@@ -719,6 +719,52 @@ __global__ __launch_bounds__(KP_SEG) void kp_write_kernel(const float* __restric
     if (pos < cap) { int* kb = kp + ((int64_t)b * cap + pos) * 2; kb[0] = (int)(i / W); kb[1] = (int)(i % W); }
 }
 
+// Four pixels per thread (one 16-byte load; H * W % 4 == 0, 16-byte aligned maps): a workgroup covers 4 * KP_SEG pixels.  Same lists, same order: the
+// rank of pixel j of lane l inside its wave = hits of the lanes before l (four ballots) + hits of l's own earlier pixels.
+__device__ __forceinline__ unsigned kp_hit4(const float* __restrict__ pb, const uint8_t* __restrict__ mb, int64_t i, int64_t HW, float thr) {
+    if (i >= HW) return 0u;
+    const float4 v = *reinterpret_cast<const float4*>(pb + i);
+    unsigned h = (v.x > thr ? 1u : 0u) | (v.y > thr ? 2u : 0u) | (v.z > thr ? 4u : 0u) | (v.w > thr ? 8u : 0u);
+    if (mb) {
+        const unsigned m = *reinterpret_cast<const unsigned*>(mb + i);
+        h &= ((m & 0xffu) ? 1u : 0u) | ((m & 0xff00u) ? 2u : 0u) | ((m & 0xff0000u) ? 4u : 0u) | ((m & 0xff000000u) ? 8u : 0u);
+    }
+    return h;
+}
+__global__ __launch_bounds__(KP_SEG) void kp_count4_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask, float thr,
+                                                            int* __restrict__ seg_counts, int64_t HW, int nseg) {
+    __shared__ int s_wave[KP_SEG / 64];
+    const int b = blockIdx.y, seg = blockIdx.x;
+    const int64_t i = ((int64_t)seg * KP_SEG + threadIdx.x) * 4;
+    const unsigned h = kp_hit4(prob + b * HW, mask ? mask + b * HW : nullptr, i, HW, thr);
+    const int c = __popcll(__ballot(h & 1u)) + __popcll(__ballot(h & 2u)) + __popcll(__ballot(h & 4u)) + __popcll(__ballot(h & 8u));
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < KP_SEG / 64; ++w) t += s_wave[w]; seg_counts[b * nseg + seg] = t; }
+}
+__global__ __launch_bounds__(KP_SEG) void kp_write4_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ mask, float thr,
+                                                            const int* __restrict__ seg_offsets, int* __restrict__ kp, int64_t HW, int W,
+                                                            int nseg, int cap) {
+    __shared__ int s_wave[KP_SEG / 64];
+    const int b = blockIdx.y, seg = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)seg * KP_SEG + threadIdx.x) * 4;
+    const unsigned h = kp_hit4(prob + b * HW, mask ? mask + b * HW : nullptr, i, HW, thr);
+    const unsigned long long before = (1ull << lane) - 1ull;
+    const unsigned long long b0 = __ballot(h & 1u), b1 = __ballot(h & 2u), b2 = __ballot(h & 4u), b3 = __ballot(h & 8u);
+    if (lane == 0) s_wave[wave] = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+    __syncthreads();
+    if (!h) return;
+    int pos = seg_offsets[b * nseg + seg] + __popcll(b0 & before) + __popcll(b1 & before) + __popcll(b2 & before) + __popcll(b3 & before);
+    for (int w = 0; w < wave; ++w) pos += s_wave[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((h >> j) & 1u) {
+            if (pos < cap) { int* kb = kp + ((int64_t)b * cap + pos) * 2; kb[0] = (int)((i + j) / W); kb[1] = (int)((i + j) % W); }
+            ++pos;
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Descriptor sampling at keypoints: bilinear grid_sample (zeros padding, align_corners=True) of the
 // NHWC descriptor volume followed by L2 normalisation, in ATen's fp32 operation order so the result
@@ -1033,13 +1079,16 @@ extern "C" int xp_extract_keypoints(const float* prob, const uint8_t* mask, floa
     XP_CHECK_ARG(batch > 0 && cap > 0, "xp_extract_keypoints: bad batch/cap");
     XP_CHECK_ARG(workspace_bytes >= xp_extract_keypoints_workspace_bytes(batch, H, W), "xp_extract_keypoints: workspace too small");
     const int64_t HW = (int64_t)H * W;
-    const int nseg = xp_cdiv(HW, KP_SEG);
     int* seg = (int*)workspace;
     hipStream_t s = (hipStream_t)stream;
     XpProfScope prof("extract_keypoints", s, 0.0, 8.0 * batch * H * W);
-    hipLaunchKernelGGL(kp_count_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, HW, nseg);
+    const bool vec4 = HW % 4 == 0 && (((uintptr_t)prob & 15) == 0) && (!mask || ((uintptr_t)mask & 3) == 0);
+    const int nseg = xp_cdiv(HW, vec4 ? 4 * KP_SEG : KP_SEG);
+    if (vec4) hipLaunchKernelGGL(kp_count4_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, HW, nseg);
+    else hipLaunchKernelGGL(kp_count_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, HW, nseg);
     hipLaunchKernelGGL(kp_scan_kernel, dim3(batch), dim3(1024), 0, s, seg, counts, nseg);
-    hipLaunchKernelGGL(kp_write_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, kp, HW, W, nseg, cap);
+    if (vec4) hipLaunchKernelGGL(kp_write4_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, kp, HW, W, nseg, cap);
+    else hipLaunchKernelGGL(kp_write_kernel, dim3(nseg, batch), dim3(KP_SEG), 0, s, prob, mask, thr, seg, kp, HW, W, nseg, cap);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
