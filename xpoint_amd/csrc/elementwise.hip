@@ -371,6 +371,14 @@ __global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__
     if (i < n) y[i] = x[i] * (m[i] ? 1.f : 0.f);
 }
 
+__global__ __launch_bounds__(256) void mul_mask4_kernel(const float4* __restrict__ x, const unsigned* __restrict__ m, float4* __restrict__ y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = x[i];
+    const unsigned k = m[i];
+    y[i] = make_float4(v.x * ((k & 0xffu) ? 1.f : 0.f), v.y * ((k & 0xff00u) ? 1.f : 0.f), v.z * ((k & 0xff0000u) ? 1.f : 0.f), v.w * ((k & 0xff000000u) ? 1.f : 0.f));
+}
+
 // 2x2 max pool stride 2, NHWC (conv backbones: XPoint.py:451-466, SuperPointMagicLeap.py:42-48).
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
     const int Ho = H / 2, Wo = W / 2;
@@ -595,7 +603,10 @@ extern "C" int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_
     XP_CHECK_ARG(x && mask && y, "xp_mul_mask: null pointer");
     if (n == 0) return XP_OK;
     XpProfScope prof("mul_mask", (hipStream_t)stream, 1.0 * n, 9.0 * n);
-    hipLaunchKernelGGL(mul_mask_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, y, n);
+    if (n % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) && (((uintptr_t)mask & 3) == 0))
+        hipLaunchKernelGGL(mul_mask4_kernel, dim3(xp_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<const unsigned*>(mask), reinterpret_cast<float4*>(y), n / 4);
+    else hipLaunchKernelGGL(mul_mask_kernel, dim3(xp_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, y, n);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
