@@ -54,50 +54,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Vectorised form for C % 4 == 0: LPR lanes (a power of two) share a row, each lane owns NV float4s, so a wave handles
 // 64/LPR rows per pass with 16-byte accesses (C = 96: two rows per wave, 24 of 32 lanes active, instead of one row on
 // 24 scalar lanes).  Same two-pass mean / variance.
-template <int LPR, int NV>
+template <int LPR, int NV, int RPG = 1>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             int64_t M, int C, float eps, int gelu) {
+    // RPG rows per lane group and pass (rows r, r + RPW, ...): RPG x NV independent 16-byte loads in flight per lane; every row's arithmetic — the lane
+    // partial, the xor butterfly, the normalisation — is exactly the RPG = 1 sequence, so the results are bit-identical
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR;
-    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (RPW * RPG) + lane / LPR;
     const int C4 = C >> 2;
-    const bool rok = row < M;
-    const float4* xr = reinterpret_cast<const float4*>(x + (rok ? row : 0) * C);
-    float4 v[NV];
-    float s = 0.f;
+    float4 v[RPG][NV];
+    bool rok[RPG];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = sub + i * LPR;
-        v[i] = (c4 < C4) ? xr[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
+    for (int r = 0; r < RPG; ++r) {
+        const int64_t row = row0 + r * RPW;
+        rok[r] = row < M;
+        const float4* xr = reinterpret_cast<const float4*>(x + (rok[r] ? row : 0) * C);
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if (sub + i * LPR < C4) {
-            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-            q = fmaf(dx, dx, q); q = fmaf(dy, dy, q); q = fmaf(dz, dz, q); q = fmaf(dw, dw, q);
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = sub + i * LPR;
+            v[r][i] = (c4 < C4) ? xr[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = 1.f / sqrtf(q / (float)C + eps);
-    if (!rok) return;
-    float4* yr = reinterpret_cast<float4*>(y + row * C);
+    for (int r = 0; r < RPG; ++r) {
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c4 = sub + i * LPR;
-        if (c4 < C4) {
-            const float4 wv = reinterpret_cast<const float4*>(w)[c4], bv = reinterpret_cast<const float4*>(b)[c4];
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * wv.x + bv.x; o.y = (v[i].y - mean) * rstd * wv.y + bv.y;
-            o.z = (v[i].z - mean) * rstd * wv.z + bv.z; o.w = (v[i].w - mean) * rstd * wv.w + bv.w;
-            if (gelu) { o.x = xp_gelu(o.x); o.y = xp_gelu(o.y); o.z = xp_gelu(o.z); o.w = xp_gelu(o.w); }
-            yr[c4] = o;
+        for (int i = 0; i < NV; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (sub + i * LPR < C4) {
+                const float dx = v[r][i].x - mean, dy = v[r][i].y - mean, dz = v[r][i].z - mean, dw = v[r][i].w - mean;
+                q = fmaf(dx, dx, q); q = fmaf(dy, dy, q); q = fmaf(dz, dz, q); q = fmaf(dw, dw, q);
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.f / sqrtf(q / (float)C + eps);
+        if (!rok[r]) continue;
+        float4* yr = reinterpret_cast<float4*>(y + (row0 + r * RPW) * C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = sub + i * LPR;
+            if (c4 < C4) {
+                const float4 wv = reinterpret_cast<const float4*>(w)[c4], bv = reinterpret_cast<const float4*>(b)[c4];
+                float4 o;
+                o.x = (v[r][i].x - mean) * rstd * wv.x + bv.x; o.y = (v[r][i].y - mean) * rstd * wv.y + bv.y;
+                o.z = (v[r][i].z - mean) * rstd * wv.z + bv.z; o.w = (v[r][i].w - mean) * rstd * wv.w + bv.w;
+                if (gelu) { o.x = xp_gelu(o.x); o.y = xp_gelu(o.y); o.z = xp_gelu(o.z); o.w = xp_gelu(o.w); }
+                yr[c4] = o;
+            }
         }
     }
 }
@@ -451,7 +462,7 @@ static int layernorm_impl(const float* x, float* y, const float* w, const float*
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
     const int C4 = C / 4;
-#define XP_LN_LAUNCH(LPR, NV) hipLaunchKernelGGL((layernorm_vec_kernel<LPR, NV>), dim3(xp_cdiv(rows, 4 * (64 / LPR))), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu)
+#define XP_LN_LAUNCH(LPR, NV) hipLaunchKernelGGL((layernorm_vec_kernel<LPR, NV, (NV == 1 ? 4 : 1)>), dim3(xp_cdiv(rows, 4 * (64 / LPR) * (NV == 1 ? 4 : 1))), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu)
     // XP_LN_COVER=1 (A/B only): for the network's widths (96 / 192 / 384 channels = 24 / 48 / 96 float4s) LPR x 3 covers the row exactly — every lane active,
     // three 16-byte loads in flight per lane: C = 96 54 -> 44 us (5.4 TB/s), 13 us per step in all.  NOT the default: it changes the order of the two row
     // sums, i.e. the last bit of some outputs, and with it WHICH near-tied keypoints / matches agree with the reference run (the C3 rehearsal's
