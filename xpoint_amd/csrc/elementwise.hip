@@ -305,37 +305,49 @@ __global__ __launch_bounds__(256) void depth_to_space_vec_kernel(const float4* _
 // prob[b, r*h+i, r*w+j] = p[b, h, w, r*i+j]   (XPoint.py:356-358).  One wave per cell.
 // mode 1 = SuperPointMagicLeap heat-map: exp(x)/(sum+1e-5), no max subtraction (SuperPointMagicLeap.py:73-74).
 // ---------------------------------------------------------------------------------------------
+constexpr int SMX_CPW = 4;       // cells per wave: the loads of all four are issued first, the four (independent) reductions interleave; per cell the arithmetic is unchanged
 __global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __restrict__ logits, float* __restrict__ prob,
                                                               int B, int Hc, int Wc, int r, int ld, int mode, int* __restrict__ status) {
     const int lane = threadIdx.x & 63;
-    const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= (int64_t)B * Hc * Wc) return;
+    const int64_t cell0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SMX_CPW;
+    const int64_t ncell = (int64_t)B * Hc * Wc;
+    if (cell0 >= ncell) return;
     const int nch = r * r + 1;
-    const float* lp = logits + cell * ld;
-    float v0 = (lane < nch) ? lp[lane] : -INFINITY;
-    float v1 = (lane + 64 < nch) ? lp[lane + 64] : -INFINITY;
-    float e0, e1, inv;
-    if (mode == 0) {
-        const float mx = xp_wave_max(fmaxf(v0, v1));
-        e0 = (lane < nch) ? expf(v0 - mx) : 0.f;
-        e1 = (lane + 64 < nch) ? expf(v1 - mx) : 0.f;
-        inv = 1.f / xp_wave_sum(e0 + e1);
-        e0 *= inv; e1 *= inv;
-        if (status && !(inv <= 1.f) && lane == 0) atomicOr(status, XP_STATUS_PROB);     // a NaN / +-inf logit makes the sum NaN (1 <= sum <= 65 otherwise)
-    } else {
-        e0 = (lane < nch) ? expf(v0) : 0.f;
-        e1 = (lane + 64 < nch) ? expf(v1) : 0.f;
-        const float den = xp_wave_sum(e0 + e1) + 0.00001f;
-        e0 = e0 / den; e1 = e1 / den;
+    float v0[SMX_CPW], v1[SMX_CPW];
+#pragma unroll
+    for (int q = 0; q < SMX_CPW; ++q) {
+        const int64_t cell = cell0 + q < ncell ? cell0 + q : ncell - 1;
+        const float* lp = logits + cell * ld;
+        v0[q] = (lane < nch) ? lp[lane] : -INFINITY;
+        v1[q] = (lane + 64 < nch) ? lp[lane + 64] : -INFINITY;
     }
-    const int w = (int)(cell % Wc), h = (int)((cell / Wc) % Hc);
-    const int64_t b = cell / ((int64_t)Wc * Hc);
-    const int64_t Wf = (int64_t)Wc * r;
-    for (int k = 0; k < 2; ++k) {
-        const int ch = lane + 64 * k;
-        if (ch < r * r) {
-            const int i = ch / r, j = ch - i * r;
-            prob[(b * Hc * r + (h * r + i)) * Wf + (w * r + j)] = k ? e1 : e0;
+#pragma unroll
+    for (int q = 0; q < SMX_CPW; ++q) {
+        const int64_t cell = cell0 + q;
+        if (cell >= ncell) break;                                    // wave-uniform
+        float e0, e1, inv;
+        if (mode == 0) {
+            const float mx = xp_wave_max(fmaxf(v0[q], v1[q]));
+            e0 = (lane < nch) ? expf(v0[q] - mx) : 0.f;
+            e1 = (lane + 64 < nch) ? expf(v1[q] - mx) : 0.f;
+            inv = 1.f / xp_wave_sum(e0 + e1);
+            e0 *= inv; e1 *= inv;
+            if (status && !(inv <= 1.f) && lane == 0) atomicOr(status, XP_STATUS_PROB);     // a NaN / +-inf logit makes the sum NaN (1 <= sum <= 65 otherwise)
+        } else {
+            e0 = (lane < nch) ? expf(v0[q]) : 0.f;
+            e1 = (lane + 64 < nch) ? expf(v1[q]) : 0.f;
+            const float den = xp_wave_sum(e0 + e1) + 0.00001f;
+            e0 = e0 / den; e1 = e1 / den;
+        }
+        const int w = (int)(cell % Wc), h = (int)((cell / Wc) % Hc);
+        const int64_t b = cell / ((int64_t)Wc * Hc);
+        const int64_t Wf = (int64_t)Wc * r;
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < r * r) {
+                const int i = ch / r, j = ch - i * r;
+                prob[(b * Hc * r + (h * r + i)) * Wf + (w * r + j)] = k ? e1 : e0;
+            }
         }
     }
 }
@@ -537,7 +549,7 @@ int xp_softmax_shuffle_st(const float* logits, float* prob, int batch, int Hc, i
     XP_CHECK_ARG(r * r + 1 <= 128 && ld >= r * r + 1, "xp_softmax_shuffle: r*r+1 must be <= 128 and <= ld");
     const int64_t cells = (int64_t)batch * Hc * Wc;
     XpProfScope prof("softmax_shuffle", (hipStream_t)stream, (double)cells * 4.0 * (r * r + 1), 4.0 * cells * (2.0 * r * r + 1));
-    hipLaunchKernelGGL(softmax_shuffle_kernel, dim3(xp_cdiv(cells, 4)), dim3(256), 0, (hipStream_t)stream, logits, prob, batch, Hc, Wc, r, ld, mode, status);
+    hipLaunchKernelGGL(softmax_shuffle_kernel, dim3(xp_cdiv(cells, 4 * SMX_CPW)), dim3(256), 0, (hipStream_t)stream, logits, prob, batch, Hc, Wc, r, ld, mode, status);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
