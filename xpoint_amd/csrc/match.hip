@@ -72,23 +72,27 @@ __global__ __launch_bounds__(256) void match_norms_kernel(const float* __restric
     const int pair = blockIdx.y, side = blockIdx.z;
     const int cap = side ? cap2 : cap1;
     const int n = count_of(cnt, pair * cnt_stride + (side ? which2 : which1), cap);
-    if (blockIdx.x * 16 >= n) return;
+    constexpr int NG = 4;                                          // row groups of four per wave: 16 independent 16-byte loads in flight per lane (was 4:
+                                                                   // 2.0 TB/s); every row's sum is formed exactly as before (lane partial in c order, wave sum)
+    if (blockIdx.x * (16 * NG) >= n) return;
     const int lane = threadIdx.x & 63;
-    const int i0 = blockIdx.x * 16 + (threadIdx.x >> 6) * 4;       // four rows per wave: four independent 16-byte loads in flight per lane
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = lane * 4; c < D; c += 256) {
-        float4 v[4];
+    const int i0 = blockIdx.x * (16 * NG) + (threadIdx.x >> 6) * (4 * NG);
+    float acc4[4 * NG];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 * NG; ++j) acc4[j] = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v[4 * NG];
+#pragma unroll
+        for (int j = 0; j < 4 * NG; ++j) {
             const int i = i0 + j < n ? i0 + j : n - 1;
             v[j] = *reinterpret_cast<const float4*>((side ? d2 : d1) + ((int64_t)pair * cap + i) * D + c);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc4[j] = fmaf(v[j].x, v[j].x, acc4[j]); acc4[j] = fmaf(v[j].y, v[j].y, acc4[j]); acc4[j] = fmaf(v[j].z, v[j].z, acc4[j]); acc4[j] = fmaf(v[j].w, v[j].w, acc4[j]); }
+        for (int j = 0; j < 4 * NG; ++j) { acc4[j] = fmaf(v[j].x, v[j].x, acc4[j]); acc4[j] = fmaf(v[j].y, v[j].y, acc4[j]); acc4[j] = fmaf(v[j].z, v[j].z, acc4[j]); acc4[j] = fmaf(v[j].w, v[j].w, acc4[j]); }
     }
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 * NG; ++j) {
         const float t = xp_wave_sum(acc4[j]);
         if (i0 + j < n) { if (lane == 0) (side ? nb : na)[(int64_t)pair * cap + i0 + j] = t; s = fmaxf(s, t); }
     }
@@ -513,7 +517,7 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     XpProfScope prof("match_mnn", s, 0.0, 0.0);   // work depends on device-side counts: bench.py prices it from the fetched counts
     hipLaunchKernelGGL(match_reset_kernel, dim3(1), dim3(64), 0, s, maxbits);
     const int capmax = cap1 > cap2 ? cap1 : cap2;
-    hipLaunchKernelGGL(match_norms_kernel, dim3(xp_cdiv(capmax, 16), pairs, 2), dim3(256), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D,
+    hipLaunchKernelGGL(match_norms_kernel, dim3(xp_cdiv(capmax, 64), pairs, 2), dim3(256), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D,
                        na, nb, maxbits);
     if (ksd == 4) mt_launch<4>(g, d1, d2, D, pairs, s);
     else if (ksd == 8) mt_launch<8>(g, d1, d2, D, pairs, s);
