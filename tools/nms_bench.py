@@ -14,7 +14,7 @@ ws = torch.zeros(lib.xp_box_nms_workspace_bytes(n, H, W, 8192), dtype=torch.uint
 out = torch.empty_like(prob)
 st = L.current_stream()
 def run():
-    L.check(lib.xp_box_nms(L.ptr(prob), L.ptr(out), L.ptr(ws), ws.numel(), n, H, W, 8.0, 0.015, 0.1, 0, 8192, 8, None, st), "nms")
+    L.check(lib.xp_box_nms(L.ptr(prob), L.ptr(out), L.ptr(ws), ws.numel(), n, H, W, 8.0, 0.015, 0.1, 0, 8192, int(os.environ.get("NMS_SWEEPS", "8")), None, st), "nms")
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
