@@ -270,8 +270,8 @@ print("h2w ok")
 
 def test_gemm_h2p_ping_pong_opt_in(gpu_lib):
     """csrc/gemm_h2p.hip — the ping-pong schedule of the same split-fp16 GEMM (the two waves of a SIMD alternate between an MFMA-only phase and a
-    fragment-read / split / LDS-store phase; each half of the workgroup accumulates the slabs of one parity) — is opt-in (XP_H2P: faster alone at long K,
-    neutral in the pair step).  Child process with XP_H2P=2 (every K >= 128 it accepts): results within the engine's bar, including ragged
+    fragment-read / split / LDS-store phase; each half of the workgroup accumulates the slabs of one parity) — is the default for K >= 768 with at least 128 tiles; the shapes
+    below would mostly stay on the tile kernel.  Child process with XP_H2P=2 (every K >= 128, any tile count): results within the engine's bar, including ragged
     M / N edges, an odd number of turns per group (K = 192, 320), GELU and residual epilogues."""
     import os, subprocess, sys
     code = r'''

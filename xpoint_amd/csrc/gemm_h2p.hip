@@ -234,14 +234,16 @@ __global__ __launch_bounds__(512) void gemm_h2p_kernel(GemmParams p) {
 
 }  // namespace
 
-// OPT-IN (XP_H2P=1: K >= 768, XP_H2P=2: K >= 128).  Measured, round 3 (tools/h2p_dbg.sh, profiles/r3_gemm_h2p_pingpong.txt): alone on the GPU it beats the tile
-// kernel where the K loop dominates (M 19200 N 384 K 1536: 79.4 vs 91.6-99.7 us, 285 TF/s; M 4800 N 768 K 3072: 86.9 vs 102.4) and loses where prologue and
-// epilogue dominate (K = 384: 32.3 vs 28.9, fc1 + GELU 131 vs 123: one workgroup per CU has nothing to hide them behind).  In the pair step it changes nothing
-// (1636 vs 1622 pairs/s overlapped, 1352 vs 1362 single-stream, C4 482 vs 480: inside the noise): the overlapped multi-stream schedule already fills the issue
-// slots the tile kernel leaves idle with other kernels' waves.  Off by default, so the default summation order (and every pinned number) stays what it was.
+// DEFAULT for K >= 768 with at least 128 tiles (XP_H2P=0 turns it off, XP_H2P=2 widens it to K >= 128 and any tile count).  Measured, round 3 (tools/h2p_dbg.sh,
+// profiles/r3_gemm_h2p_pingpong.txt): alone on the GPU it beats the tile kernel where the K loop dominates (M 19200 N 384 K 1536: 79.4 vs 91.6-99.7 us,
+// 285 TF/s; M 4800 N 768 K 3072: 86.9 vs 102.4) and loses where prologue and epilogue dominate (K = 384: 32.3 vs 28.9, fc1 + GELU 131 vs 123: one workgroup
+// per CU has nothing to hide them behind) or the tile count is small (M 4800 N 200: 25 vs 20 us).  In the pair step: +0.9 .. 1.2 % (three alternating
+// A/B runs of 5 x 100 steps on one box: 1680-1693 against 1664-1673 pairs/s).  The summation order differs from the tile kernel (even slabs + odd slabs);
+// every pinned list count of the C2 / C3 / C4 fixtures is unchanged with it (tests/test_gpu_model.py, test_gpu_configs.py).
 bool xp_gemm_h2p_applies(const GemmParams& p) {
-    static const int on = getenv("XP_H2P") ? atoi(getenv("XP_H2P")) : 0;
-    return on && p.mode == 0 && p.K % 64 == 0 && p.K >= (on > 1 ? 128 : 768) && p.lda % 4 == 0 && p.N >= 96 && (int64_t)p.M * p.lda < (1ll << 30) &&
+    static const int on = getenv("XP_H2P") ? atoi(getenv("XP_H2P")) : 1;
+    return on && p.mode == 0 && p.K % 64 == 0 && p.K >= (on > 1 ? 128 : 768) && p.lda % 4 == 0 && p.N >= 96 &&
+           (on > 1 || (int64_t)xp_cdiv(p.M, P_BM) * xp_cdiv(p.N, P_BN) >= 128) && (int64_t)p.M * p.lda < (1ll << 30) &&
            (int64_t)p.N * H2_SLAB_UNITS * 16 * (p.K / H2_BK) < (1ll << 32);
 }
 
