@@ -109,6 +109,9 @@ def pmc_kernel_for_tag(tag, names):
             raise KeyError(f"unrecognised fused-kernel tag {tag!r}")
         mode = {"mlp_fused": 0, "proj_mlp_fused": 1, "ln_proj": 2}[m.group(1)]
         pat = re.compile(rf"mlp_fused_kernel<{m.group(3)}, \d+, {mode}, \d+, {'true' if m.group(2) == 'h2' else 'false'}>$")
+    elif tag.startswith(("gemm_h2p", "gemm_h2w")):
+        # ping-pong / wave-specialised schedules of the split-fp16 GEMM: one (non-template) kernel each
+        pat = re.compile(rf"{tag.split('_mfma_')[0]}_kernel$")
     elif tag.startswith(("gemm", "conv3x3")):
         m = re.match(r"(gemm|conv3x3)(_h2r|_h2|_x3|)_mfma_(\d+)x(\d+)$", tag)
         if not m:
@@ -451,7 +454,7 @@ def main():
         avg_s = dom["ms"] / max(dom["launches"], 1) * 1e-3
         if dom["flops"] > 0 and dominant.startswith(("gemm", "conv3x3", "mlp_fused", "proj_mlp_fused")):
             ach = dom["flops"] / dom["launches"] / avg_s / 1e12
-            x3 = "_x3" in dominant or "_h2" in dominant
+            x3 = "_x3" in dominant or "_h2" in dominant          # ("_h2" also matches the _h2r / _h2p / _h2w schedules: same three-product arithmetic)
             nprod = H2_PRODUCTS if "_h2" in dominant else X3_PRODUCTS
             # split kernels: algorithmic (f32-equivalent) 2MNK flops against the 16-bit dense MFMA peak / partial products per multiply
             peak = MFMA_BF16_PEAK_TFLOPS / nprod if x3 else MFMA_F32_PEAK_TFLOPS
