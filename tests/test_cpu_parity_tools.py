@@ -206,3 +206,25 @@ def test_oracle_amp16_recipe_vs_reference_taps(golden):
         e_amp = float(np.abs(o[k].numpy() - ref).max()); e_f32 = float(np.abs(o32[k].numpy() - ref).max())
         assert e_amp < 3.0 * e_f32 + 1e-3, (k, e_amp, e_f32)          # same noise level as the recipe's own distance from f32
     assert torch.equal(o["encoder_output"], o["encoder_output"].half().float())
+
+
+def test_bench_pmc_lookup_covers_the_committed_counter_files():
+    """bench.py maps the library's HIP-event tags to the kernel names of the committed rocprofv3 PMC summaries (profiles/pmc_traffic.json,
+    pmc_mfma.json) for roofline.traffic / frac_mfma_busy_pmc: every tag that can become the dominant kernel of a bench line must resolve to exactly
+    one kernel of the committed files (a renamed template or a new schedule would otherwise surface as traffic_error in the driver's line)."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)          # bench.py imports no torch at module level (the launcher parent must stay GPU-free)
+    for fn in ("pmc_traffic.json", "pmc_mfma.json"):
+        names = list(json.load(open(os.path.join(root, "profiles", fn)))["kernels"])
+        for tag in ("gemm_h2p_mfma_128x128", "gemm_h2_mfma_128x128", "gemm_h2_mfma_64x128", "proj_mlp_fused_h2_c192", "proj_mlp_fused_h2_c96",
+                    "conv3x3_h2r_mfma_128x96", "conv3x3_h2r_mfma_128x128"):
+            assert bench.pmc_kernel_for_tag(tag, names) in names, (fn, tag)
+    names = list(json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["kernels"])
+    for tag in ("ss2d_pass2", "dwconv3x3_silu", "layernorm"):          # HBM-bound tags: traffic file only
+        try:
+            bench.pmc_kernel_for_tag(tag, names)
+        except KeyError as e:               # several template instances share a tag (ss2d passes, layernorm widths): reported, not swallowed
+            assert "matches" in str(e)
