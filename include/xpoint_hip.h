@@ -56,6 +56,24 @@ int xp_selective_scan_fwd_typed(const void* u, const void* delta, const float* A
                                 const float* delta_bias, void* out, float* x_chunks, int itype, int out_float, int batch, int dim,
                                 int delta_dim, int seqlen, int dstate, int ngroups, int delta_softplus, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Stand-alone four-route cross scan / cross merge.  Replace `cross_scan_fn` / `cross_merge_fn`
+ * (xpoint/models/vmamba_src/csm_triton.py:501-517; torch forms cross_scan_fwd :22-53, cross_merge_fwd :56-85, one_by_one forms :88-180;
+ * Triton kernel triton_cross_scan_flex :278-400) for the operator-level drop-in; the fused encoder never materialises the routes
+ * (xp_ss2d_core_fwd below).  dtype 0 / 1 / 2 = float32 / float16 / bfloat16 elements.
+ *   scans 0: routes row-major, column-major and their reverses; 1: four copies of the row-major route; 2: row-major twice, reversed twice.
+ *   xp_cross_scan:  x (B,C,H,W) if in_channel_first else (B,H,W,C)  [one_by_one: (B,4,C,H,W) / (B,H,W,4,C), route k reads its own slice]
+ *                   -> y (B,4,C,H*W) if out_channel_first else (B,H*W,4,C).
+ *   xp_cross_merge: ys in the scan's OUT layout ((B,4,C,H*W) if out_channel_first else (B,H*W,4,C)) -> out in the scan's IN layout
+ *                   ((B,C,H*W) if in_channel_first else (B,H*W,C)): (ys0 + ys2) + (ys1 + ys3) at every pixel, each add rounded to the dtype
+ *                   (scans 1: ((ys0 + ys1) + ys2) + ys3 in a float32 accumulator, one rounding — torch's `sum(1)`);
+ *                   one_by_one: the inverse permutation per route -> (B,4,C,H*W) / (B,H*W,4,C), no adds.
+ * Bit-exact against the reference functions on random data (tests/golden/g22_cross_scan_ops.npz), incl. its own check shape (27,253,57,58). */
+int xp_cross_scan(const void* x, void* y, int dtype, int B, int C, int H, int W, int in_channel_first, int out_channel_first,
+                  int one_by_one, int scans, void* stream);
+int xp_cross_merge(const void* ys, void* out, int dtype, int B, int C, int H, int W, int in_channel_first, int out_channel_first,
+                   int one_by_one, int scans, void* stream);
+
 /* Fused SS2D core in pixel layout = cross_scan + dt_proj + selective_scan + cross_merge + out_norm of
  * xpoint/models/vmamba_src/VMamba.py:601-646 (forward_corev2) with csm_triton.py:22-85 (cross scan/merge).
  *   u (batch, H, W, C) = SiLU(dwconv(in_proj(x)));  xdbl (batch*H*W, 4*(R+2)) = u @ x_proj^T with the four
@@ -117,10 +135,6 @@ int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const float* bias, 
                   const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
 int xp_conv3x3_nhwc_h2(const float* x, const void* Wh2, float* y, const float* bias, const float* scale, const float* shift,
                        int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
-/* xp_gemm_nt_h2 runs long plain GEMMs (K a multiple of 64, >= 256; N >= 96) on a wave-specialised kernel (csrc/gemm_h2w.hip: producer waves
- * fill an LDS ring, consumer waves multiply; hand-offs through counters in LDS with BOUNDED waits).  A wait that runs out sets a device word instead
- * of hanging; this returns it (0 = never happened, 1 = some launch of this process produced wrong numbers, -1 = query failed).  Synchronises. */
-int xp_gemm_h2w_error(void);
 /* Precision class of the "x3" kernels (xp_gemm_nt_x3, xp_conv3x3_nhwc_x3, xp_mlp_fused_x3 and every dense layer of
  * xp_xpoint_forward with wsplit != NULL), process-wide, read at launch time:
  *   6 (default)  all six partial products of weight >= 2^-16: f32-grade (the class pinned against the reference, 1e-4 bar)

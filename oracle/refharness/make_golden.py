@@ -576,6 +576,75 @@ def main():
     print(json.dumps(manifest, indent=1))
 
 
+def g22_inputs(shape, dtype=torch.float32):
+    """Seeded inputs of G22 in channel-first form: x (B,C,H,W), x4 / ys (B,4,C,H,W)."""
+    B, C, H, W = shape
+    tag = "g22/%dx%dx%dx%d" % shape
+    x = torch.from_numpy(synth.uniform(tag + "/x", (B, C, H, W), -1, 1)).to(dtype)
+    x4 = torch.from_numpy(synth.uniform(tag + "/x4", (B, 4, C, H, W), -1, 1)).to(dtype)
+    return x, x4
+
+
+def gen_g22():
+    """G22 — the stand-alone cross-scan / cross-merge operators through the REAL reference entry points `cross_scan_fn` / `cross_merge_fn`
+    (csm_triton.py:501-517; on CPU they dispatch to CrossScanF / CrossMergeF = cross_scan_fwd / cross_merge_fwd / the one_by_one forms, :22-190):
+    all four in/out channel layouts x scans {0, 1, 2} x one_by_one {False, True} on RANDOM data (so the association of the merge adds is pinned
+    bit for bit, incl. `y.sum(1)` of scans 1), float32 / float16 / bfloat16.  (2,3,5,7): full outputs; (1,2,33,58) — H, W not multiples of the tile —:
+    crc32 + head; the reference's own exact-equality check shape (27,253,57,58) (csm_triton.py:670): crc32 of the model's layouts.
+    Not generated: one_by_one + channel-last + scans 2, where the reference indexes the wrong axis (`x[:, 0].flatten(1, 2)` on a (B,H,W,4,C)
+    tensor, csm_triton.py:118-123), and one_by_one + channel-first in + channel-last out + scans 1, where its `x.flatten(2, 3)` yields (B,4,C H,W) and the
+    following permute scrambles it (:103, :125-126; with channel-first out the same call is byte-identical to (B,4,C,L) and IS in the fixture)."""
+    import zlib
+    torch.set_num_threads(1)
+    stubs.install()
+    from xpoint.models.vmamba_src import csm_triton
+    g = {}
+    names = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}
+
+    def store(key, t, full):
+        a = t.contiguous().view(torch.int16).numpy() if t.dtype in (torch.float16, torch.bfloat16) else t.contiguous().numpy()
+        if full:
+            g[key] = a
+        else:
+            g[key + "/crc"] = np.array([zlib.crc32(a.tobytes()), a.size], dtype=np.int64)
+            g[key + "/head"] = a.reshape(-1)[:16].copy()
+
+    for shape, dtypes, combos in [((2, 3, 5, 7), (torch.float32, torch.float16, torch.bfloat16), "all"),
+                                  ((1, 2, 33, 58), (torch.float32, torch.float16), "all"),
+                                  ((27, 253, 57, 58), (torch.float32,), "model")]:
+        B, C, H, W = shape
+        tag = "%dx%dx%dx%d" % shape
+        full = shape == (2, 3, 5, 7)
+        for dt in dtypes:
+            x, x4 = g22_inputs(shape, dt)
+            for icf in (True, False):
+                for ocf in (True, False):
+                    if combos == "model" and icf != ocf:
+                        continue
+                    for scans in (0, 1, 2):
+                        for obo in (False, True):
+                            if combos == "model" and (scans != 0 or obo):
+                                continue
+                            if obo and not icf and scans == 2:
+                                continue
+                            if obo and icf and not ocf and scans == 1:
+                                continue      # reference: `x.flatten(2, 3)` of (B,4,C,H,W) is (B,4,C H,W); its channel-last permute is then not a scan at all (:103,125-126)
+                            kw = dict(in_channel_first=icf, out_channel_first=ocf, one_by_one=obo, scans=scans)
+                            key = f"{tag}/in{int(icf)}out{int(ocf)}/obo{int(obo)}/s{scans}/{names[dt]}"
+                            src = x4 if obo else x
+                            if not icf:
+                                src = (src.permute(0, 3, 4, 1, 2) if obo else src.permute(0, 2, 3, 1)).contiguous()
+                            ys = csm_triton.cross_scan_fn(src, **kw)
+                            store(key + "/scan", ys, full)
+                            # merge input: the seeded (B,4,C,H,W) tensor in the scan's OUT layout
+                            yin = x4 if ocf else x4.permute(0, 3, 4, 1, 2).contiguous()
+                            out = csm_triton.cross_merge_fn(yin, **kw)
+                            store(key + "/merge", out, full)
+        print("g22", shape, "done", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g22_cross_scan_ops.npz"), **g)
+    print("g22 keys", len(g))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # one generator: python -m oracle.refharness.make_golden g18part 8 22 /tmp/g18_a.npz | g18merge a.npz b.npz | g19 ...
         cmd, rest = sys.argv[1], sys.argv[2:]

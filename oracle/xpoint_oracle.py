@@ -90,6 +90,59 @@ def cross_merge(ys):
     return y                                                      # (B, D, H*W)
 
 
+def _route_pixels(k, scans, H, W):
+    """pixel index (h W + w) visited at position l of route k — csm_triton.py:22-53: scans 0: k = 0 row-major, 1 column-major, 2 / 3 their
+    reverses; scans 1: four copies of route 0; scans 2: 0, 1 forward, 2, 3 reversed."""
+    import numpy as np
+    L = H * W
+    transposed = scans == 0 and (k & 1)
+    flipped = scans != 1 and (k >> 1)
+    l = np.arange(L)
+    lp = L - 1 - l if flipped else l
+    return ((lp % H) * W + lp // H) if transposed else lp
+
+
+def cross_scan_op(x, in_channel_first=True, out_channel_first=True, one_by_one=False, scans=0):
+    """Index-table restatement of reference cross_scan_fn (csm_triton.py:501-507 -> cross_scan_fwd :22-53 / cross_scan1b1_fwd :88-131) for every
+    layout: x (B,C,H,W) | (B,H,W,C) | (B,4,C,H,W) | (B,H,W,4,C) -> (B,4,C,L) | (B,L,4,C).  A pure permutation: any dtype."""
+    import numpy as np
+    if one_by_one:
+        xc = x if in_channel_first else x.permute(0, 3, 4, 1, 2)           # (B,4,C,H,W)
+        B, _, C, H, W = xc.shape
+        flat = xc.reshape(B, 4, C, H * W)
+        y = torch.stack([flat[:, k][..., torch.from_numpy(_route_pixels(k, scans, H, W))] for k in range(4)], dim=1)
+    else:
+        xc = x if in_channel_first else x.permute(0, 3, 1, 2)              # (B,C,H,W)
+        B, C, H, W = xc.shape
+        flat = xc.reshape(B, C, H * W)
+        y = torch.stack([flat[..., torch.from_numpy(_route_pixels(k, scans, H, W))] for k in range(4)], dim=1)
+    return y.contiguous() if out_channel_first else y.permute(0, 3, 1, 2).contiguous()
+
+
+def cross_merge_op(ys, in_channel_first=True, out_channel_first=True, one_by_one=False, scans=0):
+    """Restatement of reference cross_merge_fn (csm_triton.py:511-517 -> cross_merge_fwd :56-85 / cross_merge1b1_fwd :134-180): ys (B,4,C,H,W) if
+    out_channel_first else (B,H,W,4,C); result in the scan's IN layout.  Adds in the tensor's dtype, associated as the reference does:
+    (y0 + y2) + (y1 + y3) for scans 0 / 2 (every add rounded to the dtype), ((y0 + y1) + y2) + y3 for scans 1 (`y.sum(1)`: float32 accumulator, one rounding)."""
+    import numpy as np
+    yc = ys if out_channel_first else ys.permute(0, 3, 4, 1, 2)            # (B,4,C,H,W)
+    B, _, C, H, W = yc.shape
+    flat = yc.reshape(B, 4, C, H * W)
+    back = []
+    for k in range(4):
+        pix = _route_pixels(k, scans, H, W)
+        inv = np.empty_like(pix); inv[pix] = np.arange(H * W)              # position of every pixel in route k
+        back.append(flat[:, k][..., torch.from_numpy(inv)])
+    if one_by_one:
+        out = torch.stack(back, dim=1)                                     # (B,4,C,L)
+        return out.contiguous() if in_channel_first else out.permute(0, 3, 1, 2).contiguous()
+    if scans == 1:      # torch's sum accumulates 16-bit inputs in float32 and rounds once
+        f = [b.float() for b in back]
+        out = (((f[0] + f[1]) + f[2]) + f[3]).to(ys.dtype)
+    else:
+        out = (back[0] + back[2]) + (back[1] + back[3])
+    return out.contiguous() if in_channel_first else out.permute(0, 2, 1).contiguous()
+
+
 # ------------------------------------------------------------------------------------------
 # SS2D (forward_type v05_noz)                          reference VMamba.py:493-664
 # ------------------------------------------------------------------------------------------

@@ -241,45 +241,18 @@ def test_h2_adversarial_midpoints(gpu_lib, case, capsys):
     assert out["x3"] <= 2.0 ** -23 + out["f32"], out                  # six products on exact planes: accumulation error only
 
 
-def test_gemm_h2w_wave_specialised_opt_in(gpu_lib):
-    """csrc/gemm_h2w.hip — the wave-specialised schedule of the same split-fp16 GEMM (producer waves fill an LDS ring, consumer waves multiply; hand-offs
-    through LDS counters with BOUNDED waits) — is opt-in (XP_H2W=1: it is slower than the tile kernel).  Run in a child process with the
-    switch on: results within the engine's bar on the shapes it takes, and no hand-off ever timed out (xp_gemm_h2w_error() == 0)."""
-    import os, subprocess, sys
-    code = r'''
-import ctypes, sys, torch, torch.nn.functional as F
-sys.path.insert(0, %r)
-from xpoint_amd import _lib as L, synth
-for (M, N, K, res) in [(130, 768, 768, False), (4800, 3072, 768, False), (19200, 384, 1536, True), (200, 200, 768, False), (777, 130, 256, True)]:
-    A = torch.from_numpy(synth.uniform(f"wA{M}{N}{K}", (M, K), -1, 1)); W = torch.from_numpy(synth.uniform(f"wW{M}{N}{K}", (N, K), -0.1, 0.1))
-    b = torch.from_numpy(synth.uniform(f"wb{M}{N}{K}", (N,), -1, 1)); R = torch.from_numpy(synth.uniform(f"wr{M}{N}{K}", (M, N), -1, 1)) if res else None
-    ref = F.linear(A.double(), W.double(), b.double()) + (R.double() if res else 0)
-    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda(); Rd = R.cuda() if res else None
-    Wx = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device="cuda")
-    L.call("xp_split_weights_h2", L.ptr(Wd), ctypes.c_void_p(Wx.data_ptr()), N, K, L.current_stream())
-    C = torch.empty((M, N), device="cuda")
-    L.call("xp_gemm_nt_h2", L.ptr(Ad), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C), L.ptr(bd), None, None, L.ptr(Rd), M, N, K, K, N, N, 0, L.current_stream())
-    err = float((C.cpu().double() - ref).abs().max())
-    assert err < 2e-5 * max(1.0, float(ref.abs().max())), (M, N, K, err)
-assert L.load().xp_gemm_h2w_error() == 0
-print("h2w ok")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XP_H2W="1"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "h2w ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
-
-
-def test_gemm_h2p_ping_pong_opt_in(gpu_lib):
+def test_gemm_h2p_ping_pong_widened(gpu_lib):
     """csrc/gemm_h2p.hip — the ping-pong schedule of the same split-fp16 GEMM (the two waves of a SIMD alternate between an MFMA-only phase and a
-    fragment-read / split / LDS-store phase; each half of the workgroup accumulates the slabs of one parity) — is the default for K >= 768 with at least 128 tiles (DESIGN.md §5); the shapes
-    below would mostly stay on the tile kernel.  Child process with XP_H2P=2 (every K >= 128, any tile count): results within the engine's bar, including ragged
-    M / N edges, an odd number of turns per group (K = 192, 320), GELU and residual epilogues."""
+    fragment-read / split / LDS-store phase; each half of the workgroup accumulates the slabs of one parity) — is the default for K >= 768 and N >= 384
+    (a per-layer predicate: DESIGN.md §5; test_gemm_h2p_default_path below runs it as shipped).  Here a child process with XP_H2P=2 widens it to every K >= 128,
+    N >= 96 so that ragged M / N edges, an odd number of turns per group (K = 192, 320), GELU and residual epilogues reach it too."""
     import os, subprocess, sys
     code = r'''
 import ctypes, sys, torch, torch.nn.functional as F
 sys.path.insert(0, %r)
 from xpoint_amd import _lib as L, synth
 for (M, N, K, act, res) in [(130, 768, 768, 0, False), (4800, 3072, 768, 1, False), (19200, 384, 1536, 0, True), (200, 200, 768, 0, False), (777, 130, 256, 0, True),
-                            (517, 96, 192, 0, False), (260, 384, 320, 1, True), (129, 129, 128, 0, False)]:
+                            (517, 384, 192, 0, False), (260, 384, 320, 1, True), (129, 129, 128, 0, False)]:
     A = torch.from_numpy(synth.uniform(f"pA{M}{N}{K}", (M, K), -1, 1)); W = torch.from_numpy(synth.uniform(f"pW{M}{N}{K}", (N, K), -0.1, 0.1))
     b = torch.from_numpy(synth.uniform(f"pb{M}{N}{K}", (N,), -1, 1)); R = torch.from_numpy(synth.uniform(f"pr{M}{N}{K}", (M, N), -1, 1)) if res else None
     ref = F.linear(A.double(), W.double(), b.double())
@@ -297,3 +270,28 @@ print("h2p ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XP_H2P="2"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "h2p ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_gemm_h2p_default_path(gpu_lib):
+    """The shipped dispatch: K >= 768 and N >= 384 take the ping-pong kernel at EVERY M (the predicate is per layer, never per batch), so the rows of a
+    small-M call must equal, bit for bit, the same rows inside a large-M call — the kernel-level form of batch invariance."""
+    L = _lib()
+    for (N, K, act) in [(768, 768, 0), (3072, 768, 1), (384, 1536, 0), (768, 3072, 0)]:
+        M = 4800
+        A = torch.from_numpy(synth.uniform(f"dA{N}{K}", (M, K), -1, 1)); W = torch.from_numpy(synth.uniform(f"dW{N}{K}", (N, K), -0.1, 0.1))
+        b = torch.from_numpy(synth.uniform(f"db{N}{K}", (N,), -1, 1))
+        ref = F.linear(A.double(), W.double(), b.double())
+        if act == 1:
+            ref = F.gelu(ref)
+        Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+        Wx = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device="cuda")
+        L.call("xp_split_weights_h2", L.ptr(Wd), ctypes.c_void_p(Wx.data_ptr()), N, K, L.current_stream())
+        out = {}
+        for m in (M, 600, 300, 37):
+            C = torch.empty((m, N), device="cuda")
+            L.call("xp_gemm_nt_h2", L.ptr(Ad), ctypes.c_void_p(Wx.data_ptr()), L.ptr(C), L.ptr(bd), None, None, None, m, N, K, K, N, N, act, L.current_stream())
+            out[m] = C
+        err = float((out[M].cpu().double() - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), (N, K, err)
+        for m in (600, 300, 37):
+            assert torch.equal(out[m], out[M][:m]), (N, K, m)

@@ -700,3 +700,35 @@ def test_match_adversarial_low_dim_sparse_near_ties(gpu_lib, D):
     nm = int(res["match_count"][0])
     assert nm == len(q) and np.array_equal(res["match_q"][0, :nm].cpu().numpy(), q) and np.array_equal(res["match_t"][0, :nm].cpu().numpy(), idx12[q])
     assert float(np.min(gap12[::7])) < 1e-3            # the traps are near-ties on the fp16 scale
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone cross scan / merge (a7)
+def test_cross_scan_merge_ops_vs_reference_g22(gpu_lib, golden, capsys):
+    """kernels.cross_scan_fn / cross_merge_fn (xp_cross_scan / xp_cross_merge) == the REAL reference's cross_scan_fn / cross_merge_fn
+    (csm_triton.py:501-517; fixture g22) bit for bit: all four channel layouts x scans {0, 1, 2} x one_by_one x {f32, f16, bf16} on random data —
+    incl. the reference's own exact-equality check shape (27, 253, 57, 58) (csm_triton.py:670) — and == the oracle on a model-sized call."""
+    import time
+    from tests import csm_cases
+    from xpoint_amd import kernels
+    n = csm_cases.check(golden("g22_cross_scan_ops.npz"), kernels.cross_scan_fn, kernels.cross_merge_fn, device="cuda")
+    assert n >= 150, n
+    # the reference model's call at stage 0 of a 480 x 640 image batch (VMamba.py:603, :632): tiled kernels; rate printed
+    B, C, H, W = 4, 96, 120, 160
+    x = _u("csm/x", (B, C, H, W)).cuda()
+    ys = kernels.cross_scan_fn(x)
+    assert torch.equal(ys.cpu(), xo.cross_scan_op(x.cpu()))
+    y4 = _u("csm/y4", (B, 4, C, H, W)).cuda()
+    out = kernels.cross_merge_fn(y4)
+    assert torch.equal(out.cpu(), xo.cross_merge_op(y4.cpu()))
+    for fn, arg, nbytes in ((kernels.cross_scan_fn, x, 5 * x.numel() * 4), (kernels.cross_merge_fn, y4, 5 * x.numel() * 4)):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            fn(arg)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+        with capsys.disabled():
+            print(f"\n{fn.__name__} (4, 96, 120, 160) f32: {dt * 1e6:.1f} us, {nbytes / dt / 1e12:.2f} TB/s algorithmic (incl. the output allocation)")
+    for bad in (dict(scans=3), dict(scans=-1)):
+        with pytest.raises(RuntimeError):
+            kernels.cross_scan_fn(x, **bad)
+    with pytest.raises(RuntimeError):
+        kernels.cross_scan_fn(x.cpu())

@@ -210,3 +210,12 @@ def test_g12_conv_xpoint(golden):
         r = xo.forward_impl(img, sd)
     for k in ("prob", "desc", "encoder_output"):
         np.testing.assert_allclose(r[k].numpy(), g[f"64x96/{k}"], atol=2e-6, err_msg=k)
+
+
+def test_g22_cross_scan_ops_all_layouts(golden):
+    """The oracle's index-table restatement of cross_scan_fn / cross_merge_fn == the real reference (fixture g22) bit for bit: four layouts x
+    scans {0, 1, 2} x one_by_one x {f32, f16, bf16} on random data, incl. the association of the merge adds and the reference's own odd check
+    shape (27, 253, 57, 58) (csm_triton.py:670) by checksum."""
+    from tests import csm_cases
+    n = csm_cases.check(golden("g22_cross_scan_ops.npz"), xo.cross_scan_op, xo.cross_merge_op)
+    assert n >= 150, n

@@ -27,6 +27,8 @@ _SIGNATURES = {
     "xp_device_info": [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
     "xp_selective_scan_fwd": [c_p] * 9 + [c_i] * 7 + [c_p],
     "xp_selective_scan_fwd_typed": [c_p] * 9 + [c_i] * 9 + [c_p],
+    "xp_cross_scan": [c_p, c_p] + [c_i] * 9 + [c_p],
+    "xp_cross_merge": [c_p, c_p] + [c_i] * 9 + [c_p],
     "xp_ss2d_core_fwd": [c_p] * 10 + [c_sz] + [c_i] * 6 + [c_f, c_p],
     "xp_ss2d_core_set_mode": [c_i],
     "xp_set_dense_products": [c_i],
@@ -95,7 +97,6 @@ _SIZE_QUERIES = {
     "xp_get_dense_products": (c_i, []),
     "xp_get_dense_engine": (c_i, []),
     "xp_get_amp_mode": (c_i, []),
-    "xp_gemm_h2w_error": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_mlp_fused_h2_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_ln_proj_h2_pack_bytes": (c_sz, [c_i, c_i]),

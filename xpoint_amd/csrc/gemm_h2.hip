@@ -14,9 +14,6 @@
 
 #include "gemm_h2_core.h"
 
-// wave-specialised form for long plain GEMMs (gemm_h2w.hip)
-bool xp_gemm_h2w_applies(const GemmParams& p);
-int xp_gemm_h2w_launch(const GemmParams& p, hipStream_t s);
 bool xp_gemm_h2p_applies(const GemmParams& p);      // gemm_h2p.hip: ping-pong schedule of the 128 x 128 tile
 int xp_gemm_h2p_launch(const GemmParams& p, hipStream_t s);
 
@@ -285,7 +282,6 @@ int dispatch(const GemmParams& p_in, hipStream_t s) {
         XP_LAUNCH_CHECK();
         return XP_OK;
     }
-    if (sel >= 3 && xp_gemm_h2w_applies(p)) return xp_gemm_h2w_launch(p, s);
     if (sel >= 3 && xp_gemm_h2p_applies(p)) return xp_gemm_h2p_launch(p, s);
     switch (sel) {
         case 0: launch<4, 1, 1, 1>(p, s); break;       // 128 x 32

@@ -234,17 +234,17 @@ __global__ __launch_bounds__(512) void gemm_h2p_kernel(GemmParams p) {
 
 }  // namespace
 
-// DEFAULT for K >= 768 with at least 128 tiles (XP_H2P=0 turns it off, XP_H2P=2 widens it to K >= 128 and any tile count).  Measured, round 3 (tools/h2p_dbg.sh,
+// DEFAULT for K >= 768 and N >= 384 (XP_H2P=0 turns it off, XP_H2P=2 widens it to K >= 128 and N >= 96).  Measured, round 3 (tools/h2p_dbg.sh,
 // profiles/r3_gemm_h2p_pingpong.txt): alone on the GPU it beats the tile kernel where the K loop dominates (M 19200 N 384 K 1536: 79.4 vs 91.6-99.7 us,
 // 285 TF/s; M 4800 N 768 K 3072: 86.9 vs 102.4) and loses where prologue and epilogue dominate (K = 384: 32.3 vs 28.9, fc1 + GELU 131 vs 123: one workgroup
-// per CU has nothing to hide them behind) or the tile count is small (M 4800 N 200: 25 vs 20 us).  In the pair step: +0.9 .. 1.2 % (three alternating
-// A/B runs of 5 x 100 steps on one box: 1680-1693 against 1664-1673 pairs/s).  The summation order differs from the tile kernel (even slabs + odd slabs);
-// every pinned list count of the C2 / C3 / C4 fixtures is unchanged with it (tests/test_gpu_model.py, test_gpu_configs.py).
+// per CU has nothing to hide them behind) or the tile count is small (M 4800 N 200: 25 vs 20 us).  In the pair step: +0.9 .. 1.2 %.
+// The summation order differs from the tile kernel (even slabs + odd slabs), so the choice must NOT depend on M (= images x L, a batch quantity): round 3's
+// predicate had a tile-count term and a pair run alone no longer agreed bit for bit with the same pair inside a batch of 8.  The predicate
+// is now a property of the LAYER (K, N, lda) only: every batch size takes the same kernel for the same layer (tests/test_gpu_model.py::test_batch_invariance_480x640).
 bool xp_gemm_h2p_applies(const GemmParams& p) {
     static const int on = getenv("XP_H2P") ? atoi(getenv("XP_H2P")) : 1;
-    return on && p.mode == 0 && p.K % 64 == 0 && p.K >= (on > 1 ? 128 : 768) && p.lda % 4 == 0 && p.N >= 96 &&
-           (on > 1 || (int64_t)xp_cdiv(p.M, P_BM) * xp_cdiv(p.N, P_BN) >= 128) && (int64_t)p.M * p.lda < (1ll << 30) &&
-           (int64_t)p.N * H2_SLAB_UNITS * 16 * (p.K / H2_BK) < (1ll << 32);
+    return on && p.mode == 0 && p.K % 64 == 0 && p.K >= (on > 1 ? 128 : 768) && p.lda % 4 == 0 && p.N >= (on > 1 ? 96 : 384) &&
+           (int64_t)p.M * p.lda < (1ll << 30) && (int64_t)p.N * H2_SLAB_UNITS * 16 * (p.K / H2_BK) < (1ll << 32);
 }
 
 int xp_gemm_h2p_launch(const GemmParams& p, hipStream_t s) {

@@ -3,7 +3,8 @@
 Mirrors the reference's operator interfaces for the hot path so parity tests read like the
 reference's own: `selective_scan_fn` (reference vmamba_src/csms6s.py:112-126, pybind op
 selective_scan_cuda_oflex.fwd, selective_scan_oflex.cpp:143-231).  Errors from the C ABI surface as
-RuntimeError, like TORCH_CHECK failures do in the reference."""
+RuntimeError, like TORCH_CHECK failures do in the reference.  `cross_scan_fn` / `cross_merge_fn` mirror
+vmamba_src/csm_triton.py:501-517 (same arguments, shapes and layouts)."""
 from __future__ import annotations
 
 import torch
@@ -82,3 +83,54 @@ def selective_scan_fn(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus
               ptr(last), c_i(batch), c_i(dim), c_i(delta.shape[1]), c_i(L), c_i(N), c_i(G), c_i(int(bool(delta_softplus))),
               _lib.current_stream())
     return (out, last) if return_last_state else out
+
+
+def _csm_dtype(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: input must be a CUDA(HIP) tensor")
+    if t.dtype not in _ITYPE:
+        raise RuntimeError(f"{who}: dtype must be float32, float16 or bfloat16 (got {t.dtype})")
+    return _ITYPE[t.dtype]
+
+
+def cross_scan_fn(x, in_channel_first=True, out_channel_first=True, one_by_one=False, scans=0, force_torch=False):
+    """Reference `cross_scan_fn` (csm_triton.py:501-507).  x: (B,C,H,W) | (B,H,W,C) | one_by_one: (B,4,C,H,W) | (B,H,W,4,C);
+    returns (B,4,C,L) if out_channel_first else (B,L,4,C).  scans 0 cross scan, 1 unidirectional, 2 bidirectional.  `force_torch` is accepted and
+    ignored (there is one implementation).  Inference only: no autograd graph is recorded."""
+    dt = _csm_dtype(x, "cross_scan_fn")
+    if scans not in (0, 1, 2):
+        raise RuntimeError(f"cross_scan_fn: scans must be 0, 1 or 2 (got {scans})")
+    if x.dim() != (5 if one_by_one else 4):
+        raise RuntimeError(f"cross_scan_fn: expected a {5 if one_by_one else 4}-d tensor, got {tuple(x.shape)}")
+    if one_by_one:
+        B, K, C, H, W = x.shape if in_channel_first else (x.shape[0], x.shape[3], x.shape[4], x.shape[1], x.shape[2])
+        if K != 4:
+            raise RuntimeError("cross_scan_fn: one_by_one input must hold 4 routes")
+    else:
+        B, C, H, W = x.shape if in_channel_first else (x.shape[0], x.shape[3], x.shape[1], x.shape[2])
+    x = x.contiguous()
+    y = torch.empty((B, 4, C, H * W) if out_channel_first else (B, H * W, 4, C), device=x.device, dtype=x.dtype)
+    _lib.call("xp_cross_scan", ptr(x), ptr(y), c_i(dt), c_i(B), c_i(C), c_i(H), c_i(W), c_i(int(bool(in_channel_first))),
+              c_i(int(bool(out_channel_first))), c_i(int(bool(one_by_one))), c_i(scans), _lib.current_stream(x))
+    return y
+
+
+def cross_merge_fn(y, in_channel_first=True, out_channel_first=True, one_by_one=False, scans=0, force_torch=False):
+    """Reference `cross_merge_fn` (csm_triton.py:511-517).  y: (B,4,C,H,W) if out_channel_first else (B,H,W,4,C) (the scan's OUT layout);
+    returns (B,C,L) if in_channel_first else (B,L,C) — one_by_one: (B,4,C,L) / (B,L,4,C).  Adds associate as the reference's do."""
+    dt = _csm_dtype(y, "cross_merge_fn")
+    if scans not in (0, 1, 2):
+        raise RuntimeError(f"cross_merge_fn: scans must be 0, 1 or 2 (got {scans})")
+    if y.dim() != 5:
+        raise RuntimeError(f"cross_merge_fn: expected (B,4,C,H,W) or (B,H,W,4,C), got {tuple(y.shape)}")
+    B, K, C, H, W = y.shape if out_channel_first else (y.shape[0], y.shape[3], y.shape[4], y.shape[1], y.shape[2])
+    if K != 4:
+        raise RuntimeError("cross_merge_fn: input must hold 4 routes")
+    y = y.contiguous()
+    if one_by_one:
+        out = torch.empty((B, 4, C, H * W) if in_channel_first else (B, H * W, 4, C), device=y.device, dtype=y.dtype)
+    else:
+        out = torch.empty((B, C, H * W) if in_channel_first else (B, H * W, C), device=y.device, dtype=y.dtype)
+    _lib.call("xp_cross_merge", ptr(y), ptr(out), c_i(dt), c_i(B), c_i(C), c_i(H), c_i(W), c_i(int(bool(in_channel_first))),
+              c_i(int(bool(out_channel_first))), c_i(int(bool(one_by_one))), c_i(scans), _lib.current_stream(y))
+    return out
