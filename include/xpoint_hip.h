@@ -318,12 +318,20 @@ int xp_sample_descriptors(const int* kp, const int* counts, const float* desc_nh
  * rows of pair i is counts[i*cnt_stride + which1] / [.. + which2] (counts NULL: all cap rows).
  * mode 0 = strict mutual nearest neighbour (primary), 1 = legacy cross-check.  Outputs: idx12/dist12 (pairs,cap1),
  * idx21/dist21 (pairs,cap2), matches (pairs,cap1) as (queryIdx, trainIdx, distance) ascending in queryIdx,
- * match_count (pairs). */
+ * match_count (pairs).  Index results are those of exact arithmetic (first index wins exact ties): the fp16 matrix pass only nominates, the
+ * nominated pairs are re-evaluated in f32 direct form and the survivors of that window in fp64 (csrc/match.hip). */
 size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2, int D);
 int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs,
                  int cap1, int cap2, int D, int mode, int* idx12, float* dist12, int* idx21, float* dist21,
                  int* match_q, int* match_t, float* match_d, int* match_count, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* Candidate-list statistics of the latest xp_match_mnn call on `workspace` (same pairs / cap1 / cap2 / D / counts): out4 = 4 x uint64 on the device =
+ * [sum of the nomination-list lengths over live rows and columns, the longest list, rows + columns whose list overflowed the inline capacity
+ * (xp_match_cand_cap(); finished by the parallel overflow pass), live rows + columns].  bench.py reports them as match_candidates_per_row /
+ * match_overflow_rows: the matcher's run time depends on them (clustered descriptors nominate more), its result never does. */
+int xp_match_stats(void* workspace, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2, int D,
+                   unsigned long long* out4, void* stream);
+int xp_match_cand_cap(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Evaluation-harness helper: out[i] = min_j |a_i - b_j| (Euclidean, 2-D points (y, x)); +inf when

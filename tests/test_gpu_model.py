@@ -346,6 +346,38 @@ def test_overlapped_pipeline_equals_single_stream(gpu_lib, split):
                 assert a["match_q"].tolist() == b["match_q"].tolist() and a["match_t"].tolist() == b["match_t"].tolist()
 
 
+def test_batch_invariance_480x640(gpu_lib):
+    """at the BENCH size an image's result must not depend on which other images share the call.  Pair 0 of the C2 batch
+    (i) alone, (ii) inside the batch of 8 on the overlapped alternating-encoder schedule (what bench.py times), (iii) inside the batch of 8 with the
+    encoder split into two image groups (`split2`: M = 2400 rows at stage 3) and (iv) through the eager forward: prob, the descriptor volume, keypoints,
+    sampled descriptors and match indices bit-identical (torch.equal).  The reference computes every image independently (XPoint.py:283-323).
+    Round 3's ping-pong GEMM was picked by a tile count (a batch quantity) and broke exactly this at 480 x 640 while the 96 x 128 tests stayed green."""
+    from xpoint_amd.predict import PairPipeline
+    H, W = 480, 640
+    net = _net(synth.xpoint_exp1_config(H, W))
+    d8, d1 = _data(0, 8, H, W), _data(0, 1, H, W)
+    args = lambda d: (d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"])
+    with torch.no_grad():
+        runs = {}
+        for name, B, d, kw in (("alone", 1, d1, dict()), ("alone_overlap", 1, d1, dict(overlap=True, alternate_encoders=True)),
+                               ("batch8", 8, d8, dict(overlap=True, alternate_encoders=True)), ("split2", 8, d8, dict(overlap=True, split_encoder=2)),
+                               ("single_stream8", 8, d8, dict())):
+            pipe = PairPipeline(net, B, H, W, cap=8192, **kw)
+            for _ in range(2):
+                pipe.run(*args(d))
+            got = pipe.fetch()[0]
+            runs[name] = dict(prob=pipe.raw["prob"][[0, B]].clone(), desc=pipe.raw["desc_nhwc"][[0, B]].clone(), **got)
+        o, t, _ = net(d1)
+        o8, t8, _ = net(d8)
+    ref = runs["alone"]
+    for name, r in runs.items():
+        for k in ("prob", "desc", "kp_optical", "kp_thermal", "desc_optical", "desc_thermal"):
+            assert torch.equal(r[k], ref[k]), (name, k, float((r[k].float() - ref[k].float()).abs().max()) if r[k].shape == ref[k].shape else "shape")
+        assert r["match_q"].tolist() == ref["match_q"].tolist() and r["match_t"].tolist() == ref["match_t"].tolist(), name
+    assert torch.equal(o["prob"][0, 0], ref["prob"][0]) and torch.equal(t["prob"][0, 0], ref["prob"][1])
+    assert torch.equal(o8["prob"][0], o["prob"][0]) and torch.equal(t8["desc"][0], t["desc"][0]) and torch.equal(o8["encoder_output"][0], o["encoder_output"][0])
+
+
 def test_pipeline_edge_cases(gpu_lib):
     """Empty inputs (everything masked), capacity overflow and an under-iterated async NMS are detected, not silent."""
     from xpoint_amd.predict import PairPipeline

@@ -34,5 +34,9 @@ for _ in range(iters):
     run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
+st = torch.zeros(4, dtype=torch.int64, device=dev)
+_lib.check(lib.xp_match_stats(ptr(ws), ptr(counts), 1, 0, P, P, cap, cap, 256, ptr(st), _lib.current_stream()), "xp_match_stats")
+st = [int(v) for v in st.cpu()]
+print(f"candidates per row / column: mean {st[0] / max(st[3], 1):.2f}, max {st[1]}, overflowed lists {st[2]} of {st[3]} (inline capacity {lib.xp_match_cand_cap()})")
 print(f"n={n} cap={cap} pairs={P}: {dt * 1e6:.1f} us per call, {int(res['mc'].sum())} mutual matches, "
       f"{2 * P * n * n * 256 / dt / 1e12:.1f} TFLOP/s algorithmic")

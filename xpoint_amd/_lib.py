@@ -74,6 +74,7 @@ _SIGNATURES = {
     "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p],
     "xp_sample_descriptors": [c_p] * 4 + [c_i] * 7 + [c_p],
     "xp_match_mnn": [c_p, c_p, c_p] + [c_i] * 8 + [c_p] * 9 + [c_sz, c_p],
+    "xp_match_stats": [c_p, c_p] + [c_i] * 7 + [c_p, c_p],
     "xp_points_min_dist": [c_p, c_i, c_p, c_i, c_p, c_p],
     "xp_gather_match_points": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "xp_find_homography": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, ctypes.c_uint, c_p, c_p, c_p, c_p, c_sz, c_p],
@@ -104,6 +105,7 @@ _SIZE_QUERIES = {
     "xp_find_homography_workspace_bytes": (c_sz, [c_i]),
     "xp_box_nms_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_match_workspace_bytes": (c_sz, [c_i] * 4),
+    "xp_match_cand_cap": (c_i, []),
     "xp_extract_keypoints_workspace_bytes": (c_sz, [c_i] * 3),
 }
 

@@ -43,7 +43,7 @@ typedef __attribute__((address_space(3))) void* mt_lds_ptr_t;
 
 namespace {
 
-constexpr int CAND_CAP = 16;
+constexpr int CAND_CAP = 64;                // inline candidates per row / column (one per lane of the refining wave); longer lists -> overflow list -> match_overflow_kernel
 constexpr float MT_EPS_REL = 1.0e-3f, MT_EPS_ABS = 4e-6f;    // 2 (2^-11 + 8.5e-6) = 9.94e-4, see the bound above
 constexpr float MT_DEAD = -30000.f;          // score term of rows past the count (finite in fp16)
 constexpr int MT_STRIP = 256, MT_TILE = 64;  // query rows per workgroup, target descriptors per LDS tile
@@ -62,7 +62,7 @@ __device__ __forceinline__ float mt_max(float a, float b) { float d; asm("v_max_
 __device__ __forceinline__ float mt_max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 // (a kernel, not hipMemsetAsync: see nms_reset_counters_kernel in postproc.hip)
-__global__ void match_reset_kernel(unsigned* __restrict__ maxbits) { if (threadIdx.x < 4) maxbits[threadIdx.x] = 0u; }
+__global__ void match_reset_kernel(unsigned* __restrict__ maxbits) { if (threadIdx.x < 8) maxbits[threadIdx.x] = 0u; }
 
 // ---- pass 0a: squared norms of both descriptor sets and the largest one of the call ----
 __global__ __launch_bounds__(256) void match_norms_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ cnt,
@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
                         const unsigned e = (unsigned)cl | (rl << 16) | (hr ? 0x40000000u : 0u) | (hc ? 0x80000000u : 0u);
                         const unsigned pos = atomicAdd(q_count, 1u);
                         if (pos < MT_QCAP) q_entry[pos] = e;
-                        else {       // queue full (degenerate inputs, e.g. thousands of identical descriptors): mark the lists as
-                                     // overflowed, which sends that row / column to the refine kernel's scan of every target
-                            if (hr) atomicAdd(&rcnt[r0 + (int)rl], CAND_CAP + 1);
-                            if (hc) atomicAdd(&ccnt[c_begin + cl], CAND_CAP + 1);
+                        else {       // queue full (heavily clustered descriptors): append to the global lists from here — slow (a returning global
+                                     // atomic per hit) but complete: round 3 flagged the row as overflowed instead, which sent it to a full scan
+                            if (hr) { const int row = r0 + (int)rl; const int k = atomicAdd(&rcnt[row], 1); if (k < CAND_CAP) rcand[(int64_t)row * CAND_CAP + k] = c_begin + cl; }
+                            if (hc) { const int col = c_begin + cl; const int k = atomicAdd(&ccnt[col], 1); if (k < CAND_CAP) ccand[(int64_t)col * CAND_CAP + k] = r0 + (int)rl; }
                         }
                     }
                 }
@@ -361,33 +361,190 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
     }
 }
 
-// Exact nearest neighbour among the nominated candidates (fp64 direct form); one wave per query.
-// Falls back to scanning every target when the candidate list overflowed.
+// ---- refinement: exact nearest neighbour among the nominated candidates ------------------------------------------------------------------------
+// Round 4.  Round 3 re-evaluated every candidate in fp64 and, when a list overflowed (CAND_CAP 16), let ONE wave scan every target
+// in fp64: 2.5 us per target — a single overflowing row of a 4060-keypoint pair cost 10 ms (0.30 -> 10.7 ms per 8 pairs on clustered descriptors).
+// Now three levels, each cheaper per element than the next:
+//   level 1  fp16 one-product Gram nomination (above): window 2e-3 of the score;
+//   level 2  f32 DIRECT form sum (a_k - b_k)^2 of every listed candidate (lists up to CAND_CAP = 64: one candidate per lane of the refining wave, eight
+//            target rows in flight): relative error <= 14 x 2^-24 = 8.4e-7 (one rounding per difference, square, fma and reduction step; all terms >= 0),
+//            so only candidates with s <= s_min (1 + MT_F32_REL) + MT_F32_ABS can be the exact minimum (or tie with it) — a window 400 x narrower;
+//   level 3  fp64 direct form of those (usually one: the winner, whose fp64 distance is the reported one), first index wins exact ties.
+// Rows whose list overflowed are appended to an overflow list and finished by match_overflow_kernel: a WORKGROUP per row scans all targets with the
+// same level 2 / 3 logic (running minimum per wave), rows in parallel across the chip.  The result is the exact-arithmetic argmin as before.
+constexpr int MT_OVF_GRID = 512;               // persistent workgroups of the overflow pass (two per CU)
+constexpr float MT_F32_REL = 1.0e-5f, MT_F32_ABS = 1.0e-30f;    // 2 x (8.4e-7 rounded up 5 x); the absolute term covers squares that underflow
+
+// fp64 direct-form squared distance between the lane-distributed query (a4 = its float4 at column 4 lane, zeros past D) and target row b
+__device__ __forceinline__ double mt_dist64(const float4& a4, const float* __restrict__ b, int lane, int D) {
+    double s = 0.0;
+    if (lane * 4 < D) {
+        const float4 v = *reinterpret_cast<const float4*>(b + lane * 4);
+        double df = (double)a4.x - (double)v.x; s = fma(df, df, s);
+        df = (double)a4.y - (double)v.y; s = fma(df, df, s);
+        df = (double)a4.z - (double)v.z; s = fma(df, df, s);
+        df = (double)a4.w - (double)v.w; s = fma(df, df, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+__device__ __forceinline__ float mt_part32(const float4& a4, const float4& v) {
+    float d = a4.x - v.x, s = d * d;
+    d = a4.y - v.y; s = fmaf(d, d, s);
+    d = a4.z - v.z; s = fmaf(d, d, s);
+    d = a4.w - v.w; s = fmaf(d, d, s);
+    return s;
+}
+
+struct OvfList { int* count; int2* entry; };      // entry = (pair * 2 + direction, query row)
+
+// One wave per query.  K2 (knn): the TWO nearest targets are returned (idx_out / dist_out hold 2 entries per query), see xp_match_knn.
+template <bool K2>
 __global__ __launch_bounds__(256) void match_refine_kernel(const float* __restrict__ dq, const float* __restrict__ dt, const int* __restrict__ nqp,
                                                            const int* __restrict__ ntp, int cnt_stride, int whichq, int whicht, int capq,
                                                            int capt, int D, const int* __restrict__ cnt, const int* __restrict__ cand,
-                                                           int* __restrict__ idx_out, float* __restrict__ dist_out) {
+                                                           int* __restrict__ idx_out, float* __restrict__ dist_out, OvfList ovf, int dir) {
     const int pair = blockIdx.y;
     const int nq = count_of(nqp, pair * cnt_stride + whichq, capq), nt = count_of(ntp, pair * cnt_stride + whicht, capt);
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (q >= nq) return;
     const int lane = threadIdx.x & 63;
     const float* a = dq + ((int64_t)pair * capq + q) * D;
     const float* tb = dt + (int64_t)pair * capt * D;
     const int nc = cnt[(int64_t)pair * capq + q];
-    const bool overflow = nc > CAND_CAP;
-    const int total = overflow ? nt : nc;
-    double best = INFINITY; int bi = -1;
-    for (int c = 0; c < total; ++c) {
-        const int t = overflow ? c : cand[((int64_t)pair * capq + q) * CAND_CAP + c];
-        const float* b = tb + (int64_t)t * D;
-        double s = 0.0;
-        for (int k = lane; k < D; k += 64) { const double df = (double)a[k] - (double)b[k]; s = fma(df, df, s); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (s < best || (s == best && t < bi)) { best = s; bi = t; }
+    if (nc > CAND_CAP) {
+        if (lane == 0) { const int pos = atomicAdd(ovf.count, 1); ovf.entry[pos] = make_int2(pair * 2 + dir, q); }
+        return;
     }
-    if (lane == 0) { idx_out[(int64_t)pair * capq + q] = bi; dist_out[(int64_t)pair * capq + q] = (float)sqrt(best); }
+    const int* cl = cand + ((int64_t)pair * capq + q) * CAND_CAP;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane * 4 < D) a4 = *reinterpret_cast<const float4*>(a + lane * 4);
+    const int mine_t = lane < nc ? cl[lane] : 0;                   // lane c owns candidate c
+    // level 2: f32 direct form, eight candidates in flight
+    float mine = INFINITY;
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+        float part[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = __builtin_amdgcn_readlane(mine_t, (c0 + j) & 63);      // lanes past nc hold 0: a valid row, its sum is discarded
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane * 4 < D) v = *reinterpret_cast<const float4*>(tb + (int64_t)t * D + lane * 4);
+            part[j] = mt_part32(a4, v);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float sum = xp_wave_sum(part[j]); if (lane == c0 + j) mine = sum; }
+    }
+    if (lane >= nc) mine = INFINITY;
+    float m32 = -xp_wave_max(-mine);
+    if (K2) {       // the window hangs from the SECOND smallest f32 sum (every candidate within it may be one of the exact two nearest)
+        const unsigned long long at_min = __ballot(mine == m32);
+        const int first = __ffsll((long long)at_min) - 1;
+        const float second = -xp_wave_max(lane == first ? -INFINITY : -mine);
+        m32 = second;       // INFINITY when there is a single candidate: everything passes
+    }
+    const float thr = m32 < INFINITY ? fmaf(m32, MT_F32_REL, m32) + MT_F32_ABS : INFINITY;
+    unsigned long long pass = __ballot(lane < nc && mine <= thr);
+    // level 3: fp64 on the survivors
+    double best = INFINITY, best2 = INFINITY; int bi = -1, bi2 = -1;
+    while (pass) {
+        const int c = __ffsll((long long)pass) - 1;
+        pass &= pass - 1ull;
+        const int t = __builtin_amdgcn_readlane(mine_t, c);
+        const double s = mt_dist64(a4, tb + (int64_t)t * D, lane, D);
+        if (s < best || (s == best && t < bi)) { best2 = best; bi2 = bi; best = s; bi = t; }
+        else if (K2 && (s < best2 || (s == best2 && t < bi2))) { best2 = s; bi2 = t; }
+    }
+    (void)nt;
+    if (lane == 0) {
+        if (K2) {
+            int* io = idx_out + ((int64_t)pair * capq + q) * 2; float* dd = dist_out + ((int64_t)pair * capq + q) * 2;
+            io[0] = bi; dd[0] = (float)sqrt(best); io[1] = bi2; dd[1] = (float)sqrt(best2);
+        } else { idx_out[(int64_t)pair * capq + q] = bi; dist_out[(int64_t)pair * capq + q] = (float)sqrt(best); }
+    }
+}
+
+// Rows whose candidate list overflowed: a workgroup (16 waves) per row walks every target — f32 direct form, sixteen... eight rows in flight per wave, a
+// running minimum per wave; a target within the f32 window of the running minimum (a superset of the final window: the minimum only falls) is evaluated
+// in fp64 on the spot (the branch is wave-uniform) — then the waves' (distance, index) pairs are reduced through LDS.  Persistent over the overflow
+// list, so one fixed-size launch serves any number of rows (0 rows: every workgroup exits after one load).
+template <bool K2>
+__global__ __launch_bounds__(1024) void match_overflow_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ counts,
+                                                              int cnt_stride, int which1, int which2, int cap1, int cap2, int D, OvfList ovf,
+                                                              int* __restrict__ idx12, float* __restrict__ dist12, int* __restrict__ idx21,
+                                                              float* __restrict__ dist21) {
+    __shared__ double s_best[2][16];
+    __shared__ int s_idx[2][16];
+    const int n_ovf = *ovf.count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = blockIdx.x; e < n_ovf; e += gridDim.x) {
+        const int2 ent = ovf.entry[e];
+        const int pair = ent.x >> 1, dir = ent.x & 1, q = ent.y;
+        const int capq = dir ? cap2 : cap1, capt = dir ? cap1 : cap2;
+        const int nt = count_of(counts, pair * cnt_stride + (dir ? which1 : which2), capt);
+        const float* a = (dir ? d2 : d1) + ((int64_t)pair * capq + q) * D;
+        const float* tb = (dir ? d1 : d2) + (int64_t)pair * capt * D;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane * 4 < D) a4 = *reinterpret_cast<const float4*>(a + lane * 4);
+        float run1 = INFINITY, run2 = INFINITY;          // smallest (and, K2, second smallest) f32 sums this wave has seen
+        double best = INFINITY, best2 = INFINITY; int bi = -1, bi2 = -1;
+        for (int t0 = wave * 8; t0 < nt; t0 += 16 * 8) {
+            float part[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + j < nt ? t0 + j : nt - 1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane * 4 < D) v = *reinterpret_cast<const float4*>(tb + (int64_t)t * D + lane * 4);
+                part[j] = mt_part32(a4, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sum = xp_wave_sum(part[j]);
+                const int t = t0 + j;
+                if (t >= nt) continue;
+                const float ref = K2 ? run2 : run1;
+                if (sum < run1) { run2 = run1; run1 = sum; } else if (sum < run2) run2 = sum;
+                if (!(sum <= fmaf(ref, MT_F32_REL, ref) + MT_F32_ABS) && ref < INFINITY) continue;       // wave-uniform
+                const double s = mt_dist64(a4, tb + (int64_t)t * D, lane, D);
+                if (s < best || (s == best && t < bi)) { best2 = best; bi2 = bi; best = s; bi = t; }
+                else if (K2 && (s < best2 || (s == best2 && t < bi2))) { best2 = s; bi2 = t; }
+            }
+        }
+        if (lane == 0) { s_best[0][wave] = best; s_idx[0][wave] = bi; s_best[1][wave] = best2; s_idx[1][wave] = bi2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double b1 = INFINITY, b2 = INFINITY; int i1 = -1, i2 = -1;
+            for (int k = 0; k < 2; ++k)
+                for (int w = 0; w < 16; ++w) {
+                    const double s = s_best[k][w]; const int t = s_idx[k][w];
+                    if (t < 0) continue;
+                    if (s < b1 || (s == b1 && t < i1)) { b2 = b1; i2 = i1; b1 = s; i1 = t; }
+                    else if (s < b2 || (s == b2 && t < i2)) { b2 = s; i2 = t; }
+                }
+            int* io = dir ? idx21 : idx12; float* dd = dir ? dist21 : dist12;
+            if (K2) { io += ((int64_t)pair * capq + q) * 2; dd += ((int64_t)pair * capq + q) * 2; io[0] = i1; dd[0] = (float)sqrt(b1); io[1] = i2; dd[1] = (float)sqrt(b2); }
+            else { io[(int64_t)pair * capq + q] = i1; dd[(int64_t)pair * capq + q] = (float)sqrt(b1); }
+        }
+        __syncthreads();
+    }
+}
+
+// Candidate-list statistics of the latest call on a workspace (bench.py: match_candidates_per_row, match_overflow_rows): out[0] = sum of the list
+// lengths of the live rows and columns, out[1] = the longest, out[2] = rows + columns that overflowed CAND_CAP, out[3] = live rows + columns.
+__global__ __launch_bounds__(256) void match_stats_kernel(const int* __restrict__ rcnt, const int* __restrict__ ccnt, const int* __restrict__ counts,
+                                                          int cnt_stride, int which1, int which2, int cap1, int cap2, int pairs,
+                                                          unsigned long long* __restrict__ out) {
+    const int64_t a = (int64_t)pairs * cap1, total = a + (int64_t)pairs * cap2;
+    unsigned long long sum = 0, mx = 0, ov = 0, live = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const bool col = i >= a;
+        const int64_t j = col ? i - a : i;
+        const int cap = col ? cap2 : cap1, pair = (int)(j / cap), r = (int)(j % cap);
+        if (r >= count_of(counts, pair * cnt_stride + (col ? which2 : which1), cap)) continue;
+        const unsigned long long n = (unsigned long long)(col ? ccnt : rcnt)[j];
+        sum += n; mx = n > mx ? n : mx; ov += n > (unsigned long long)CAND_CAP; live += 1;
+    }
+    atomicAdd(&out[0], sum); atomicMax(&out[1], mx); atomicAdd(&out[2], ov); atomicAdd(&out[3], live);
 }
 
 // Mutual test + ordered compaction (ascending queryIdx, like BFMatcher.match output order).
@@ -447,8 +604,36 @@ extern "C" size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2, int D)
     const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
     const size_t aP = (size_t)pairs * mt_up(cap1, MT_STRIP), bP = (size_t)pairs * mt_up(cap2, MT_TILE);
     const size_t rowb = mt_rowb(mt_ksd(D));
-    // rowkey, colkey (u32, padded rows) | scratch (u64) | na, nb | rcnt, ccnt | rcand, ccand | max-norm word | fp16 images of both sets
-    return 4 * (aP + bP) + 8 * a + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 1024 + (aP + bP) * rowb;
+    // rowkey, colkey (u32, padded rows) | scratch (u64) | na, nb | rcnt, ccnt | rcand, ccand | overflow list (int2) | max-norm / counter words | fp16 images
+    return 4 * (aP + bP) + 8 * a + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 8 * (a + b) + 1024 + (aP + bP) * rowb;
+}
+
+// The carve-up of a workspace (shared by xp_match_mnn and xp_match_stats)
+struct MatchWs {
+    unsigned long long* scratch; unsigned* rowkey; unsigned* colkey; float* na; float* nb; int* rcnt; int* ccnt; int* rcand; int* ccand;
+    int2* ovf_entry; unsigned* words; unsigned char* A; unsigned char* B; int rows1P, rows2P;
+};
+static MatchWs mt_carve(void* workspace, int pairs, int cap1, int cap2, int D) {
+    MatchWs m{};
+    const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
+    m.rows1P = (int)mt_up(cap1, MT_STRIP); m.rows2P = (int)mt_up(cap2, MT_TILE);
+    const size_t aP = (size_t)pairs * m.rows1P, bP = (size_t)pairs * m.rows2P;
+    char* w = (char*)workspace;
+    m.scratch = (unsigned long long*)w; w += 8 * a;
+    m.ovf_entry = (int2*)w; w += 8 * (a + b);
+    m.rowkey = (unsigned*)w; w += 4 * aP;
+    m.colkey = (unsigned*)w; w += 4 * bP;
+    m.na = (float*)w; w += 4 * a;
+    m.nb = (float*)w; w += 4 * b;
+    m.rcnt = (int*)w; w += 4 * a;
+    m.ccnt = (int*)w; w += 4 * b;
+    m.rcand = (int*)w; w += 4 * CAND_CAP * a;
+    m.ccand = (int*)w; w += 4 * CAND_CAP * b;
+    w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    m.words = (unsigned*)w; w += 256;          // [0] largest squared norm (bits), [2] overflow-list length, [8..15] statistics (xp_match_stats)
+    m.A = (unsigned char*)w; w += aP * mt_rowb(mt_ksd(D));
+    m.B = (unsigned char*)w;
+    return m;
 }
 
 template <int KSD>
@@ -481,34 +666,26 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
                  "xp_match_mnn: null pointer");
     XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D % 4 == 0, "xp_match_mnn: bad shape (D must be a multiple of 4)");
     XP_CHECK_ARG(cap1 <= 65536 && cap2 <= 65536, "xp_match_mnn: at most 65536 descriptors per image");
+    XP_CHECK_ARG(pairs <= (1 << 29), "xp_match_mnn: too many pairs");
     XP_CHECK_ARG(D <= 256, "xp_match_mnn: descriptor size %d > 256 (the query strip is register resident; the reference's models use 64 and 256)", D);
     XP_CHECK_ARG(mode == 0 || mode == 1, "xp_match_mnn: mode 0 (strict_mnn) or 1 (legacy_crosscheck)");
     XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2, D), "xp_match_mnn: workspace too small");
     XP_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "xp_match_mnn: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
-    const int rows1P = (int)mt_up(cap1, MT_STRIP), rows2P = (int)mt_up(cap2, MT_TILE);
-    const size_t aP = (size_t)pairs * rows1P, bP = (size_t)pairs * rows2P;
+    const MatchWs m = mt_carve(workspace, pairs, cap1, cap2, D);
+    const int rows1P = m.rows1P, rows2P = m.rows2P;
     const int ksd = mt_ksd(D);
-    char* w = (char*)workspace;
     GramParams g{};
     g.rows1P = rows1P; g.rows2P = rows2P; g.counts = counts; g.cnt_stride = cnt_stride; g.which1 = which1; g.which2 = which2;
     g.cap1 = cap1; g.cap2 = cap2;
-    unsigned long long* scratch = (unsigned long long*)w; w += 8 * a;
-    g.rowkey = (unsigned*)w; w += 4 * aP;
-    g.colkey = (unsigned*)w; w += 4 * bP;
-    float* na = (float*)w; w += 4 * a;
-    float* nb = (float*)w; w += 4 * b;
-    g.na = na; g.nb = nb;
-    g.rcnt = (int*)w; w += 4 * a;
-    g.ccnt = (int*)w; w += 4 * b;
-    g.rcand = (int*)w; w += 4 * CAND_CAP * a;
-    g.ccand = (int*)w; w += 4 * CAND_CAP * b;
-    w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
-    unsigned* maxbits = (unsigned*)w; w += 256;
+    unsigned long long* scratch = m.scratch;
+    g.rowkey = m.rowkey; g.colkey = m.colkey; g.na = m.na; g.nb = m.nb;
+    g.rcnt = m.rcnt; g.ccnt = m.ccnt; g.rcand = m.rcand; g.ccand = m.ccand;
+    unsigned* maxbits = m.words;
     g.maxbits = maxbits;
-    g.A = (const unsigned char*)w; w += aP * mt_rowb(ksd);
-    g.B = (const unsigned char*)w;
+    g.A = m.A; g.B = m.B;
+    float* na = m.na; float* nb = m.nb;
+    const OvfList ovf{reinterpret_cast<int*>(m.words + 2), m.ovf_entry};
     // enough workgroups to fill the chip twice when the lists are half full; at least one 64-wide tile per split
     int csplit = xp_cdiv(1024, (int64_t)(rows1P / MT_STRIP) * pairs);
     csplit = csplit < 1 ? 1 : (csplit > 16 ? 16 : csplit);
@@ -522,12 +699,30 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     if (ksd == 4) mt_launch<4>(g, d1, d2, D, pairs, s);
     else if (ksd == 8) mt_launch<8>(g, d1, d2, D, pairs, s);
     else mt_launch<16>(g, d1, d2, D, pairs, s);
-    hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
-                       cap1, cap2, D, g.rcnt, g.rcand, idx12, dist12);
-    hipLaunchKernelGGL(match_refine_kernel, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, d1, counts, counts, cnt_stride, which2, which1,
-                       cap2, cap1, D, g.ccnt, g.ccand, idx21, dist21);
+    hipLaunchKernelGGL(match_refine_kernel<false>, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
+                       cap1, cap2, D, g.rcnt, g.rcand, idx12, dist12, ovf, 0);
+    hipLaunchKernelGGL(match_refine_kernel<false>, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, d1, counts, counts, cnt_stride, which2, which1,
+                       cap2, cap1, D, g.ccnt, g.ccand, idx21, dist21, ovf, 1);
+    hipLaunchKernelGGL(match_overflow_kernel<false>, dim3(MT_OVF_GRID), dim3(1024), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D, ovf,
+                       idx12, dist12, idx21, dist21);
     hipLaunchKernelGGL(match_mutual_kernel, dim3(pairs), dim3(1024), 0, s, idx12, dist12, idx21, dist21, counts, counts, cnt_stride, which1,
                        which2, cap1, cap2, mode, match_q, match_t, match_d, match_count, scratch);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
+
+// Candidate-list statistics of the LATEST xp_match_mnn call that used this workspace with the same shapes: out4 (device, 4 x uint64) =
+// [sum of list lengths over live rows + columns, longest list, rows + columns that overflowed the inline list (finished by the overflow pass), live rows + columns].
+extern "C" int xp_match_stats(void* workspace, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2, int D,
+                              unsigned long long* out4, void* stream) {
+    XP_CHECK_ARG(workspace && out4, "xp_match_stats: null pointer");
+    XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D <= 256, "xp_match_stats: bad shape");
+    const MatchWs m = mt_carve(workspace, pairs, cap1, cap2, D);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(match_reset_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned*>(out4));          // 8 words (a kernel, not a memset node)
+    hipLaunchKernelGGL(match_stats_kernel, dim3(256), dim3(256), 0, s, m.rcnt, m.ccnt, counts, cnt_stride, which1, which2, cap1, cap2, pairs, out4);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_match_cand_cap(void) { return CAND_CAP; }

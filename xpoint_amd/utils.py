@@ -154,7 +154,19 @@ def match_descriptors(d1, d2, counts=None, mode="strict_mnn"):
                                 ptr(res["match_t"]), ptr(res["match_d"]), ptr(res["match_count"]), ptr(ws), ws.numel(),
                                 _lib.current_stream()), "xp_match_mnn")
     res["_ws"] = ws
+    res["_call"] = (counts, P, cap1, cap2, D)
     return res
+
+
+def match_stats(res):
+    """Nomination statistics of a match_descriptors() result (xp_match_stats): dict(mean, max, overflow_rows, rows, cand_cap) over the live rows and
+    columns of the call — what the matcher's run time depends on (its result never does)."""
+    counts, P, cap1, cap2, D = res["_call"]
+    lib = _lib.load()
+    out = torch.zeros(4, dtype=torch.int64, device=res["_ws"].device)
+    _lib.check(lib.xp_match_stats(ptr(res["_ws"]), ptr(counts), 1, 0, P, P, cap1, cap2, D, ptr(out), _lib.current_stream()), "xp_match_stats")
+    s, mx, ov, rows = (int(v) for v in out.cpu())
+    return dict(mean=s / max(rows, 1), max=mx, overflow_rows=ov, rows=rows, cand_cap=int(lib.xp_match_cand_cap()))
 
 
 def get_matches(desc_1, desc_2, method='bfmatcher', knn_matches=False, mode="strict_mnn", **kwargs):
