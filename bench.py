@@ -158,6 +158,18 @@ def visible_gpus():
         v = os.environ.get(var)
         if v is not None:
             n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    # sysfs can mislead in a container: every host GPU is listed although only some /dev/dri render nodes are mapped (count too high), or
+    # /sys/class/kfd is not mounted (count 0).  Cross-check against the render nodes; if the two disagree or sysfs is silent, ask the runtime in a
+    # SHORT-LIVED CHILD (torch.cuda.device_count() there), so that this process still never loads it.
+    import glob as _glob
+    render = len(_glob.glob("/dev/dri/renderD*"))
+    if n == 0 or (render and render < n):
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            return int(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            return min(n, render) if render else n
     return n
 
 
@@ -200,6 +212,36 @@ def self_launch(args):
     raise SystemExit(rc if rc >= 0 else 128 - rc)
 
 
+def dt_hint(region_dt):
+    return sorted(region_dt)[(len(region_dt) - 1) // 2]
+
+
+def gpu_clock_mhz():
+    """Current shader clock of the first amdgpu device, MHz (sysfs pp_dpm_sclk: the level marked '*'; rocm-smi as a fallback), or None.
+    Read before, in the middle of and after the sustained region: the matrix pipe's peak assumes 2.4 GHz, the part throttles under dense MFMA load."""
+    import glob
+    import re
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                    if m:
+                        return int(m.group(1))
+        except OSError:
+            pass
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=15)
+        m = re.search(r'"sclk clock speed:?"\s*:\s*"\((\d+)Mhz\)"', r.stdout)
+        if m:
+            return int(m.group(1))
+        m = re.search(r"sclk[^\n]*?\((\d+)Mhz\)", r.stdout + r.stderr)
+        return int(m.group(1)) if m else None
+    except Exception:
+        return None
+
+
 def main():
     global H, W
     args = parse()
@@ -211,6 +253,10 @@ def main():
         args.graph = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # every rank pins itself to the CPUs next to its GPU BEFORE torch (and with it the HIP runtime's helper threads) is loaded; never a re-exec
+    from xpoint_amd import affinity
+    pin = affinity.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))),
+                            apply=os.environ.get("XP_BENCH_NO_PIN") is None)
     global torch
     import torch
     # stdout carries exactly ONE line, the JSON: keep the real stdout for it and point fd 1 at stderr for everything else (RCCL prints its
@@ -365,6 +411,8 @@ def main():
         lib.xp_prof_enable(0)
         dom = [r for r in prof_table() if r["tag"] == dominant][0]
         pipe.verify()
+        if args.config == "c5":
+            sstep.verify()                  # the head's own status word (its forward runs from its own graph): read once, after the timed region
         if args.config != "c2" or world > 1:
             args.no_other_backend = True        # the extra passes (other back ends, precision classes, PCIe-inclusive) are single-GPU records: an N-rank run stays short
         if world > 1:
@@ -421,6 +469,50 @@ def main():
             net.gemm_mode = args.gemm
             pipe.run(opt, thr, mo, mt)          # leave the buffers holding the headline back end's results
             torch.cuda.synchronize()
+    hygiene = {}
+    if args.config == "c2" and world == 1 and not args.no_other_backend and not args.graph:
+        with torch.no_grad():
+            # (a) rotating inputs: the 64 pairs of BASELINE config C3 resident in HBM, a different batch of 8 every step (the headline region replays one batch;
+            #     other pairs carry other keypoint counts and NMS chains)
+            batches = []
+            for k in range(8):
+                d = synth.to_torch(synth.make_pair_batch(8 * k, B, H, W), dev)
+                batches.append((d["optical"]["image"], d["thermal"]["image"], d["optical"]["valid_mask"], d["thermal"]["valid_mask"]))
+            for k in range(8):
+                pipe.run(*batches[k])
+            sync_all()
+            t4 = time.perf_counter()
+            for i in range(args.steps):
+                pipe.run(*batches[i % 8])
+            sync_all()
+            hygiene["rotating_inputs_pairs_per_s"] = round(B * args.steps / (time.perf_counter() - t4), 2)
+            pipe.verify()
+            hygiene["rotating_inputs_note"] = "the same K steps cycling through pairs 0..63 (8 resident batches of 8), a different batch every step"
+            # (b) sustained: one region of >= 10 s with the shader clock read before, in the middle and after (DVFS under sustained MFMA load)
+            import threading
+            n_sus = max(args.steps, int(10.5 / (dt_hint(region_dt) / args.steps)))
+            clocks = {"before_mhz": gpu_clock_mhz()}
+            timer = threading.Timer(5.0, lambda: clocks.__setitem__("mid_region_mhz", gpu_clock_mhz()))
+            sync_all()
+            timer.start()
+            t5 = time.perf_counter()
+            for _ in range(n_sus):
+                pipe.run(opt, thr, mo, mt)
+            sync_all()
+            t_sus = time.perf_counter() - t5
+            clocks["after_mhz"] = gpu_clock_mhz()
+            timer.cancel()
+            pipe.verify()
+            hygiene["sustained_pairs_per_s"] = round(B * n_sus / t_sus, 2)
+            hygiene["sustained_region"] = {"steps": n_sus, "seconds": round(t_sus, 2), "shader_clock": clocks,
+                                           "note": "one timed region of >= 10 s on the headline schedule (same batch every step), shader clock from sysfs pp_dpm_sclk / rocm-smi"}
+            pipe.run(opt, thr, mo, mt)
+            torch.cuda.synchronize()
+    ms = pipe.match_stats()
+    hygiene["match_candidates_per_row"] = {"mean": ms["mean"], "max": ms["max"]}
+    hygiene["match_overflow_rows"] = ms["overflow_rows"]
+    hygiene["match_stats_note"] = (f"nomination lists of the last step's matcher call over {ms['rows']} live rows + columns (inline capacity {ms['inline_capacity']}; longer lists "
+                                   "go through the parallel overflow pass): the matcher's time depends on them, its result never does")
     pcie = None
     if not args.no_h2d and args.config == "c2":
         ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
@@ -444,6 +536,7 @@ def main():
     med = order[(len(order) - 1) // 2]
     dt = job_dt[med]
     rank_rates = [B * args.steps / per_rank[k][med] for k in range(len(per_rank))]
+    rank_cpus = xdist.gather_strings(str(pin.get("cpus")), device=dev) if dist.is_initialized() else [str(pin.get("cpus"))]
     if dist.is_initialized():
         # fixed-size result headers of every rank's last step, all-gathered (the only other collective)
         hdr = xdist.gather_headers(first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res),
@@ -532,6 +625,9 @@ def main():
                                      "note": "each rank's own pairs/s in the reported region (its own clock between the same barriers)"},
         }
         out.update(rccl)
+        out.update(hygiene)
+        out["rank_cpu_affinity"] = {"rank0": pin, "cpus_per_rank": rank_cpus, "note": "every rank pins itself (os.sched_setaffinity before torch is imported) to the CPUs of its GPU's NUMA node, "
+                                                           "GPUs on one node splitting them (xpoint_amd/affinity.py); the CPU baseline runs on the unpinned mask"}
         # the other large kernels of the step, each against its own bound (from the untimed single-stream breakdown pass; the
         # `roofline` object above is the dominant one, timed next to the timed region)
         tot_ms = sum(r["ms"] for r in breakdown) or 1.0
@@ -569,6 +665,8 @@ def main():
             out["pcie_inclusive_pairs_per_s"] = round(pcie, 2)
         if not args.no_cpu_baseline and world == 1:
             try:
+                if pin.get("applied"):
+                    affinity.restore(pin["previous"])
                 out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
             except Exception as e:   # the baseline must never hide the measurement
                 out["cpu_baseline"] = {"error": repr(e)}

@@ -325,6 +325,18 @@ int xp_match_mnn(const float* d1, const float* d2, const int* counts, int cnt_st
                  int cap1, int cap2, int D, int mode, int* idx12, float* dist12, int* idx21, float* dist21,
                  int* match_q, int* match_t, float* match_d, int* match_count, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* `get_matches(..., knn_matches=True)` (matching.py:20-27): cv2.BFMatcher(NORM_L2).knnMatch(d1, d2, k = 2) — the two nearest targets of every query in
+ * exact arithmetic (ties -> lower index); the caller applies Lowe's ratio test.  idx2 / dist2 (pairs, cap1, 2); a pair with fewer than two targets gets
+ * -1 / +inf in the missing slots.  Same workspace as xp_match_mnn. */
+int xp_match_knn2(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2,
+                  int D, int* idx2, float* dist2, void* workspace, size_t workspace_bytes, void* stream);
+/* `ThresholdMatcher.match` (matching.py:77-102): every (q, t) with sqrt(2 - 2 clip(<a_q, b_t>, -1, 1)) < threshold, decided in fp64 (the matrix pass only
+ * nominates).  out_pairs (out_cap, 3) = (pair, query, target) in NO particular order (the reference lists them row-major: the host wrapper sorts),
+ * out_dist (out_cap); out_count: EIGHT ints on the device, [0] = accepted pairs (> out_cap: list truncated), [1] = nominated pairs (> hit_cap: repeat with a
+ * larger `hits` scratch of hit_cap x 2 ints — accepted pairs may be missing).  0 <= threshold <= 2. */
+int xp_match_threshold(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2,
+                       int D, double threshold, int* hits, int hit_cap, int* out_pairs, float* out_dist, int* out_count, int out_cap,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* Candidate-list statistics of the latest xp_match_mnn call on `workspace` (same pairs / cap1 / cap2 / D / counts): out4 = 4 x uint64 on the device =
  * [sum of the nomination-list lengths over live rows and columns, the longest list, rows + columns whose list overflowed the inline capacity
  * (xp_match_cand_cap(); finished by the parallel overflow pass), live rows + columns].  bench.py reports them as match_candidates_per_row /

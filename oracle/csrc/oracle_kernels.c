@@ -152,3 +152,47 @@ void xo_nn_both(const float* d1, int64_t n1, const float* d2, int64_t n2, int64_
     if (dist21) for (int64_t t = 0; t < n2; ++t) dist21[t] = sqrt(col_best[t]);
     free(col_best);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * k = 2 nearest targets of every query (fp64 direct form; ties -> lower index first): what
+ * cv2.BFMatcher(NORM_L2).knnMatch(d1, d2, 2) returns per query, reference
+ * xpoint/utils/matching.py:20-27 (knn_matches + Lowe ratio).  idx (n1,2) = -1 / dist = inf where n2 < 2.
+ * ---------------------------------------------------------------------------------------- */
+void xo_knn2(const float* d1, int64_t n1, const float* d2, int64_t n2, int64_t dim, int32_t* idx, double* dist) {
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < n1; ++q) {
+        double b1 = INFINITY, b2 = INFINITY; int32_t i1 = -1, i2 = -1;
+        const float* a = d1 + q * dim;
+        for (int64_t t = 0; t < n2; ++t) {
+            const float* b = d2 + t * dim;
+            double s = 0.0;
+            for (int64_t k = 0; k < dim; ++k) { double df = (double)a[k] - (double)b[k]; s += df * df; }
+            if (s < b1) { b2 = b1; i2 = i1; b1 = s; i1 = (int32_t)t; }       /* t ascending: strict < keeps the lower index on ties */
+            else if (s < b2) { b2 = s; i2 = (int32_t)t; }
+        }
+        idx[2 * q] = i1; idx[2 * q + 1] = i2; dist[2 * q] = sqrt(b1); dist[2 * q + 1] = sqrt(b2);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ThresholdMatcher (reference xpoint/utils/matching.py:77-102): every (q, t) with
+ * sqrt(2 - 2 clip(<a_q, b_t>, -1, 1)) < threshold, row-major order.  fp64 dot products.
+ * Returns the number of pairs; writes at most `cap` of them.
+ * ---------------------------------------------------------------------------------------- */
+int64_t xo_threshold_pairs(const float* d1, int64_t n1, const float* d2, int64_t n2, int64_t dim, double threshold,
+                           int32_t* pairs, double* dist, int64_t cap) {
+    int64_t n = 0;
+    for (int64_t q = 0; q < n1; ++q) {
+        const float* a = d1 + q * dim;
+        for (int64_t t = 0; t < n2; ++t) {
+            const float* b = d2 + t * dim;
+            double s = 0.0;
+            for (int64_t k = 0; k < dim; ++k) s += (double)a[k] * (double)b[k];
+            if (s > 1.0) s = 1.0;
+            if (s < -1.0) s = -1.0;
+            const double d = sqrt(2.0 - 2.0 * s);
+            if (d < threshold) { if (n < cap) { pairs[2 * n] = (int32_t)q; pairs[2 * n + 1] = (int32_t)t; dist[n] = d; } ++n; }
+        }
+    }
+    return n;
+}

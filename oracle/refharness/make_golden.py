@@ -645,6 +645,29 @@ def gen_g22():
     print("g22 keys", len(g))
 
 
+def gen_g23():
+    """G23 — the remaining `get_matches` branches (matching.py:4-36, :77-102) through the REAL reference: `ThresholdMatcher(threshold).match` (pure
+    numpy) on the seeded unit descriptors of G8 (257 x 311 x 256) at a threshold far from any distance (the reference's float32 BLAS product is not
+    bit-pinnable at the boundary: the nearest distance to the threshold is stored so tests can see the margin), and `get_matches(..., 'nnmatcher')` with
+    its default threshold 0.7.  (knn_matches needs cv2.BFMatcher.knnMatch — absent from the image: unpinned, like BFMatcher.match itself)"""
+    torch.set_num_threads(1)
+    stubs.install()
+    import xpoint.utils as ref_utils
+    g8 = np.load(os.path.join(OUT, "g8_match.npz"))
+    d1, d2 = g8["d1"], g8["d2"]
+    g = {}
+    dm = np.sqrt(2 - 2 * np.clip(d1.astype(np.float64) @ d2.astype(np.float64).T, -1, 1))
+    for thr in (1.25, 1.3):
+        ms = ref_utils.get_matches(d1, d2, "thresholdmatcher", False, threshold=thr)
+        g[f"thr{thr}/pairs"] = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int32).reshape(-1, 2)
+        g[f"thr{thr}/dist"] = np.array([m.distance for m in ms], dtype=np.float32)
+        g[f"thr{thr}/margin"] = np.array([np.abs(dm - thr).min()])
+        print("g23 threshold", thr, len(ms), "pairs, margin", g[f"thr{thr}/margin"])
+    ms = ref_utils.get_matches(d1, d2, "nnmatcher", False)
+    g["nn0.7/pairs"] = np.array([[m.queryIdx, m.trainIdx] for m in ms], dtype=np.int32).reshape(-1, 2)
+    np.savez_compressed(os.path.join(OUT, "g23_threshold_matcher.npz"), **g)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # one generator: python -m oracle.refharness.make_golden g18part 8 22 /tmp/g18_a.npz | g18merge a.npz b.npz | g19 ...
         cmd, rest = sys.argv[1], sys.argv[2:]

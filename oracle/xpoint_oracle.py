@@ -34,6 +34,7 @@ def lib():
     if _lib is None:
         _lib = ctypes.CDLL(_build.build())
         _lib.xo_box_nms.restype = ctypes.c_int64
+        _lib.xo_threshold_pairs.restype = ctypes.c_int64
     return _lib
 
 
@@ -492,6 +493,40 @@ def get_matches(d1, d2, mode="strict_mnn", return_arrays=False):
     if return_arrays:
         return ms, dict(idx12=idx12, dist12=dist12, gap12=gap12, idx21=idx21, dist21=dist21)
     return ms
+
+
+def knn2(d1, d2):
+    """The two nearest targets of every query in exact (fp64 direct form) arithmetic, ties -> lower index: idx (n1, 2) int32, dist (n1, 2) float64."""
+    d1 = np.ascontiguousarray(d1, dtype=np.float32); d2 = np.ascontiguousarray(d2, dtype=np.float32)
+    idx = np.empty((d1.shape[0], 2), np.int32); dist = np.empty((d1.shape[0], 2), np.float64)
+    lib().xo_knn2(_p(d1), ctypes.c_int64(d1.shape[0]), _p(d2), ctypes.c_int64(d2.shape[0]), ctypes.c_int64(d1.shape[1]), _p(idx), _p(dist))
+    return idx, dist
+
+
+def knn_ratio_matches(d1, d2, ratio_thresh=0.9):
+    """matching.py:20-27: `matcher.knnMatch(desc_1, desc_2, 2)` + Lowe's ratio test `m.distance < 0.9 * n.distance` (distances as the float32 values a
+    DMatch carries, compared as Python floats).  Fewer than two targets: the reference's `for m, n in all_matches` fails to unpack -> ValueError."""
+    if d1.shape[0] == 0:
+        return []
+    if d2.shape[0] < 2:
+        raise ValueError(f"not enough values to unpack (expected 2, got {d2.shape[0]})")
+    idx, dist = knn2(d1, d2)
+    df = dist.astype(np.float32).astype(np.float64)
+    keep = df[:, 0] < ratio_thresh * df[:, 1]
+    return [Match(q, idx[q, 0], df[q, 0]) for q in np.nonzero(keep)[0]]
+
+
+def thresholdmatcher(d1, d2, threshold=0.4):
+    """matching.py:77-102 (ThresholdMatcher.match): every (q, t) with sqrt(2 - 2 clip(<a, b>, -1, 1)) < threshold in row-major order — in exact
+    (fp64) arithmetic; the reference's own float32 BLAS product is not bit-pinnable."""
+    d1 = np.ascontiguousarray(d1, dtype=np.float32); d2 = np.ascontiguousarray(d2, dtype=np.float32)
+    if d1.shape[0] == 0 or d2.shape[0] == 0:
+        return []
+    cap = d1.shape[0] * d2.shape[0]
+    pairs = np.empty((cap, 2), np.int32); dist = np.empty(cap, np.float64)
+    n = lib().xo_threshold_pairs(_p(d1), ctypes.c_int64(d1.shape[0]), _p(d2), ctypes.c_int64(d2.shape[0]), ctypes.c_int64(d1.shape[1]),
+                                 ctypes.c_double(threshold), _p(pairs), _p(dist), ctypes.c_int64(cap))
+    return [Match(a, b, c) for (a, b), c in zip(pairs[:n], dist[:n])]
 
 
 def nnmatcher(d1, d2, threshold=0.7):

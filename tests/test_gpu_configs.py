@@ -132,46 +132,56 @@ def test_c3_shard_rehearsal_ranks_0_to_7(gpu_lib, golden, capsys):
         assert int(r[1]) == len(g18[f"p{i}/kp_optical"]) and int(r[3]) == len(g18[f"p{i}/matches"])
         assert int(r[4]) == zlib.crc32(np.ascontiguousarray(g18[f"p{i}/kp_optical"]).astype("<i2").tobytes())
     net = _net(synth.xpoint_exp1_config(H, W))
-    pipe = PairPipeline(net, B, H, W, cap=8192, overlap=True, alternate_encoders=True)
     world, total = 8, 64
-    lines, tot = [], np.zeros(4, dtype=np.int64)
-    crc_equal = 0
-    for rank in range(world):
-        first, n = xdist.shard_pairs(total, world, rank)
-        assert (first, n) == (rank * B, B)
-        data = synth.to_torch(synth.make_pair_batch(first, n, H, W), "cuda")
-        with torch.no_grad():
-            pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
-            res = pipe.fetch()
-        prob, dvol = pipe.raw["prob"], pipe.raw["desc_nhwc"]
-        g = g15 if rank == 0 else g18
-        before = tot.copy()
-        for j in range(n):
-            i = first + j if rank else j
-            tot += _check_pair_lists(i, res[j]["kp_optical"].numpy(), res[j]["kp_thermal"].numpy(), res[j]["match_q"], res[j]["match_t"], g,
-                                     prob[j], prob[B + j], dvol[j], dvol[B + j], lines)
-            if rank:
-                r = hdr_tab[first + j]
-                mine = np.stack([res[j]["match_q"], res[j]["match_t"]], 1)
-                crc_equal += int(zlib.crc32(res[j]["kp_optical"].numpy().astype("<i2").tobytes()) == int(r[4])
-                                 and zlib.crc32(res[j]["kp_thermal"].numpy().astype("<i2").tobytes()) == int(r[5])
-                                 and zlib.crc32(np.ascontiguousarray(mine).astype("<i2").tobytes()) == int(r[6]))
-        # the header this rank would contribute to the all-gather
-        hdr = (first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res), sum(len(r["match_q"]) for r in res))
-        exp_kp = sum(len(g[f"p{first + j if rank else j}/kp_optical"]) + len(g[f"p{first + j if rank else j}/kp_thermal"]) for j in range(n))
-        exp_m = sum(len(g[f"p{first + j if rank else j}/matches"]) for j in range(n))
-        d = tot - before
-        if d[1] == 0 and d[3] == 0:
-            assert hdr == (first, n, exp_kp, exp_m), (rank, hdr, exp_kp, exp_m)
-        else:   # an attributed near-tie may move a count by the number of attributed elements, never more
-            assert hdr[:2] == (first, n) and abs(hdr[2] - exp_kp) <= d[1] and abs(hdr[3] - exp_m) <= d[3], (rank, hdr, exp_kp, exp_m, d)
-        lines.append(f"rank {rank}: pairs {first}..{first + n - 1}, header {hdr}, reference ({exp_kp} keypoints, {exp_m} matches)")
+    summary = {}
+    # every f32-grade dense back end (how many of the near-ties come from the split-fp16 arithmetic, how many from the reference's own
+    # f32 thread-order noise?): the default h2 carries the hard pins, x3 (exact six-product split) and f32 (exact-f32 MFMA) are counted beside it
+    for gemm_mode in ("h2", "x3", "f32"):
+        net.gemm_mode = gemm_mode
+        pipe = PairPipeline(net, B, H, W, cap=8192, overlap=True, alternate_encoders=True)
+        lines, tot = [], np.zeros(4, dtype=np.int64)
+        crc_equal = 0
+        for rank in range(world):
+            first, n = xdist.shard_pairs(total, world, rank)
+            assert (first, n) == (rank * B, B)
+            data = synth.to_torch(synth.make_pair_batch(first, n, H, W), "cuda")
+            with torch.no_grad():
+                pipe.run(data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
+                res = pipe.fetch()
+            prob, dvol = pipe.raw["prob"], pipe.raw["desc_nhwc"]
+            g = g15 if rank == 0 else g18
+            before = tot.copy()
+            for j in range(n):
+                i = first + j if rank else j
+                tot += _check_pair_lists(i, res[j]["kp_optical"].numpy(), res[j]["kp_thermal"].numpy(), res[j]["match_q"], res[j]["match_t"], g,
+                                         prob[j], prob[B + j], dvol[j], dvol[B + j], lines)
+                if rank:
+                    r = hdr_tab[first + j]
+                    mine = np.stack([res[j]["match_q"], res[j]["match_t"]], 1)
+                    crc_equal += int(zlib.crc32(res[j]["kp_optical"].numpy().astype("<i2").tobytes()) == int(r[4])
+                                     and zlib.crc32(res[j]["kp_thermal"].numpy().astype("<i2").tobytes()) == int(r[5])
+                                     and zlib.crc32(np.ascontiguousarray(mine).astype("<i2").tobytes()) == int(r[6]))
+            # the header this rank would contribute to the all-gather
+            hdr = (first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res), sum(len(r["match_q"]) for r in res))
+            exp_kp = sum(len(g[f"p{first + j if rank else j}/kp_optical"]) + len(g[f"p{first + j if rank else j}/kp_thermal"]) for j in range(n))
+            exp_m = sum(len(g[f"p{first + j if rank else j}/matches"]) for j in range(n))
+            d = tot - before
+            if d[1] == 0 and d[3] == 0:
+                assert hdr == (first, n, exp_kp, exp_m), (gemm_mode, rank, hdr, exp_kp, exp_m)
+            else:   # an attributed near-tie may move a count by the number of attributed elements, never more
+                assert hdr[:2] == (first, n) and abs(hdr[2] - exp_kp) <= d[1] and abs(hdr[3] - exp_m) <= d[3], (gemm_mode, rank, hdr, exp_kp, exp_m, d)
+            lines.append(f"rank {rank}: pairs {first}..{first + n - 1}, header {hdr}, reference ({exp_kp} keypoints, {exp_m} matches)")
+        with capsys.disabled():
+            print(f"\nC3 shard rehearsal [{gemm_mode}] (8 ranks x 8 pairs on one GPU) vs reference: {tot[0]} keypoints, {tot[1]} differ (explained); {tot[2]} mutual-NN "
+                  f"pairs, {tot[3]} differ (explained); {crc_equal} / 56 pairs of ranks 1..7 CRC-identical in all three lists")
+            if gemm_mode == "h2":
+                print("\n".join(lines))
+        assert tot[1] <= tot[0] // 200 and tot[3] <= tot[2] // 50, (gemm_mode, tot)
+        summary[gemm_mode] = (int(tot[1]), int(tot[3]), crc_equal)
     with capsys.disabled():
-        print(f"\nC3 shard rehearsal (8 ranks x 8 pairs on one GPU) vs reference: {tot[0]} keypoints, {tot[1]} differ (explained); {tot[2]} mutual-NN "
-              f"pairs, {tot[3]} differ (explained); {crc_equal} / 56 pairs of ranks 1..7 CRC-identical in all three lists")
-        print("\n".join(lines))
-    assert tot[1] <= tot[0] // 200 and tot[3] <= tot[2] // 50
-    # hard pins of today's numbers (519 595 keypoints: 6 differ; 79 848 pairs: 8 differ; 50 of 56 pairs CRC-identical): a kernel change that moves a
-    # rounding moves these (an exact-cover LayerNorm lane mapping took the CRC count to 49)
-    assert tot[1] <= 6 and tot[3] <= 8, tot
-    assert crc_equal >= 50
+        print("near-ties per dense back end (differing keypoints, differing match elements, CRC-identical pairs of 56): " +
+              ", ".join(f"{k} {v}" for k, v in summary.items()))
+    # hard pins of the default back end's numbers (519 595 keypoints: 6 differ; 79 848 pairs: 8 differ; 50 of 56 pairs CRC-identical): a kernel change that
+    # moves a rounding moves these (an exact-cover LayerNorm lane mapping took the CRC count to 49)
+    assert summary["h2"][0] <= 6 and summary["h2"][1] <= 8, summary
+    assert summary["h2"][2] >= 50

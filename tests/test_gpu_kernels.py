@@ -795,6 +795,64 @@ def test_match_trained_like_descriptors_g19(gpu_lib, golden, capsys):
             print(f"\ng19 descriptors {a} x {b}: {len(d1)} x {len(d2)}, candidates per row mean {st['mean']:.2f}, max {st['max']}, overflow rows {st['overflow_rows']}")
 
 
+def test_get_matches_knn_ratio_and_threshold_matcher(gpu_lib, golden):
+    """The remaining branches of `get_matches` (matching.py:20-27 knn + Lowe ratio 0.9; :77-102 ThresholdMatcher): the two nearest targets per query and
+    the thresholded pair list in EXACT arithmetic (fp64 oracle), the threshold list also against the real reference class (fixture g23), on well-spread,
+    clustered and duplicate-laden descriptors; reference-shaped errors for the calls the reference itself cannot make."""
+    from xpoint_amd.utils import get_matches, knn2_descriptors, threshold_pairs
+    g = golden("g23_threshold_matcher.npz"); g8 = golden("g8_match.npz")
+    d1, d2 = g8["d1"], g8["d2"]
+    for thr in (1.25, 1.3):
+        ms = get_matches(d1, d2, "thresholdmatcher", False, threshold=thr)
+        assert np.array_equal(np.array([[m.queryIdx, m.trainIdx] for m in ms], np.int32).reshape(-1, 2), g[f"thr{thr}/pairs"])
+        np.testing.assert_allclose([m.distance for m in ms], g[f"thr{thr}/dist"], atol=2e-6)
+    assert get_matches(d1, d2, "thresholdmatcher") == [] and get_matches(d1[:0], d2, "thresholdmatcher") == []      # default 0.4: nothing that close
+    nn = get_matches(d1, d2, "nnmatcher")
+    assert np.array_equal(np.array([[m.queryIdx, m.trainIdx] for m in nn], np.int32).reshape(-1, 2), g["nn0.7/pairs"])
+    # knn + ratio test vs the oracle, incl. duplicates (distance 0 twice: 0 < 0.9 * 0 is False -> dropped) and a clustered set
+    cases = [(d1, d2.copy())]
+    cases[0][1][7] = cases[0][1][3]; cases[0][1][20] = d1[5]; cases[0][1][21] = d1[5]
+    c1, c2 = _clustered(3, 1, 1500, 256, 0.35)
+    cases.append((c1[0].numpy(), c2[0].numpy()))
+    t1, t2 = _clustered(4, 1, 700, 64, 0.02)            # every list overflows
+    cases.append((t1[0].numpy(), t2[0].numpy()))
+    for a, b in cases:
+        idx, dist = xo.knn2(a, b)
+        gi, gd = knn2_descriptors(torch.from_numpy(a).cuda().unsqueeze(0), torch.from_numpy(b).cuda().unsqueeze(0))
+        assert np.array_equal(gi[0].cpu().numpy(), idx)
+        np.testing.assert_allclose(gd[0].cpu().numpy(), dist, atol=1e-6)
+        ref = xo.knn_ratio_matches(a, b)
+        ms = get_matches(a, b, "bfmatcher", True)
+        assert [(m.queryIdx, m.trainIdx) for m in ms] == [(m.queryIdx, m.trainIdx) for m in ref]
+    # threshold matcher on the clustered set vs the oracle (thousands of pairs; list growth path)
+    a, b = cases[1]
+    ref = xo.thresholdmatcher(a, b, 0.42)
+    pairs, dist = threshold_pairs(torch.from_numpy(a).cuda().unsqueeze(0), torch.from_numpy(b).cuda().unsqueeze(0), 0.42)
+    assert len(ref) > 1000 and np.array_equal(pairs[:, 1:], np.array([[m.queryIdx, m.trainIdx] for m in ref], np.int32))
+    np.testing.assert_allclose(dist, [m.distance for m in ref], atol=2e-6)
+    # batched, ragged counts
+    P, cap = 2, 300
+    e1 = np.stack([_unit(f"kn/a{i}", cap, 64) for i in range(P)]); e2 = np.stack([_unit(f"kn/b{i}", cap, 64) for i in range(P)])
+    n1, n2 = [300, 17], [250, 1]
+    counts = torch.tensor(n1 + n2, dtype=torch.int32).cuda()
+    gi, gd = knn2_descriptors(torch.from_numpy(e1).cuda(), torch.from_numpy(e2).cuda(), counts)
+    for i in range(P):
+        idx, dist = xo.knn2(e1[i, :n1[i]], e2[i, :n2[i]])
+        assert np.array_equal(gi[i, :n1[i]].cpu().numpy(), idx)
+        assert np.array_equal(np.isinf(gd[i, :n1[i]].cpu().numpy()), np.isinf(dist))
+    # the calls the reference cannot make fail the way it fails
+    with pytest.raises(ValueError):
+        get_matches(d1, d2[:1], "bfmatcher", True)
+    with pytest.raises(AttributeError):
+        get_matches(d1, d2, "nnmatcher", True)
+    with pytest.raises(RuntimeError):
+        get_matches(d1, d2, "bfmatcher", True, crossCheck=True)
+    with pytest.raises(ValueError):
+        get_matches(d1, d2, "thresholdmatcher", threshold=-1.0)
+    with pytest.raises(NotImplementedError):
+        get_matches(d1, d2, "flann")
+
+
 # ------------------------------------------------------------------------------------------------ stand-alone cross scan / merge (a7)
 def test_cross_scan_merge_ops_vs_reference_g22(gpu_lib, golden, capsys):
     """kernels.cross_scan_fn / cross_merge_fn (xp_cross_scan / xp_cross_merge) == the REAL reference's cross_scan_fn / cross_merge_fn

@@ -219,3 +219,24 @@ def test_g22_cross_scan_ops_all_layouts(golden):
     from tests import csm_cases
     n = csm_cases.check(golden("g22_cross_scan_ops.npz"), xo.cross_scan_op, xo.cross_merge_op)
     assert n >= 150, n
+
+
+def test_g23_threshold_matcher_and_knn_restatements(golden):
+    """The oracle's ThresholdMatcher restatement (exact arithmetic) == the REAL reference class on the G8 descriptors (fixture g23; thresholds with a
+    margin >> float32 BLAS noise), NNMatcher at its default threshold too; the k = 2 restatement agrees with a brute-force numpy fp64 ranking."""
+    g = golden("g23_threshold_matcher.npz"); g8 = golden("g8_match.npz")
+    d1, d2 = g8["d1"], g8["d2"]
+    for thr in (1.25, 1.3):
+        assert float(g[f"thr{thr}/margin"][0]) > 1e-5
+        ms = xo.thresholdmatcher(d1, d2, thr)
+        assert np.array_equal(np.array([[m.queryIdx, m.trainIdx] for m in ms], np.int32).reshape(-1, 2), g[f"thr{thr}/pairs"])
+        np.testing.assert_allclose([m.distance for m in ms], g[f"thr{thr}/dist"], atol=2e-6)
+    nn = xo.nnmatcher(d1, d2)
+    assert np.array_equal(np.array([[m.queryIdx, m.trainIdx] for m in nn], np.int32).reshape(-1, 2), g["nn0.7/pairs"])
+    idx, dist = xo.knn2(d1[:40], d2)
+    dm = ((d1[:40, None, :].astype(np.float64) - d2[None].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(dm, axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, order.astype(np.int32))
+    np.testing.assert_allclose(dist, np.sqrt(np.take_along_axis(dm, order, 1)), rtol=1e-12)
+    with pytest.raises(ValueError):
+        xo.knn_ratio_matches(d1, d2[:1])

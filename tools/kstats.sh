@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of one single-stream bench run; prints the kernels whose names match $1 (regex).   usage: bash tools/kstats.sh "match_|nms_"
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kst
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d ${KSTATS_ARGS} > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d ${KSTATS_ARGS} > /tmp/kst_bench.log 2>&1 || { echo "bench.py failed under rocprofv3:"; tail -5 /tmp/kst_bench.log; exit 1; }
 python3 - "$1" <<'PY'
 import csv, glob, re, sys
 f = glob.glob("/tmp/kst/**/*kernel_stats.csv", recursive=True)[0]

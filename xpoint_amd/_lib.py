@@ -74,6 +74,8 @@ _SIGNATURES = {
     "xp_extract_keypoints": [c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_sz, c_p],
     "xp_sample_descriptors": [c_p] * 4 + [c_i] * 7 + [c_p],
     "xp_match_mnn": [c_p, c_p, c_p] + [c_i] * 8 + [c_p] * 9 + [c_sz, c_p],
+    "xp_match_knn2": [c_p, c_p, c_p] + [c_i] * 7 + [c_p, c_p, c_p, c_sz, c_p],
+    "xp_match_threshold": [c_p, c_p, c_p] + [c_i] * 7 + [ctypes.c_double, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_sz, c_p],
     "xp_match_stats": [c_p, c_p] + [c_i] * 7 + [c_p, c_p],
     "xp_points_min_dist": [c_p, c_i, c_p, c_i, c_p, c_p],
     "xp_gather_match_points": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],

@@ -459,9 +459,15 @@ extern "C" int xp_round_f16(const float* x, float* y, int64_t n, void* stream) {
 static int layernorm_impl(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps, int gelu, void* stream);
 extern "C" int xp_layernorm(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps,
                             int gelu, void* stream) {
+    // mixed-precision class: LayerNorm of a half tensor returns a half tensor (statistics in f32, as here).  Only the form the model uses is
+    // implemented for it — no fused GELU (autocast rounds BETWEEN LayerNorm and GELU: the stem kernel does that itself), C a multiple of 4, y 16-byte
+    // aligned (xp_round_f16's vector form) — and anything else is refused instead of silently skipping a rounding point.
+    if (xp_amp_value()) {
+        XP_CHECK_ARG(gelu == 0, "xp_layernorm: the fused GELU has no mixed-precision form (the LayerNorm -> GELU boundary would not be rounded); use xp_stem_conv_ln_gelu or gelu = 0");
+        XP_CHECK_ARG(C % 4 == 0 && ((uintptr_t)y & 15) == 0, "xp_layernorm: mixed-precision mode needs C %% 4 == 0 and a 16-byte aligned output (C = %d)", C);
+    }
     const int rc = layernorm_impl(x, y, w, b, rows, C, eps, gelu, stream);
-    // mixed-precision class: LayerNorm of a half tensor returns a half tensor (statistics in f32, as here)
-    if (rc == XP_OK && xp_amp_value() && rows > 0 && (C % 4 == 0)) return xp_round_f16(y, y, rows * C, stream);
+    if (rc == XP_OK && xp_amp_value() && rows > 0) return xp_round_f16(y, y, rows * C, stream);
     return rc;
 }
 static int layernorm_impl(const float* x, float* y, const float* w, const float* b, int64_t rows, int C, float eps,

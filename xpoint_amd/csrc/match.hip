@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void match_convert_kernel(const float* __restr
                                                             int cnt_stride, int which1, int which2, int cap1, int cap2, int rows1P, int rows2P, int D,
                                                             const float* __restrict__ na, const float* __restrict__ nb, const unsigned* __restrict__ maxbits,
                                                             unsigned char* __restrict__ imgA, unsigned char* __restrict__ imgB,
-                                                            unsigned* __restrict__ rowkey, unsigned* __restrict__ colkey, int* __restrict__ rcnt, int* __restrict__ ccnt) {
+                                                            unsigned* __restrict__ rowkey, unsigned* __restrict__ colkey, int* __restrict__ rcnt, int* __restrict__ ccnt,
+                                                            unsigned long long* __restrict__ rowkey2) {
     constexpr int ROWB = mt_rowb(KSD);
     const int pair = blockIdx.y, side = blockIdx.z;
     const int cap = side ? cap2 : cap1, rowsP = side ? rows2P : rows1P;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void match_convert_kernel(const float* __restr
         else           { e.h[0] = one; e.h[1] = one; e.h[2] = hi; e.h[3] = lo; }
         uint4* dst = reinterpret_cast<uint4*>(row + KSD * 32);
         dst[0] = e.u[0]; dst[1] = e.u[1]; dst[2] = e.u[2];
-        if (side == 0) { rowkey[(int64_t)pair * rows1P + i] = 0u; if (i < cap1) rcnt[(int64_t)pair * cap1 + i] = 0; }
+        if (side == 0) { rowkey[(int64_t)pair * rows1P + i] = 0u; rowkey2[(int64_t)pair * rows1P + i] = 0ull; if (i < cap1) rcnt[(int64_t)pair * cap1 + i] = 0; }
         else           { colkey[(int64_t)pair * rows2P + i] = 0u; if (i < cap2) ccnt[(int64_t)pair * cap2 + i] = 0; }
     }
 }
@@ -160,18 +161,27 @@ struct GramParams {
     const float* na; const float* nb; const unsigned* maxbits;
     int* rcnt; int* ccnt; int* rcand; int* ccand;        // candidate lists (pairs, cap[, CAND_CAP])
     int csplit;
+    // knn (xp_match_knn2): rows only, thresholds hang from the SECOND largest approximate score of the row
+    unsigned long long* rowkey2;                          // [pair][rows1P]: ordered-uint (largest << 32 | second largest)
+    int knn;
+    // threshold matcher (xp_match_threshold, PASS 3): nominate a.b > c0 - E
+    float thr_c0; int* hit_count; int2* hits; int hit_cap;
 };
 
 // ---- passes 1 and 2: the Gram loop ----
-template <int KSD, int PASS>
-__global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
+// PASS 1: approximate row / column maxima (TOP2: the two largest per row, rows only — one wave per SIMD, 32 more resident registers);
+// PASS 2: nomination against them; PASS 3: nomination against a fixed inner-product threshold (ThresholdMatcher).
+__device__ __forceinline__ float mt_med3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+template <int KSD, int PASS, bool TOP2 = false>
+__global__ __launch_bounds__(256, TOP2 ? 1 : 2) void match_gram_kernel(GramParams p) {
     constexpr int KS = KSD + 1, ROWB = mt_rowb(KSD), TILEB = MT_TILE * ROWB, NPIECE = TILEB / 1024;
     static_assert(TILEB % 1024 == 0, "a tile must be whole LDS-DMA pieces");
     extern __shared__ __align__(16) unsigned char lds[];          // two target tiles | pass 2: hit queue (count word + MT_QCAP entries)
     unsigned* const q_count = reinterpret_cast<unsigned*>(lds + 2 * TILEB);
     unsigned* const q_entry = q_count + 4;
     float* const row_thr = reinterpret_cast<float*>(lds + 2 * TILEB + 16 + 4 * MT_QCAP);     // pass 2: [MT_STRIP]
-    if (PASS == 2 && threadIdx.x == 0) *q_count = 0u;             // visible to everybody after the first tile's barrier
+    if (PASS >= 2 && threadIdx.x == 0) *q_count = 0u;             // visible to everybody after the first tile's barrier
     const int pair = blockIdx.z, strip = blockIdx.y, split = blockIdx.x;
     const int n1 = count_of(p.counts, pair * p.cnt_stride + p.which1, p.cap1);
     const int n2 = count_of(p.counts, pair * p.cnt_stride + p.which2, p.cap2);
@@ -209,12 +219,13 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
     }
     // row of register r of row block rb (wave-relative): 32 rb + (r & 3) + 8 (r >> 2) + 4 h
     float rowv[2][16];     // pass 1 only: running row maxima over this workgroup's columns
+    float rowv2[TOP2 ? 2 : 1][TOP2 ? 16 : 1];     // TOP2: running second largest
     float Mx = 0.f, S2 = 1.f;
     if (PASS == 1) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rowv[rb][r] = -INFINITY;
+            for (int r = 0; r < 16; ++r) { rowv[rb][r] = -INFINITY; if (TOP2) rowv2[rb][r] = -INFINITY; }
     } else {
         // pass 2: the 256 row thresholds of the strip live in LDS (a broadcast ds_read_b128 per four accumulator registers): as
         // 32 more resident registers they pushed the kernel past the 256 of two waves per SIMD
@@ -224,8 +235,15 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
         S2 = ldexpf(1.f, -2 * ex);
         Mx = mxn * S2;
         const int row = r0 + (int)threadIdx.x;
-        const float thr = mt_unord(p.rowkey[(int64_t)pair * p.rows1P + row]) -
-                          (MT_EPS_REL * (p.na[(int64_t)pair * p.cap1 + (row < n1 ? row : n1 - 1)] * S2 + Mx) + MT_EPS_ABS);
+        const float nas = p.na[(int64_t)pair * p.cap1 + (row < n1 ? row : n1 - 1)] * S2;
+        const float Eq = MT_EPS_REL * (nas + Mx) + MT_EPS_ABS;
+        float thr;
+        if (PASS == 3) thr = p.thr_c0 * S2 - 0.5f * nas - Eq;             // a.b > c0  <=>  score + |b|^2 / 2 > c0 - |a|^2 / 2 (scaled units); the column term rides in cthr
+        else if (p.knn) {                                                  // hang the window from the row's SECOND largest approximate score; a row with
+            const unsigned lo = (unsigned)(p.rowkey2[(int64_t)pair * p.rows1P + row] & 0xffffffffull);      // one live target nominates every live one
+            thr = lo ? fmaxf(mt_unord(lo) - Eq, -1000.f) : -1000.f;        // (live scores >= -8, dead ones <= -29000: with one live target the second
+                                                                           //  largest IS a dead column's score and must not pull the dead ones in)
+        } else thr = mt_unord(p.rowkey[(int64_t)pair * p.rows1P + row]) - Eq;
         row_thr[threadIdx.x] = row < n1 ? thr : INFINITY;                 // rows past the count never nominate
     }
     unsigned* ck = p.colkey + (int64_t)pair * p.rows2P + c_begin;
@@ -239,12 +257,13 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
         for (int cb = 0; cb < 2; ++cb) {
             const int cl = t * MT_TILE + cb * 32 + fr, col = c_begin + cl;
             const int cc = col < n2 ? col : n2 - 1;               // unconditional loads, clamped (see the row thresholds)
-            const float thr = mt_unord(ck[cc - c_begin]) - (MT_EPS_REL * (p.nb[(int64_t)pair * p.cap2 + cc] * S2 + Mx) + MT_EPS_ABS);
-            out[cb] = col < n2 ? thr : INFINITY;
+            const float nbs = p.nb[(int64_t)pair * p.cap2 + cc] * S2;
+            const float thr = PASS == 3 ? -0.5f * nbs : mt_unord(ck[cc - c_begin]) - (MT_EPS_REL * (nbs + Mx) + MT_EPS_ABS);
+            out[cb] = (col < n2 && !(PASS == 2 && p.knn)) ? thr : INFINITY;
         }
     };
     float cthr[2] = {INFINITY, INFINITY}, cnext[2] = {INFINITY, INFINITY};
-    if (PASS == 2) col_thresholds(0, cnext);
+    if (PASS >= 2) col_thresholds(0, cnext);
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
         if (PASS == 1 && t > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(XP_MT_DBG & 8)) __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is done reading tile t - 1
-        if (PASS == 2) { cthr[0] = cnext[0]; cthr[1] = cnext[1]; col_thresholds(t + 1, cnext); }
+        if (PASS >= 2) { cthr[0] = cnext[0]; cthr[1] = cnext[1]; col_thresholds(t + 1, cnext); }
         if (t + 1 < ntiles && !(XP_MT_DBG & 2)) issue_tile(t + 1, buf ^ 1);
         const unsigned char* tb = lds + buf * TILEB + fr * ROWB + h * 16;
 #pragma unroll
@@ -279,7 +298,15 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
             // front of fmaxf on MFMA results).  hipcc pads no hazards for an asm statement, so the MFMA -> VALU-read wait states
             // (up to 18 for a 16-pass XDL write) are spent here, once per block, in a statement that owns both accumulators.
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
-            if (PASS == 1) {
+            if (PASS == 1 && TOP2) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        rowv2[rb][r] = mt_med3(rowv[rb][r], rowv2[rb][r], acc[rb][r]);      // rowv2 <= rowv: the median of (largest, second, new) is the new second
+                        rowv[rb][r] = mt_max(rowv[rb][r], acc[rb][r]);
+                    }
+            } else if (PASS == 1) {
                 float cm = acc[0][0];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
@@ -301,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
                 // overflow them and get spilled lane by lane; a scalar branch per register drains the instruction buffer 32 times per
                 // block): acc >= thr  <=>  sign bit of (acc - thr) clear, and v_alignbit shifts that sign bit into the mask.
                 // Element i = 16 rb + r ends up, inverted, in bit 31 - i.
-                unsigned rneg = 0u, cneg = 0u;
+                unsigned rneg = 0u, cneg = PASS == 3 ? ~0u : 0u;
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -311,8 +338,11 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float v = acc[rb][4 * g4 + q];
-                            rneg = __builtin_amdgcn_alignbit(rneg, __float_as_uint(v - rtv[q]), 31);
-                            cneg = __builtin_amdgcn_alignbit(cneg, __float_as_uint(v - cthr[cb]), 31);
+                            if (PASS == 3) rneg = __builtin_amdgcn_alignbit(rneg, __float_as_uint((v - cthr[cb]) - rtv[q]), 31);
+                            else {
+                                rneg = __builtin_amdgcn_alignbit(rneg, __float_as_uint(v - rtv[q]), 31);
+                                cneg = __builtin_amdgcn_alignbit(cneg, __float_as_uint(v - cthr[cb]), 31);
+                            }
                         }
                     }
                 const unsigned rbits = ~rneg, cbits = ~cneg;
@@ -327,7 +357,10 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
                         const unsigned e = (unsigned)cl | (rl << 16) | (hr ? 0x40000000u : 0u) | (hc ? 0x80000000u : 0u);
                         const unsigned pos = atomicAdd(q_count, 1u);
                         if (pos < MT_QCAP) q_entry[pos] = e;
-                        else {       // queue full (heavily clustered descriptors): append to the global lists from here — slow (a returning global
+                        else if (PASS == 3) {
+                            const int k = atomicAdd(p.hit_count, 1);
+                            if (k < p.hit_cap) p.hits[k] = make_int2(pair, ((r0 + (int)rl) << 16) | (c_begin + cl));
+                        } else {     // queue full (heavily clustered descriptors): append to the global lists from here — slow (a returning global
                                      // atomic per hit) but complete: round 3 flagged the row as overflowed instead, which sent it to a full scan
                             if (hr) { const int row = r0 + (int)rl; const int k = atomicAdd(&rcnt[row], 1); if (k < CAND_CAP) rcand[(int64_t)row * CAND_CAP + k] = c_begin + cl; }
                             if (hc) { const int col = c_begin + cl; const int k = atomicAdd(&ccnt[col], 1); if (k < CAND_CAP) ccand[(int64_t)col * CAND_CAP + k] = r0 + (int)rl; }
@@ -337,17 +370,46 @@ __global__ __launch_bounds__(256, 2) void match_gram_kernel(GramParams p) {
             }
         }
     }
-    if (PASS == 2) {
+    if (PASS >= 2) {
         __syncthreads();
         const unsigned nq = min(*q_count, (unsigned)MT_QCAP);
         for (unsigned i = threadIdx.x; i < nq; i += 256) {
             const unsigned e = q_entry[i];
             const int row = r0 + (int)((e >> 16) & 0x3fffu), col = c_begin + (int)(e & 0xffffu);
+            if (PASS == 3) { const int k = atomicAdd(p.hit_count, 1); if (k < p.hit_cap) p.hits[k] = make_int2(pair, (row << 16) | col); continue; }
             if (e & 0x40000000u) { const int k = atomicAdd(&rcnt[row], 1); if (k < CAND_CAP) rcand[(int64_t)row * CAND_CAP + k] = col; }
             if (e & 0x80000000u) { const int k = atomicAdd(&ccnt[col], 1); if (k < CAND_CAP) ccand[(int64_t)col * CAND_CAP + k] = row; }
         }
     }
-    if (PASS == 1) {
+    if (PASS == 1 && TOP2) {
+        // the two largest of every row over the 32 lanes (columns) of its half, then one 64-bit compare-and-swap merge per row and workgroup
+        unsigned long long* rk2 = p.rowkey2 + (int64_t)pair * p.rows1P + wr0;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m1 = rowv[rb][r], m2 = rowv2[rb][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    const float o1 = __shfl_xor(m1, o, 64), o2 = __shfl_xor(m2, o, 64);
+                    m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2)); m1 = fmaxf(m1, o1);
+                }
+                if (fr == 0) {
+                    unsigned long long* w = &rk2[32 * rb + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    const unsigned a1 = mt_ord(m1), a2 = mt_ord(m2);           // -inf maps below every score, 0 = "none yet"
+                    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        const unsigned b1 = (unsigned)(old >> 32), b2 = (unsigned)old;
+                        const unsigned n1v = a1 > b1 ? a1 : b1, lo = a1 > b1 ? b1 : a1, n2v = max(lo, max(a2, b2));
+                        const unsigned long long nw = ((unsigned long long)n1v << 32) | n2v;
+                        if (nw == old) break;
+                        const unsigned long long prev = atomicCAS(w, old, nw);
+                        if (prev == old) break;
+                        old = prev;
+                    }
+                }
+            }
+    } else if (PASS == 1) {
         // row maxima: reduce each register over the 32 lanes (columns) of its half, one atomicMax per row and workgroup
         unsigned* rk = p.rowkey + (int64_t)pair * p.rows1P + wr0;
 #pragma unroll
@@ -604,13 +666,13 @@ extern "C" size_t xp_match_workspace_bytes(int pairs, int cap1, int cap2, int D)
     const size_t a = (size_t)pairs * cap1, b = (size_t)pairs * cap2;
     const size_t aP = (size_t)pairs * mt_up(cap1, MT_STRIP), bP = (size_t)pairs * mt_up(cap2, MT_TILE);
     const size_t rowb = mt_rowb(mt_ksd(D));
-    // rowkey, colkey (u32, padded rows) | scratch (u64) | na, nb | rcnt, ccnt | rcand, ccand | overflow list (int2) | max-norm / counter words | fp16 images
-    return 4 * (aP + bP) + 8 * a + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 8 * (a + b) + 1024 + (aP + bP) * rowb;
+    // rowkey, colkey (u32, padded rows), rowkey2 (u64) | scratch (u64) | na, nb | rcnt, ccnt | rcand, ccand | overflow list (int2) | max-norm / counter words | fp16 images
+    return 4 * (aP + bP) + 8 * aP + 8 * a + 4 * (a + b) + 4 * (a + b) + 4 * CAND_CAP * (a + b) + 8 * (a + b) + 1024 + (aP + bP) * rowb;
 }
 
 // The carve-up of a workspace (shared by xp_match_mnn and xp_match_stats)
 struct MatchWs {
-    unsigned long long* scratch; unsigned* rowkey; unsigned* colkey; float* na; float* nb; int* rcnt; int* ccnt; int* rcand; int* ccand;
+    unsigned long long* scratch; unsigned long long* rowkey2; unsigned* rowkey; unsigned* colkey; float* na; float* nb; int* rcnt; int* ccnt; int* rcand; int* ccand;
     int2* ovf_entry; unsigned* words; unsigned char* A; unsigned char* B; int rows1P, rows2P;
 };
 static MatchWs mt_carve(void* workspace, int pairs, int cap1, int cap2, int D) {
@@ -621,6 +683,7 @@ static MatchWs mt_carve(void* workspace, int pairs, int cap1, int cap2, int D) {
     char* w = (char*)workspace;
     m.scratch = (unsigned long long*)w; w += 8 * a;
     m.ovf_entry = (int2*)w; w += 8 * (a + b);
+    m.rowkey2 = (unsigned long long*)w; w += 8 * aP;
     m.rowkey = (unsigned*)w; w += 4 * aP;
     m.colkey = (unsigned*)w; w += 4 * bP;
     m.na = (float*)w; w += 4 * a;
@@ -636,23 +699,60 @@ static MatchWs mt_carve(void* workspace, int pairs, int cap1, int cap2, int D) {
     return m;
 }
 
+// kind 0: mutual NN (passes 1 + 2), 1: knn (pass 1 with the two largest per row + pass 2 on rows), 2: threshold matcher (pass 3)
 template <int KSD>
-static void mt_launch(const GramParams& g, const float* d1, const float* d2, int D, int pairs, hipStream_t s) {
+static void mt_launch(const GramParams& g, const float* d1, const float* d2, int D, int pairs, int kind, hipStream_t s) {
     constexpr int ROWB = mt_rowb(KSD);
     constexpr size_t kLds = 2 * (size_t)MT_TILE * ROWB + 16 + 4 * MT_QCAP + 4 * MT_STRIP;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
         attr_set = true;
     }
     const int rowsmax = g.rows1P > g.rows2P ? g.rows1P : g.rows2P;
     hipLaunchKernelGGL(match_convert_kernel<KSD>, dim3(xp_cdiv(rowsmax, 4), pairs, 2), dim3(256), 0, s, d1, d2, g.counts, g.cnt_stride, g.which1, g.which2,
                        g.cap1, g.cap2, g.rows1P, g.rows2P, D, g.na, g.nb, g.maxbits, const_cast<unsigned char*>(g.A), const_cast<unsigned char*>(g.B),
-                       g.rowkey, g.colkey, g.rcnt, g.ccnt);
+                       g.rowkey, g.colkey, g.rcnt, g.ccnt, g.rowkey2);
     const dim3 grid(g.csplit, g.rows1P / MT_STRIP, pairs);
-    hipLaunchKernelGGL((match_gram_kernel<KSD, 1>), grid, dim3(256), kLds, s, g);
-    hipLaunchKernelGGL((match_gram_kernel<KSD, 2>), grid, dim3(256), kLds, s, g);
+    if (kind == 2) { hipLaunchKernelGGL((match_gram_kernel<KSD, 3, false>), grid, dim3(256), kLds, s, g); return; }
+    if (kind == 1) hipLaunchKernelGGL((match_gram_kernel<KSD, 1, true>), grid, dim3(256), kLds, s, g);
+    else hipLaunchKernelGGL((match_gram_kernel<KSD, 1, false>), grid, dim3(256), kLds, s, g);
+    hipLaunchKernelGGL((match_gram_kernel<KSD, 2, false>), grid, dim3(256), kLds, s, g);
+}
+
+// Shared front end: argument checks, workspace carve-up, norms, fp16 images, Gram passes of `kind`.
+static int mt_front(const char* who, const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2,
+                    int D, void* workspace, size_t workspace_bytes, int kind, GramParams& g, MatchWs& m, hipStream_t s) {
+    XP_CHECK_ARG(d1 && d2 && workspace, "%s: null pointer", who);
+    XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D % 4 == 0, "%s: bad shape (D must be a multiple of 4)", who);
+    XP_CHECK_ARG(cap1 <= 65536 && cap2 <= 65536, "%s: at most 65536 descriptors per image", who);
+    XP_CHECK_ARG(pairs <= (1 << 29), "%s: too many pairs", who);
+    XP_CHECK_ARG(D <= 256, "%s: descriptor size %d > 256 (the query strip is register resident; the reference's models use 64 and 256)", who, D);
+    XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2, D), "%s: workspace too small", who);
+    XP_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "%s: workspace must be 16-byte aligned", who);
+    m = mt_carve(workspace, pairs, cap1, cap2, D);
+    g.rows1P = m.rows1P; g.rows2P = m.rows2P; g.counts = counts; g.cnt_stride = cnt_stride; g.which1 = which1; g.which2 = which2;
+    g.cap1 = cap1; g.cap2 = cap2;
+    g.rowkey = m.rowkey; g.colkey = m.colkey; g.rowkey2 = m.rowkey2; g.na = m.na; g.nb = m.nb;
+    g.rcnt = m.rcnt; g.ccnt = m.ccnt; g.rcand = m.rcand; g.ccand = m.ccand;
+    g.maxbits = m.words; g.A = m.A; g.B = m.B; g.knn = kind == 1;
+    // enough workgroups to fill the chip twice when the lists are half full; at least one 64-wide tile per split
+    int csplit = xp_cdiv(1024, (int64_t)(m.rows1P / MT_STRIP) * pairs);
+    csplit = csplit < 1 ? 1 : (csplit > 16 ? 16 : csplit);
+    if (csplit > m.rows2P / MT_TILE) csplit = m.rows2P / MT_TILE;
+    g.csplit = csplit;
+    hipLaunchKernelGGL(match_reset_kernel, dim3(1), dim3(64), 0, s, m.words);
+    const int capmax = cap1 > cap2 ? cap1 : cap2;
+    hipLaunchKernelGGL(match_norms_kernel, dim3(xp_cdiv(capmax, 64), pairs, 2), dim3(256), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D,
+                       m.na, m.nb, m.words);
+    const int ksd = mt_ksd(D);
+    if (ksd == 4) mt_launch<4>(g, d1, d2, D, pairs, kind, s);
+    else if (ksd == 8) mt_launch<8>(g, d1, d2, D, pairs, kind, s);
+    else mt_launch<16>(g, d1, d2, D, pairs, kind, s);
+    return XP_OK;
 }
 
 // d1 (pairs, cap1, D), d2 (pairs, cap2, D); counts: device int array, n1 of pair i at counts[i*cnt_stride + which1]
@@ -662,43 +762,14 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
                             int pairs, int cap1, int cap2, int D, int mode, int* idx12, float* dist12, int* idx21,
                             float* dist21, int* match_q, int* match_t, float* match_d, int* match_count, void* workspace,
                             size_t workspace_bytes, void* stream) {
-    XP_CHECK_ARG(d1 && d2 && idx12 && dist12 && idx21 && dist21 && match_q && match_t && match_d && match_count && workspace,
-                 "xp_match_mnn: null pointer");
-    XP_CHECK_ARG(pairs > 0 && cap1 > 0 && cap2 > 0 && D > 0 && D % 4 == 0, "xp_match_mnn: bad shape (D must be a multiple of 4)");
-    XP_CHECK_ARG(cap1 <= 65536 && cap2 <= 65536, "xp_match_mnn: at most 65536 descriptors per image");
-    XP_CHECK_ARG(pairs <= (1 << 29), "xp_match_mnn: too many pairs");
-    XP_CHECK_ARG(D <= 256, "xp_match_mnn: descriptor size %d > 256 (the query strip is register resident; the reference's models use 64 and 256)", D);
+    XP_CHECK_ARG(idx12 && dist12 && idx21 && dist21 && match_q && match_t && match_d && match_count, "xp_match_mnn: null pointer");
     XP_CHECK_ARG(mode == 0 || mode == 1, "xp_match_mnn: mode 0 (strict_mnn) or 1 (legacy_crosscheck)");
-    XP_CHECK_ARG(workspace_bytes >= xp_match_workspace_bytes(pairs, cap1, cap2, D), "xp_match_mnn: workspace too small");
-    XP_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "xp_match_mnn: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const MatchWs m = mt_carve(workspace, pairs, cap1, cap2, D);
-    const int rows1P = m.rows1P, rows2P = m.rows2P;
-    const int ksd = mt_ksd(D);
-    GramParams g{};
-    g.rows1P = rows1P; g.rows2P = rows2P; g.counts = counts; g.cnt_stride = cnt_stride; g.which1 = which1; g.which2 = which2;
-    g.cap1 = cap1; g.cap2 = cap2;
-    unsigned long long* scratch = m.scratch;
-    g.rowkey = m.rowkey; g.colkey = m.colkey; g.na = m.na; g.nb = m.nb;
-    g.rcnt = m.rcnt; g.ccnt = m.ccnt; g.rcand = m.rcand; g.ccand = m.ccand;
-    unsigned* maxbits = m.words;
-    g.maxbits = maxbits;
-    g.A = m.A; g.B = m.B;
-    float* na = m.na; float* nb = m.nb;
-    const OvfList ovf{reinterpret_cast<int*>(m.words + 2), m.ovf_entry};
-    // enough workgroups to fill the chip twice when the lists are half full; at least one 64-wide tile per split
-    int csplit = xp_cdiv(1024, (int64_t)(rows1P / MT_STRIP) * pairs);
-    csplit = csplit < 1 ? 1 : (csplit > 16 ? 16 : csplit);
-    if (csplit > rows2P / MT_TILE) csplit = rows2P / MT_TILE;
-    g.csplit = csplit;
     XpProfScope prof("match_mnn", s, 0.0, 0.0);   // work depends on device-side counts: bench.py prices it from the fetched counts
-    hipLaunchKernelGGL(match_reset_kernel, dim3(1), dim3(64), 0, s, maxbits);
-    const int capmax = cap1 > cap2 ? cap1 : cap2;
-    hipLaunchKernelGGL(match_norms_kernel, dim3(xp_cdiv(capmax, 64), pairs, 2), dim3(256), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D,
-                       na, nb, maxbits);
-    if (ksd == 4) mt_launch<4>(g, d1, d2, D, pairs, s);
-    else if (ksd == 8) mt_launch<8>(g, d1, d2, D, pairs, s);
-    else mt_launch<16>(g, d1, d2, D, pairs, s);
+    GramParams g{}; MatchWs m{};
+    const int rc = mt_front("xp_match_mnn", d1, d2, counts, cnt_stride, which1, which2, pairs, cap1, cap2, D, workspace, workspace_bytes, 0, g, m, s);
+    if (rc != XP_OK) return rc;
+    const OvfList ovf{reinterpret_cast<int*>(m.words + 2), m.ovf_entry};
     hipLaunchKernelGGL(match_refine_kernel<false>, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
                        cap1, cap2, D, g.rcnt, g.rcand, idx12, dist12, ovf, 0);
     hipLaunchKernelGGL(match_refine_kernel<false>, dim3(xp_cdiv(cap2, 4), pairs), dim3(256), 0, s, d2, d1, counts, counts, cnt_stride, which2, which1,
@@ -706,7 +777,77 @@ extern "C" int xp_match_mnn(const float* d1, const float* d2, const int* counts,
     hipLaunchKernelGGL(match_overflow_kernel<false>, dim3(MT_OVF_GRID), dim3(1024), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D, ovf,
                        idx12, dist12, idx21, dist21);
     hipLaunchKernelGGL(match_mutual_kernel, dim3(pairs), dim3(1024), 0, s, idx12, dist12, idx21, dist21, counts, counts, cnt_stride, which1,
-                       which2, cap1, cap2, mode, match_q, match_t, match_d, match_count, scratch);
+                       which2, cap1, cap2, mode, match_q, match_t, match_d, match_count, m.scratch);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+// cv2.BFMatcher(NORM_L2).knnMatch(d1, d2, k = 2) of reference matching.py:20-21: the two nearest targets of every query in exact arithmetic (ties ->
+// lower index).  idx2 / dist2 (pairs, cap1, 2); a pair with fewer than two targets gets idx -1 / dist +inf in the missing slots.
+extern "C" int xp_match_knn2(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2,
+                             int D, int* idx2, float* dist2, void* workspace, size_t workspace_bytes, void* stream) {
+    XP_CHECK_ARG(idx2 && dist2, "xp_match_knn2: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    XpProfScope prof("match_knn2", s, 0.0, 0.0);
+    GramParams g{}; MatchWs m{};
+    const int rc = mt_front("xp_match_knn2", d1, d2, counts, cnt_stride, which1, which2, pairs, cap1, cap2, D, workspace, workspace_bytes, 1, g, m, s);
+    if (rc != XP_OK) return rc;
+    const OvfList ovf{reinterpret_cast<int*>(m.words + 2), m.ovf_entry};
+    hipLaunchKernelGGL(match_refine_kernel<true>, dim3(xp_cdiv(cap1, 4), pairs), dim3(256), 0, s, d1, d2, counts, counts, cnt_stride, which1, which2,
+                       cap1, cap2, D, g.rcnt, g.rcand, idx2, dist2, ovf, 0);
+    hipLaunchKernelGGL(match_overflow_kernel<true>, dim3(MT_OVF_GRID), dim3(1024), 0, s, d1, d2, counts, cnt_stride, which1, which2, cap1, cap2, D, ovf,
+                       idx2, dist2, (int*)nullptr, (float*)nullptr);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+// ThresholdMatcher (reference matching.py:77-102): every (q, t) with sqrt(2 - 2 clip(<a_q, b_t>, -1, 1)) < threshold.  The matrix pass nominates pairs whose
+// fp16 inner product is within the proven error of the threshold, this kernel decides each in fp64 (one wave per nominated pair) and appends the accepted ones.
+__global__ __launch_bounds__(256) void match_threshold_verify_kernel(const float* __restrict__ d1, const float* __restrict__ d2, int cap1, int cap2, int D,
+                                                                     const int* __restrict__ hit_count, const int2* __restrict__ hits, int hit_cap,
+                                                                     double threshold, int* __restrict__ out_pairs, float* __restrict__ out_dist,
+                                                                     int* __restrict__ out_count, int out_cap) {
+    const int nh = min(*hit_count, hit_cap);
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nh; i += gridDim.x * 4) {
+        const int2 hte = hits[i];
+        const int pair = hte.x, q = (int)((unsigned)hte.y >> 16), t = hte.y & 0xffff;
+        const float* a = d1 + ((int64_t)pair * cap1 + q) * D; const float* b = d2 + ((int64_t)pair * cap2 + t) * D;
+        double sdot = 0.0;
+        for (int k = lane * 4; k < D; k += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(a + k), y = *reinterpret_cast<const float4*>(b + k);
+            sdot = fma((double)x.x, (double)y.x, sdot); sdot = fma((double)x.y, (double)y.y, sdot);
+            sdot = fma((double)x.z, (double)y.z, sdot); sdot = fma((double)x.w, (double)y.w, sdot);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+        sdot = sdot > 1.0 ? 1.0 : (sdot < -1.0 ? -1.0 : sdot);
+        const double dist = sqrt(2.0 - 2.0 * sdot);
+        if (lane == 0 && dist < threshold) {
+            const int k = atomicAdd(out_count, 1);
+            if (k < out_cap) { out_pairs[3 * k] = pair; out_pairs[3 * k + 1] = q; out_pairs[3 * k + 2] = t; out_dist[k] = (float)dist; }
+        }
+    }
+}
+
+// out_pairs (out_cap, 3) = (pair, query, target) in NO particular order (the host wrapper sorts them into the reference's row-major order), out_dist (out_cap),
+// out_count[0] = accepted pairs (may exceed out_cap: the list was truncated), out_count[1] = nominated pairs (if > hit_cap the call must be repeated with a
+// larger hit list: accepted pairs may be missing).  hits: caller-owned (hit_cap, 2) int32 scratch.  threshold <= 2 (beyond it every pair matches).
+extern "C" int xp_match_threshold(const float* d1, const float* d2, const int* counts, int cnt_stride, int which1, int which2, int pairs, int cap1, int cap2,
+                                  int D, double threshold, int* hits, int hit_cap, int* out_pairs, float* out_dist, int* out_count, int out_cap,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    XP_CHECK_ARG(hits && out_pairs && out_dist && out_count && hit_cap > 0 && out_cap > 0, "xp_match_threshold: null pointer / empty output");
+    XP_CHECK_ARG(threshold >= 0.0 && threshold <= 2.0, "xp_match_threshold: threshold %g outside [0, 2] (unit descriptors: distances lie in [0, 2])", threshold);
+    hipStream_t s = (hipStream_t)stream;
+    XpProfScope prof("match_threshold", s, 0.0, 0.0);
+    GramParams g{}; MatchWs m{};
+    g.thr_c0 = (float)(1.0 - 0.5 * threshold * threshold) - 1e-6f;        // a.b > c0 (rounded down: the window below only widens)
+    g.hit_count = out_count + 1; g.hits = reinterpret_cast<int2*>(hits); g.hit_cap = hit_cap;
+    hipLaunchKernelGGL(match_reset_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned*>(out_count));       // zeroes 8 words: out_count must hold 8 ints
+    const int rc = mt_front("xp_match_threshold", d1, d2, counts, cnt_stride, which1, which2, pairs, cap1, cap2, D, workspace, workspace_bytes, 2, g, m, s);
+    if (rc != XP_OK) return rc;
+    hipLaunchKernelGGL(match_threshold_verify_kernel, dim3(1024), dim3(256), 0, s, d1, d2, cap1, cap2, D, out_count + 1, reinterpret_cast<const int2*>(hits), hit_cap,
+                       threshold, out_pairs, out_dist, out_count, out_cap);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }

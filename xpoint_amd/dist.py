@@ -106,3 +106,17 @@ def gather_headers(first_pair: int, pairs: int, keypoints: int, matches: int, de
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, mine, group=group)
     return [tuple(int(v) for v in t.tolist()) for t in out]
+
+
+def gather_strings(text: str, device=None, group=None, width: int = 256):
+    """All-gather of one short string per rank (e.g. the rank's CPU-affinity mask) as fixed-width byte tensors: returns [rank] -> str."""
+    import torch.distributed as dist
+    raw = text.encode()[:width]
+    mine = torch.zeros(width, dtype=torch.uint8, device=torch.device(device) if device is not None else torch.device("cpu"))
+    if raw:
+        mine[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    if not dist.is_initialized():
+        return [text[:width]]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return [bytes(t.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for t in out]

@@ -284,6 +284,8 @@ class XPoint(torch.nn.Module):
         assert blob.is_cuda and blob.dtype == torch.float32 and blob.numel() == self.weights_numel()
         self._blob = blob.contiguous()
         self._wsplit = None
+        self._amp_w = {}                  # derived copies of the OLD weights (fp16-rounded blob, its split planes) must not survive a new blob
+        self._h2_off = False              # and a new weight set gets the default engine back, as in load_state_dict
         self._device = blob.device
 
     def to(self, device=None, *a, **k):

@@ -165,6 +165,7 @@ class PairPipeline:
                            n_inliers=torch.zeros((P,), dtype=torch.int32, device=dev),
                            ws=torch.empty(lib.xp_find_homography_workspace_bytes(P) // 8 + 1, dtype=torch.float64, device=dev))
         self.raw = None
+        self.repaired = False        # set by verify(): the latest call was recomputed (range guard): earlier host downloads of it are stale
         self._last = None            # (buffer set, masked) of the latest call: what verify() re-runs when the range guard trips
         self._graphs = None
         self._capture_masked = None
@@ -292,6 +293,18 @@ class PairPipeline:
                                               float(self.pred.get('reprojection_threshold', 3.0)), self.ransac_iters, 0, ptr(h["H"]), ptr(h["mask"]),
                                               ptr(h["n_inliers"]), ptr(h["ws"]), h["ws"].numel() * 8, st), "xp_find_homography")
         return self
+
+    def match_stats(self):
+        """Nomination statistics of the latest step's matcher call (xp_match_stats): what its run time depends on (clustered descriptors nominate
+        more), never its result.  Synchronises."""
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            lib = _lib.load()
+            out = torch.zeros(4, dtype=torch.int64, device=self.device)
+            _lib.check(lib.xp_match_stats(ptr(self.match_ws), ptr(self.counts), 1, 0, self.B, self.B, self.cap, self.cap, self.D, ptr(out),
+                                          _lib.current_stream()), "xp_match_stats")
+            s, mx, ov, rows = (int(v) for v in out.cpu())
+        return dict(mean=round(s / max(rows, 1), 3), max=mx, overflow_rows=ov, rows=rows, inline_capacity=int(lib.xp_match_cand_cap()))
 
     def wait(self):
         """Make the caller's current stream wait for everything run() has enqueued so far (overlapped mode: the
@@ -443,7 +456,11 @@ class PairPipeline:
         lib = _lib.load()
         # range guard of the split-fp16 dense engine (include/xpoint_hip.h, xp_xpoint_forward_ex): the forwards' status word.  A trip re-runs the
         # latest call on "x3" (and keeps that engine), so the checks below — and the caller — see the repaired results.
-        self._settle_engine()
+        # SCOPE of the repair: only the LATEST call (self._last) is recomputed; earlier calls still in flight when the guard tripped (depth 2-3
+        # bursts, streaming) ran on the overflowed engine and are NOT recomputed — a caller that keeps several steps in flight must treat every step
+        # since its last verify() as suspect.  Host buffers already filled by download_async() are stale after a repair: `self.repaired` is set and the
+        # caller must call download_async() again for the latest step (bufs["status"] != 0 is the trigger, see download_async).
+        self.repaired = self._settle_engine()
         if self.pred['nms'] > 0:
             left = c_i(-1)
             _lib.check(lib.xp_box_nms_check(ptr(self.nms_ws), 2 * self.B, self.H, self.W, ctypes.byref(left), _lib.current_stream()),

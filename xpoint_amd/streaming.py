@@ -43,7 +43,9 @@ class StreamingRegistrationStep:
 
     def __call__(self, optical, thermal, mask_optical=None, mask_thermal=None):
         """Enqueue one step.  Returns (bufs, event, hm_host, hm_event): pinned host buffers of THIS step, valid after the two events.
-        bufs["status"] != 0 (forward status word, see PairPipeline.download_async) means the caller must run pipe.verify()."""
+        bufs["status"] != 0 (forward status word, see PairPipeline.download_async) means the caller must run verify() — and, when verify() reports
+        `pipe.repaired`, fetch the latest step's lists again (pipe.download_async()): the pinned buffers it already holds were filled BEFORE the repair.
+        Steps before the latest one are not recomputed by verify() (PairPipeline.verify)."""
         pipe = self.pipe
         with torch.cuda.device(pipe.device), torch.no_grad():
             self.replay(optical, thermal, mask_optical, mask_thermal)

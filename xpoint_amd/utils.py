@@ -169,23 +169,89 @@ def match_stats(res):
     return dict(mean=s / max(rows, 1), max=mx, overflow_rows=ov, rows=rows, cand_cap=int(lib.xp_match_cand_cap()))
 
 
+def knn2_descriptors(d1, d2, counts=None):
+    """Batched device-side k = 2 nearest neighbours (xp_match_knn2): idx (P,cap1,2) int32, dist (P,cap1,2) float32."""
+    P, cap1, D = d1.shape
+    cap2 = d2.shape[1]
+    lib = _lib.load()
+    idx = torch.empty((P, cap1, 2), dtype=torch.int32, device=d1.device); dist = torch.empty((P, cap1, 2), device=d1.device)
+    ws = torch.empty(lib.xp_match_workspace_bytes(P, cap1, cap2, D), dtype=torch.uint8, device=d1.device)
+    d1, d2 = d1.contiguous(), d2.contiguous()
+    _lib.check(lib.xp_match_knn2(ptr(d1), ptr(d2), ptr(counts), 1, 0, P, P, cap1, cap2, D, ptr(idx), ptr(dist), ptr(ws), ws.numel(), _lib.current_stream()),
+               "xp_match_knn2")
+    return idx, dist
+
+
+def threshold_pairs(d1, d2, threshold, counts=None):
+    """Batched device-side ThresholdMatcher (xp_match_threshold): (pair, query, target) int32 rows sorted row-major per pair, and their distances."""
+    P, cap1, D = d1.shape
+    cap2 = d2.shape[1]
+    lib = _lib.load()
+    dev = d1.device
+    d1, d2 = d1.contiguous(), d2.contiguous()
+    ws = torch.empty(lib.xp_match_workspace_bytes(P, cap1, cap2, D), dtype=torch.uint8, device=dev)
+    cap = max(4096, 4 * P * max(cap1, cap2))
+    while True:
+        hits = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        out = torch.empty((cap, 3), dtype=torch.int32, device=dev); dist = torch.empty((cap,), device=dev)
+        cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+        _lib.check(lib.xp_match_threshold(ptr(d1), ptr(d2), ptr(counts), 1, 0, P, P, cap1, cap2, D, float(threshold), ptr(hits), cap, ptr(out), ptr(dist), ptr(cnt),
+                                          cap, ptr(ws), ws.numel(), _lib.current_stream()), "xp_match_threshold")
+        n_out, n_hit = int(cnt[0].item()), int(cnt[1].item())
+        if n_hit <= cap and n_out <= cap:
+            break
+        cap = max(n_hit, n_out) + 1024                      # the lists were truncated: repeat with room for everything (counts are exact)
+    out = out[:n_out].cpu().numpy(); dist = dist[:n_out].cpu().numpy()
+    order = np.lexsort((out[:, 2], out[:, 1], out[:, 0]))
+    return out[order], dist[order]
+
+
+def _as_device_f32(d):
+    dev = d.device if (torch.is_tensor(d) and d.is_cuda) else torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(np.ascontiguousarray(d) if isinstance(d, np.ndarray) else d).to(dev).float()
+
+
 def get_matches(desc_1, desc_2, method='bfmatcher', knn_matches=False, mode="strict_mnn", **kwargs):
-    """desc_1 (N1,D), desc_2 (N2,D): numpy arrays (as the reference passes them) or torch tensors.
+    """desc_1 (N1,D), desc_2 (N2,D): numpy arrays (as the reference passes them) or torch tensors (matching.py:4-36).
     method 'bfmatcher' with crossCheck=True (configs/cipdp.yaml:57-61) -> list of DMatch in ascending queryIdx;
     `mode` picks the cross-check semantics: 'strict_mnn' (default) or 'legacy_crosscheck'.
-    'nnmatcher' = strict mutual NN with the reference's distance threshold (matching.py:38-75)."""
-    if method not in ('bfmatcher', 'nnmatcher'):
-        if method in ('flann', 'thresholdmatcher'):
-            raise NotImplementedError(f"matching method '{method}' is out of scope (not selected by configs/cipdp.yaml)")
+    'nnmatcher' = strict mutual NN with the reference's distance threshold (matching.py:38-75).
+    'thresholdmatcher' = every pair with sqrt(2 - 2 <a, b>) < threshold (default 0.4), row-major (matching.py:77-102).
+    knn_matches=True ('bfmatcher'): the two nearest targets of every query + Lowe's ratio test `m.distance < 0.9 * n.distance` (matching.py:20-27).
+    'flann' (cv2.FlannBasedMatcher: randomised kd-trees, approximate, no reference semantics to reproduce) raises."""
+    if method not in ('bfmatcher', 'nnmatcher', 'thresholdmatcher'):
+        if method == 'flann':
+            raise NotImplementedError("matching method 'flann' is an approximate randomised search in OpenCV: there is no result to reproduce (use 'bfmatcher')")
         raise ValueError('unknown matching method')
+    if method == 'nnmatcher' and float(kwargs.get('threshold', 0.7)) < 0.0 or method == 'thresholdmatcher' and float(kwargs.get('threshold', 0.4)) < 0.0:
+        raise ValueError("'threshold' should be non-negative")                          # matching.py:41-42, :80-81
     if knn_matches:
-        raise NotImplementedError("knn_matches (Lowe ratio) is out of scope (configs/cipdp.yaml: knn_matches False)")
+        if method != 'bfmatcher':
+            raise AttributeError(f"'{'NNMatcher' if method == 'nnmatcher' else 'ThresholdMatcher'}' object has no attribute 'knnMatch'")   # what the reference does
+        if kwargs.get('crossCheck', False):
+            raise RuntimeError("BFMatcher.knnMatch with crossCheck=True requires k == 1 (OpenCV asserts); the reference calls it with k = 2")
+        if desc_1.shape[0] == 0:
+            return []
+        if desc_2.shape[0] < 2:       # knnMatch returns shorter lists and the reference's `for m, n in all_matches` fails to unpack
+            raise ValueError(f"not enough values to unpack (expected 2, got {desc_2.shape[0]})")
+        t1, t2 = _as_device_f32(desc_1), _as_device_f32(desc_2)
+        with torch.cuda.device(t1.device):
+            idx, dist = knn2_descriptors(t1.unsqueeze(0), t2.unsqueeze(0))
+        idx = idx[0].cpu().numpy(); dist = dist[0].cpu().numpy().astype(np.float64)      # DMatch.distance is a float32 value; Python compares doubles
+        keep = dist[:, 0] < 0.9 * dist[:, 1]                                              # ratio_thresh = 0.9 (matching.py:23-26)
+        return [DMatch(q, idx[q, 0], dist[q, 0]) for q in np.nonzero(keep)[0]]
     if desc_1.shape[0] == 0 or desc_2.shape[0] == 0:
         return []
     # device tensors are matched where they live; host arrays (what the reference passes) go to the current device
-    dev = desc_1.device if (torch.is_tensor(desc_1) and desc_1.is_cuda) else torch.device("cuda", torch.cuda.current_device())
-    t1 = torch.as_tensor(np.ascontiguousarray(desc_1) if isinstance(desc_1, np.ndarray) else desc_1).to(dev).float()
-    t2 = torch.as_tensor(np.ascontiguousarray(desc_2) if isinstance(desc_2, np.ndarray) else desc_2).to(dev).float()
+    t1, t2 = _as_device_f32(desc_1), _as_device_f32(desc_2)
+    dev = t1.device
+    if method == 'thresholdmatcher':
+        thr = float(kwargs.get('threshold', 0.4))
+        if thr > 2.0:
+            raise ValueError("thresholdmatcher: threshold > 2 accepts every pair of unit descriptors")
+        with torch.cuda.device(dev):
+            pairs, dist = threshold_pairs(t1.unsqueeze(0), t2.unsqueeze(0), thr)
+        return [DMatch(a, b, c) for (_, a, b), c in zip(pairs, dist)]
     with torch.cuda.device(dev):
         res = match_descriptors(t1.unsqueeze(0), t2.unsqueeze(0), None, mode)
     if method == 'bfmatcher' and not kwargs.get('crossCheck', False):
