@@ -135,6 +135,19 @@ int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const float* bias, 
                   const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
 int xp_conv3x3_nhwc_h2(const float* x, const void* Wh2, float* y, const float* bias, const float* scale, const float* shift,
                        int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * fp16-STORAGE dense kernels of the fast mixed-precision class (csrc/gemm_f16.hip): the reference's `mixed_precision: true` deployment
+ * (xpoint/models/XPoint.py:182 autocast) with half tensors in HBM.  A (M, lda) and W (N, K) are fp16, K-contiguous; one exact fp16 product per multiply on
+ * v_mfma_f32_32x32x16_f16, f32 accumulate;  C = r16( r16( act( r16(acc + bias) ) * scale + shift ) + res )  with r16 = round to nearest fp16 at every
+ * point where autocast ends in a half tensor (absent terms drop out with their rounding); res (M, ldres) fp16; C fp16, or f32 holding the fp16-exact values
+ * when c_f32 != 0 (the heads' `.to(torch.float)`, XPoint.py:349,363).  act as xp_gemm_nt.  K, lda multiples of 8; buffers 16-byte aligned. */
+int xp_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+int xp_gemm_nt_f16(const void* A, const void* W, void* C, int c_f32, const float* bias, const float* scale, const float* shift, const void* res,
+                   int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
+/* 3x3 convolution (stride 1 | 2, zero or reflection pad 1) over NHWC halves as an implicit GEMM of the same kernel; W (Co, 3, 3, Ci) fp16; Ci % 8 == 0. */
+int xp_conv3x3_nhwc_f16(const void* x, const void* W, void* y, int y_f32, const float* bias, const float* scale, const float* shift,
+                        int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
+
 /* Precision class of the "x3" kernels (xp_gemm_nt_x3, xp_conv3x3_nhwc_x3, xp_mlp_fused_x3 and every dense layer of
  * xp_xpoint_forward with wsplit != NULL), process-wide, read at launch time:
  *   6 (default)  all six partial products of weight >= 2^-16: f32-grade (the class pinned against the reference, 1e-4 bar)

@@ -295,3 +295,83 @@ def test_gemm_h2p_default_path(gpu_lib):
         assert err < 2e-5 * max(1.0, float(ref.abs().max())), (N, K, err)
         for m in (600, 300, 37):
             assert torch.equal(out[m], out[M][:m]), (N, K, m)
+
+
+# ------------------------------------------------------------------------------------------------ fp16-storage kernels of the fast mixed-precision class
+def _r16(t):
+    return t.half().double()
+
+
+def _f16_ref(A16, W16, bias, scale, shift, R16, act, acc=None):
+    """The epilogue recipe of csrc/gemm_f16.hip in float64 on the exact fp16 operands: r16(r16(act(r16(acc + bias))) * scale + shift) + res -> r16.
+    Returns (result, mag): mag = the largest magnitude an element had at any rounding point — a one-ulp difference at an earlier point (f32 accumulation
+    order) survives a cancelling affine / residual step at full size, so errors are measured in fp16 ulps of mag, not of the result."""
+    if acc is None:
+        acc = F.linear(A16.double(), W16.double())
+    v = _r16((acc + (0 if bias is None else bias.double())).float())
+    mag = v.abs()
+    if act == 1:
+        v = _r16(F.gelu(v).float())
+    if act == 2:
+        v = v.clamp_min(0)
+    if scale is not None:
+        mag = torch.maximum(mag, (v * scale.double()).abs())
+        v = _r16((v * scale.double() + shift.double()).float())
+    if act == 3:
+        v = v.clamp_min(0)
+    if R16 is not None:
+        v = _r16((v + R16.double()).float())
+    return v, torch.maximum(mag, v.abs())
+
+
+def _ulp16(x):
+    return torch.clamp(x.abs(), min=2.0 ** -14) * 2.0 ** -10
+
+
+@pytest.mark.parametrize("M,N,K,act,res,bn,cf32", [(300, 96, 96, 0, True, False, False), (1000, 32, 96, 0, False, False, False), (517, 56, 192, 0, False, False, False),
+                                                  (260, 384, 96, 1, False, False, False), (260, 96, 384, 0, True, False, False), (130, 768, 768, 0, False, False, False),
+                                                  (4800, 3072, 768, 1, False, False, False), (333, 65, 256, 0, False, True, True), (200, 200, 768, 0, False, False, False),
+                                                  (777, 256, 256, 2, False, True, True), (129, 104, 384, 0, False, False, False), (19200, 384, 1536, 0, True, False, False)])
+def test_gemm_f16(gpu_lib, M, N, K, act, res, bn, cf32):
+    """xp_gemm_nt_f16 == the autocast recipe evaluated in float64 on the same fp16 operands, to within one fp16 ulp of the result on a vanishing fraction of
+    elements (the f32 accumulation order before a rounding point) and bit-equal elsewhere; rows / columns past the matrix untouched; f32 outputs carry
+    fp16-exact values."""
+    L = _lib()
+    A = _u(f"fA{M}{N}{K}", (M, K)).half(); W = _u(f"fW{M}{N}{K}", (N, K), -0.1, 0.1).half(); b = _u(f"fb{M}{N}{K}", (N,))
+    R = _u(f"fr{M}{N}{K}", (M, N)).half() if res else None
+    sc = _u(f"fs{M}{N}{K}", (N,), 0.5, 1.5) if bn else None; sh = _u(f"ft{M}{N}{K}", (N,)) if bn else None
+    ref, mag = _f16_ref(A, W, b, sc, sh, R, act)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    scd, shd, Rd = (sc.cuda() if bn else None), (sh.cuda() if bn else None), (R.cuda() if res else None)      # held: a temporary's memory is reused at once
+    C = torch.full((M + 1, N), 777.0, device="cuda", dtype=torch.float32 if cf32 else torch.float16)
+    L.call("xp_gemm_nt_f16", L.ptr(Ad), L.ptr(Wd), L.ptr(C), int(cf32), L.ptr(bd), L.ptr(scd), L.ptr(shd), L.ptr(Rd), M, N, K, K, N, N, act, L.current_stream())
+    got = C[:M].cpu().double()
+    assert bool((C[M] == 777.0).all()), "row past M written"
+    if cf32:
+        assert torch.equal(got, got.half().double())                 # fp16-exact values in the f32 container
+    d = (got - ref).abs()
+    assert float((d / _ulp16(mag)).max()) <= 2.01, (M, N, K, float((d / _ulp16(mag)).max()))
+    assert float((d == 0).double().mean()) > 0.98, float((d == 0).double().mean())
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride,reflect,act", [(2, 12, 20, 48, 96, 2, 0, 0), (1, 15, 20, 96, 192, 2, 0, 0), (2, 8, 12, 48, 512, 1, 1, 2),
+                                                           (1, 30, 40, 192, 384, 2, 0, 0), (1, 9, 7, 8, 40, 1, 0, 0)])
+def test_conv3x3_f16(gpu_lib, B, H, W, Ci, Co, stride, reflect, act):
+    """xp_conv3x3_nhwc_f16 (implicit GEMM, gathered rows by LDS-DMA with the padding taps read from a zero page) vs torch conv2d in float64 on the same fp16
+    operands + the half roundings of the recipe."""
+    L = _lib()
+    x = _u(f"cx{B}{H}{Ci}{Co}", (B, H, W, Ci)).half(); w = _u(f"cw{B}{H}{Ci}{Co}", (Co, 3, 3, Ci), -0.1, 0.1).half(); b = _u(f"cb{B}{H}{Ci}{Co}", (Co,))
+    sc = _u(f"cs{Co}", (Co,), 0.5, 1.5) if act == 2 else None; sh = _u(f"ct{Co}", (Co,)) if act == 2 else None
+    xin = x.double().permute(0, 3, 1, 2)
+    if reflect:
+        xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
+    acc = F.conv2d(xin, w.double().permute(0, 3, 1, 2), None, stride=stride, padding=0 if reflect else 1).permute(0, 2, 3, 1)
+    ref, mag = _f16_ref(None, None, b, sc, sh, None, act, acc=acc)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    y = torch.empty((B, Ho, Wo, Co), device="cuda", dtype=torch.float16)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    scd, shd = (sc.cuda() if sc is not None else None), (sh.cuda() if sh is not None else None)
+    L.call("xp_conv3x3_nhwc_f16", L.ptr(xd), L.ptr(wd), L.ptr(y), 0, L.ptr(bd), L.ptr(scd), L.ptr(shd), B, H, W, Ci, Co, stride, reflect, act, L.current_stream())
+    d = (y.cpu().double() - ref).abs()
+    assert float((d / _ulp16(mag)).max()) <= 2.01, float((d / _ulp16(mag)).max())
+    assert float((d == 0).double().mean()) > 0.98

@@ -24,6 +24,10 @@ for (M, N, K, act, res) in shapes:
     st = L.current_stream()
     X3 = os.environ.get("GB_X3", "0") == "1"
     H2 = os.environ.get("GB_H2", "0") == "1"
+    F16 = os.environ.get("GB_F16", "0") == "1"      # fp16-storage kernel (csrc/gemm_f16.hip): half A / W / C / res
+    if F16:
+        A16, W16, C16 = A.half(), W.half(), torch.empty(M, N, device="cuda", dtype=torch.float16)
+        R16 = R.half() if res else None
     if H2:
         import ctypes
         Wx = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device="cuda")
@@ -35,7 +39,9 @@ for (M, N, K, act, res) in shapes:
         L.call("xp_split_weights_x3", L.ptr(W), ctypes.c_void_p(Wx.data_ptr()), N, K, st)
         wxp = ctypes.c_void_p(Wx.data_ptr())
     def run():
-        if H2:
+        if F16:
+            L.call("xp_gemm_nt_f16", L.ptr(A16), L.ptr(W16), L.ptr(C16), 0, L.ptr(b), None, None, L.ptr(R16), M, N, K, K, N, N, act, st)
+        elif H2:
             L.call("xp_gemm_nt_h2", L.ptr(A), wxp, L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
         elif X3:
             L.call("xp_gemm_nt_x3", L.ptr(A), wxp, L.ptr(C), L.ptr(b), None, None, L.ptr(R), M, N, K, K, N, N, act, st)
@@ -50,5 +56,5 @@ for (M, N, K, act, res) in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * M * N * K
-    by = 4.0 * (M * K + N * K + M * N * (2 if res else 1))
+    by = (2.0 if F16 else 4.0) * (M * K + N * K + M * N * (2 if res else 1))
     print(f"M{M:7d} N{N:5d} K{K:5d} act{act} res{res}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s  {by/ms/1e6:7.0f} GB/s", flush=True)

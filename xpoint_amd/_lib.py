@@ -43,6 +43,9 @@ _SIGNATURES = {
     "xp_split_weights_h2": [c_p, c_p, c_i, c_i, c_p],
     "xp_gemm_nt_h2": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc_h2": [c_p] * 6 + [c_i] * 8 + [c_p],
+    "xp_f32_to_f16": [c_p, c_p, c_l, c_p],
+    "xp_gemm_nt_f16": [c_p, c_p, c_p, c_i] + [c_p] * 4 + [c_i] * 7 + [c_p],
+    "xp_conv3x3_nhwc_f16": [c_p, c_p, c_p, c_i] + [c_p] * 3 + [c_i] * 8 + [c_p],
     "xp_mlp_fused_h2": [c_p] * 10 + [c_i] * 3 + [c_f, c_p],
     "xp_mlp_fused_h2_pack": [c_p] * 4 + [c_i] * 2 + [c_p],
     "xp_ln_proj_h2_pack": [c_p] * 2 + [c_i] * 2 + [c_p],
