@@ -148,6 +148,27 @@ int xp_gemm_nt_f16(const void* A, const void* W, void* C, int c_f32, const float
 int xp_conv3x3_nhwc_f16(const void* x, const void* W, void* y, int y_f32, const float* bias, const float* scale, const float* shift,
                         int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
 
+/* Glue kernels of the same class (csrc/elementwise_f16.hip): half tensors in HBM, f32 arithmetic, one rounding per autocast boundary (= the store). */
+int xp_stem_conv_ln_gelu_f16(const float* img, const float* w9co, const float* bias, const float* ln_w, const float* ln_b, void* y,
+                             int batch, int H, int W, int CO, float eps, void* stream);
+int xp_layernorm_f16(const void* x, void* y, const float* w, const float* b, int64_t rows, int C, float eps, void* stream);
+int xp_dwconv3x3_silu_f16(const void* x, const float* w9c, void* y, float* y_f32_copy, int batch, int H, int W, int C, void* stream);
+int xp_depth_to_space_nhwc_f16(const void* x, float* y_f32, void* y_f16, int batch, int H, int W, int C, int bs, int* status, void* stream);
+/* Fused SS2D core on half tensors (see xp_ss2d_core_fwd): u, xdbl, out are fp16; scan state / softplus / exp / out_norm in f32 (csms6s.py:47-67,
+ * VMamba.py:644-646); dt projection rounded to fp16 before the f32 bias.  u_f32 / xdbl_f32: optional f32 copies enabling the sequential deep-stage form
+ * (xp_ss2d_core_f16_wants_f32_copies tells, from per-image quantities only, whether it would be taken). */
+int xp_ss2d_core_f16_wants_f32_copies(int H, int W, int C, int R);
+int xp_ss2d_core_fwd_f16(const void* u, const void* xdbl, const float* u_f32, const float* xdbl_f32, const float* wdt, const float* dt_bias,
+                         const float* A, const float* Ds, const float* ln_w, const float* ln_b, void* out, float* workspace, size_t workspace_bytes,
+                         int batch, int H, int W, int C, int R, int dstate, float eps, void* stream);
+/* The whole forward in that class (csrc/model.cpp): `weights` = the blob whose autocast-cast tensors were rounded to fp16 (host), w16 = their fp16 copies
+ * (xp_f16_weights_bytes / xp_prepare_f16_weights); workspace as xp_forward_workspace_bytes; outputs as xp_xpoint_forward_ex (f32, holding fp16-exact
+ * encoder values; prob / desc computed in f32 from the half head outputs, XPoint.py:349,363). */
+size_t xp_f16_weights_bytes(void* ctx);
+int xp_prepare_f16_weights(void* ctx, const float* weights, void* w16, size_t w16_bytes, void* stream);
+int xp_xpoint_forward_f16(void* ctx, const float* weights, const void* w16, const float* images, int batch, int H, int W, void* workspace,
+                          size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc, float* logits_nhwc, int* status, void* stream);
+
 /* Precision class of the "x3" kernels (xp_gemm_nt_x3, xp_conv3x3_nhwc_x3, xp_mlp_fused_x3 and every dense layer of
  * xp_xpoint_forward with wsplit != NULL), process-wide, read at launch time:
  *   6 (default)  all six partial products of weight >= 2^-16: f32-grade (the class pinned against the reference, 1e-4 bar)

@@ -15,7 +15,7 @@
 namespace {
 
 struct Param { std::string name; size_t offset; size_t numel; };
-struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset, h2_offset; };   // a GEMM weight and its split-bf16 / split-fp16 copies
+struct SplitW { std::string name; size_t src_offset; int N, K; size_t byte_offset, h2_offset, f16_offset; };   // a GEMM weight and its split-bf16 / split-fp16 / plain fp16 copies
 struct MlpPack { std::string block; int C, H4; size_t byte_offset, in_offset, h2_offset, h2_in_offset; };   // weight streams of one VSS block's fused tail (out_proj + MLP) and head (in_proj), x3 and h2 forms
 
 struct Ctx {
@@ -26,6 +26,7 @@ struct Ctx {
     std::vector<SplitW> split;
     std::vector<MlpPack> packs;
     size_t total, split_bytes, h2_bytes;    // split_bytes: the x3 region (planes + fused-kernel packs); the h2 region follows it
+    size_t f16_bytes;                        // plain fp16 (N, K) copies of the GEMM weights (fast mixed-precision class)
     size_t add(const std::string& n, size_t numel) {
         size_t off = total;
         params.push_back({n, off, numel});
@@ -35,7 +36,8 @@ struct Ctx {
     // a (N, K) matrix consumed by a GEMM / 3x3 conv: also gets a slot in the split-weights buffer
     size_t add_gemm(const std::string& n, int N, int K) {
         const size_t off = add(n, (size_t)N * K);
-        split.push_back({n, off, N, K, split_bytes, h2_bytes});
+        split.push_back({n, off, N, K, split_bytes, h2_bytes, f16_bytes});
+        f16_bytes += ((size_t)N * K * 2 + 255) / 256 * 256;
         split_bytes += (xp_split_weights_x3_bytes(N, K) + 255) / 256 * 256;
         h2_bytes += (xp_split_weights_h2_bytes(N, K) + 255) / 256 * 256;
         return off;
@@ -50,6 +52,10 @@ struct Ctx {
     }
     size_t h2_off(const std::string& n) const {       // offset inside the whole buffer (the h2 region starts at split_bytes)
         for (auto& p : split) if (p.name == n) return split_bytes + p.h2_offset;
+        return (size_t)-1;
+    }
+    size_t f16_off(const std::string& n) const {
+        for (auto& p : split) if (p.name == n) return p.f16_offset;
         return (size_t)-1;
     }
     size_t pack_off(const std::string& block) const {
@@ -74,7 +80,7 @@ int enc_channels_of(const Ctx& c) { return c.dims[c.nstages - 1] / 16; }
 
 void build_layout(Ctx& c) {
     const int E = c.cfg.embed_dim, N = c.cfg.d_state;
-    c.total = 0; c.split_bytes = 0; c.h2_bytes = 0; c.split.clear(); c.packs.clear();
+    c.total = 0; c.split_bytes = 0; c.h2_bytes = 0; c.f16_bytes = 0; c.split.clear(); c.packs.clear();
     c.add("stem.w", 9 * (E / 2)); c.add("stem.b", E / 2); c.add("stem.ln_w", E / 2); c.add("stem.ln_b", E / 2);
     c.add_gemm("pe2.w", E, 9 * (E / 2)); c.add("pe2.b", E); c.add("pe2.ln_w", E); c.add("pe2.ln_b", E);
     for (int s = 0; s < c.nstages; ++s) {
@@ -352,6 +358,119 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
     if (desc_nhwc) {
         RUN(gemm(HB + HC, "desc2.w", T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0));
         RUN(xp_l2norm_rows_st(T1, desc_nhwc, Mc, DS, 1e-12f, status, stream));
+    }
+    return XP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Fast mixed-precision class ("amp16f"): the reference's `mixed_precision: true` deployment (XPoint.py:182 autocast, half by default)
+// with HALF STORAGE — every tensor between two operations lives in HBM as fp16, dense layers are one-product fp16 MFMA GEMMs fed by LDS-DMA
+// (csrc/gemm_f16.hip), the scan state / softplus / exp / out_norm / softmax / normalize stay f32 exactly where the recipe keeps them
+// (csms6s.py:47-67, VMamba.py:644-646, XPoint.py:349,363).  Same rounding points as the round-3 parity class (xp_set_amp_mode(1), f32 containers):
+// pinned by the same fixture, tests/golden/g20.  `weights` must be the blob whose autocast-cast tensors were rounded to fp16 on the host
+// (models.XPoint.pack_weights(amp=True)); w16 = their fp16 copies (xp_prepare_f16_weights).
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+extern "C" size_t xp_f16_weights_bytes(void* ctx) { return ctx ? ((Ctx*)ctx)->f16_bytes : 0; }
+
+extern "C" int xp_prepare_f16_weights(void* ctx, const float* weights, void* w16, size_t w16_bytes, void* stream) {
+    XP_CHECK_ARG(ctx && weights && w16, "xp_prepare_f16_weights: null pointer");
+    Ctx* c = (Ctx*)ctx;
+    XP_CHECK_ARG(w16_bytes >= c->f16_bytes, "xp_prepare_f16_weights: buffer too small");
+    XP_CHECK_ARG(((uintptr_t)w16 & 255) == 0, "xp_prepare_f16_weights: buffer must be 256-byte aligned");
+    for (auto& e : c->split) {
+        XP_CHECK_ARG(e.K % 8 == 0, "xp_prepare_f16_weights: %s has K = %d, not a multiple of 8", e.name.c_str(), e.K);
+        RUN(xp_f32_to_f16(weights + e.src_offset, (char*)w16 + e.f16_offset, (int64_t)e.N * e.K, stream));
+    }
+    return XP_OK;
+}
+
+extern "C" int xp_xpoint_forward_f16(void* ctx, const float* weights, const void* w16, const float* images, int batch, int H, int W,
+                                     void* workspace, size_t workspace_bytes, float* prob, float* desc_nhwc, float* enc_nhwc,
+                                     float* logits_nhwc, int* status, void* stream) {
+    XP_CHECK_ARG(ctx && weights && w16 && images && workspace && enc_nhwc, "xp_xpoint_forward_f16: null pointer");
+    XP_CHECK_ARG(batch > 0, "xp_xpoint_forward_f16: empty batch");
+    Ctx* c = (Ctx*)ctx; Shapes sh;
+    XP_CHECK_ARG(shapes_of(*c, batch, H, W, sh), "xp_xpoint_forward_f16: image too small");
+    XP_CHECK_ARG(H % 32 == 0 && W % 32 == 0, "xp_xpoint_forward_f16: H and W must be multiples of 32 for the VMamba encoder (got %dx%d)", H, W);
+    XP_CHECK_ARG(sh.Hc * 8 == H && sh.Wc * 8 == W, "xp_xpoint_forward_f16: encoder output %dx%d is not 1/8 of the image", sh.Hc, sh.Wc);
+    XP_CHECK_ARG(c->cfg.embed_dim % 16 == 0, "xp_xpoint_forward_f16: embed_dim must be a multiple of 16");
+    const WsPlan wp = plan_ws(*c, batch, sh);
+    XP_CHECK_ARG(workspace_bytes >= wp.total_floats * sizeof(float), "xp_xpoint_forward_f16: workspace too small");
+    // the f32 plan's regions, used as half buffers (each holds twice the elements it needs); T3 / XD double as the f32 copies the sequential
+    // deep-stage scan reads (upper halves of their regions)
+    float* ws = (float*)workspace;
+    typedef unsigned short h16;      // opaque fp16 storage on the host side
+    h16 *X = (h16*)(ws + wp.X), *T1 = (h16*)(ws + wp.T1), *T2 = (h16*)(ws + wp.T2), *T3 = (h16*)(ws + wp.T3), *HB = (h16*)(ws + wp.HB), *XD = (h16*)(ws + wp.XD);
+    float* SS = ws + wp.SS;
+    auto P = [&](const std::string& n) -> const float* { return weights + c->off(n); };
+    auto WH = [&](const std::string& n) -> const void* { return (const char*)w16 + c->f16_off(n); };
+    auto gemm = [&](const void* A, const std::string& w, void* C, int c_f32, const float* bias, const float* scale, const float* shift,
+                    const void* res, int M, int N, int K, int lda, int ldc, int ldres, int act) -> int {
+        return xp_gemm_nt_f16(A, WH(w), C, c_f32, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
+    };
+    auto conv = [&](const void* x, const std::string& w, void* y, const float* bias, const float* scale, const float* shift,
+                    int Hi, int Wi, int Ci, int Co, int stride, int reflect, int act) -> int {
+        return xp_conv3x3_nhwc_f16(x, WH(w), y, 0, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
+    };
+    const float eps = 1e-5f;
+    const int E = c->cfg.embed_dim;
+
+    // patch embed (VMamba.py:1405-1420)
+    RUN(xp_stem_conv_ln_gelu_f16(images, P("stem.w"), P("stem.b"), P("stem.ln_w"), P("stem.ln_b"), HB, batch, H, W, E / 2, eps, stream));
+    RUN(conv(HB, "pe2.w", T1, P("pe2.b"), nullptr, nullptr, sh.Hs, sh.Ws, E / 2, E, 2, 0, 0));
+    RUN(xp_layernorm_f16(T1, X, P("pe2.ln_w"), P("pe2.ln_b"), sh.M[0], E, eps, stream));
+
+    for (int s = 0; s < c->nstages; ++s) {
+        const int C = c->dims[s], R = c->ranks[s], H4 = (int)(C * c->cfg.mlp_ratio);
+        const int M = (int)sh.M[s];
+        const int XW = 4 * (R + 2);
+        // deep stages: the scan's sequential form reads f32 copies of u and xdbl, written beside the half tensors by their producers (upper halves of
+        // the T3 / XD regions: a region holds M * C floats = twice the halves)
+        const bool seq = xp_ss2d_core_f16_wants_f32_copies(sh.H[s], sh.W[s], C, R) != 0;
+        float* T3f = seq ? (ws + wp.T3 + ((size_t)M * C / 2 + 63) / 64 * 64) : nullptr;
+        float* XDf = seq ? (ws + wp.XD + ((size_t)M * XW / 2 + 63) / 64 * 64) : nullptr;
+        for (int j = 0; j < c->cfg.depths[s]; ++j) {
+            const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
+            // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
+            RUN(xp_layernorm_f16(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, stream));
+            RUN(gemm(T1, b + "in_w", T2, 0, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
+            RUN(xp_dwconv3x3_silu_f16(T2, P(b + "dw_w"), T3, T3f, batch, sh.H[s], sh.W[s], C, stream));
+            RUN(gemm(T3, b + "xproj_w", XD, 0, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
+            if (seq) RUN(gemm(T3, b + "xproj_w", XDf, 1, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));     // the same half values in f32 containers (M <= a few thousand rows)
+            RUN(xp_ss2d_core_fwd_f16(T3, XD, T3f, XDf, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
+                                     T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
+            RUN(gemm(T1, b + "out_w", X, 0, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
+            // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
+            RUN(xp_layernorm_f16(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, stream));
+            RUN(gemm(T1, b + "fc1_w", HB, 0, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
+            RUN(gemm(HB, b + "fc2_w", X, 0, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));
+        }
+        if (s < c->nstages - 1) {   // downsample v3 (VMamba.py:1432-1440)
+            const std::string d = "s" + std::to_string(s) + ".ds.";
+            RUN(conv(X, d + "w", T1, P(d + "b"), nullptr, nullptr, sh.H[s], sh.W[s], C, 2 * C, 2, 0, 0));
+            RUN(xp_layernorm_f16(T1, X, P(d + "ln_w"), P(d + "ln_b"), sh.M[s + 1], 2 * C, eps, stream));
+        }
+    }
+    const int L = c->nstages - 1;
+    // VMamba.py:1500-1505; a half overflow anywhere upstream reaches the residual stream as inf / NaN and is reported here (XP_STATUS_ENC)
+    RUN(xp_depth_to_space_nhwc_f16(X, enc_nhwc, T2, batch, sh.H[L], sh.W[L], c->dims[L], 4, status, stream));
+
+    // heads (XPoint.py:112-138, :348-371): shared 3x3 trunk for both heads, the two 1x1 convolutions end in `.to(torch.float)` (c_f32)
+    const int EC = enc_channels_of(*c), HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
+    const int Mc = batch * sh.Hc * sh.Wc;
+    if (prob || logits_nhwc || desc_nhwc) {
+        RUN(conv(T2, "head.w", HB, P("head.b"), P("head.scale"), P("head.shift"), sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2));
+    }
+    if (prob || logits_nhwc) {
+        float* lg = logits_nhwc ? logits_nhwc : (float*)(ws + wp.T3);
+        RUN(gemm(HB, "det2.w", lg, 1, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0));
+        if (prob) RUN(xp_softmax_shuffle_st(lg, prob, batch, sh.Hc, sh.Wc, 8, DET, 0, status, stream));
+    }
+    if (desc_nhwc) {
+        float* dtmp = (float*)(ws + wp.T1);
+        RUN(gemm(HB + HC, "desc2.w", dtmp, 1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0));
+        RUN(xp_l2norm_rows_st(dtmp, desc_nhwc, Mc, DS, 1e-12f, status, stream));
     }
     return XP_OK;
 }

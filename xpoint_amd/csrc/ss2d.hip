@@ -109,6 +109,7 @@ struct DtWeights {
     static constexpr int KS = (R + 15) / 16;
     f16x8_t bw[2][KS][2];                                               // [channel tile][k slab][plane]
     float bias[2];
+    float bias_lane;                                                    // AMP: the unscaled bias of channel cbase + lane (the layout AFTER dt_tile's lane swap)
 };
 __device__ __forceinline__ void dt_split8(const float (&v)[8], f16x8_t& hi, f16x8_t& lo) {
     uint2 a0, a1, b0, b1;
@@ -119,13 +120,17 @@ __device__ __forceinline__ void dt_split8(const float (&v)[8], f16x8_t& hi, f16x
     hi = x.h; lo = y.h;
 }
 // wdt_dir: (R, C) weights of one direction, dtb_dir: (C); cbase: first of the wave's 64 channels.  log2(e) folded in (see step_vals).
-template <int R>
+// AMP (mixed-precision classes): the projection is a half convolution whose output is rounded to fp16 BEFORE the f32 bias is added (see step_vals): weights
+// and bias arrive without the log2(e) factor, the accumulator starts at 0, and dt_tile finishes with (r16(acc) + bias) * log2(e)
+template <int R, bool AMP = false>
 __device__ __forceinline__ void dt_load_weights(DtWeights<R>& w, const float* __restrict__ wdt_dir, const float* __restrict__ dtb_dir, int C, int cbase) {
+    constexpr float WL2E = AMP ? 1.f : XP_L2E;
     const int fr = threadIdx.x & 31, fh = (threadIdx.x >> 5) & 1;
+    w.bias_lane = dtb_dir[cbase + (threadIdx.x & 63)];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int cj = cbase + 32 * j + fr;
-        w.bias[j] = XP_L2E * dtb_dir[cj];
+        w.bias[j] = AMP ? 0.f : XP_L2E * dtb_dir[cj];
 #pragma unroll
         for (int ks = 0; ks < DtWeights<R>::KS; ++ks) {
             float wv[8];
@@ -133,14 +138,14 @@ __device__ __forceinline__ void dt_load_weights(DtWeights<R>& w, const float* __
             for (int e = 0; e < 8; ++e) {
                 const int r = ks * 16 + fh * 8 + e;                     // clamped unconditional load + select: no branch per element
                 const float t = wdt_dir[(int64_t)(r < R ? r : 0) * C + cj];
-                wv[e] = r < R ? XP_L2E * t : 0.f;
+                wv[e] = r < R ? WL2E * t : 0.f;
             }
             dt_split8(wv, w.bw[j][ks][0], w.bw[j][ks][1]);
         }
     }
 }
 // rows: LDS, tile pixel i's dt_rank values at rows + i * stride (floats, 8-byte aligned)
-template <int R>
+template <int R, bool AMP = false>
 __device__ __forceinline__ void dt_tile(const DtWeights<R>& w, const float* rows, int stride, float (&dtv)[2][16]) {
     const int fr = threadIdx.x & 31, fh = (threadIdx.x >> 5) & 1;
     f32x16 acc[2];
@@ -172,12 +177,18 @@ __device__ __forceinline__ void dt_tile(const DtWeights<R>& w, const float* rows
     for (int e = 0; e < 16; ++e) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][e]), __float_as_uint(acc[1][e]), false, false);
         dtv[0][e] = __uint_as_float(sw[0]); dtv[1][e] = __uint_as_float(sw[1]);
+        if constexpr (AMP) {
+            dtv[0][e] = ((float)(_Float16)dtv[0][e] + w.bias_lane) * XP_L2E;
+            dtv[1][e] = ((float)(_Float16)dtv[1][e] + w.bias_lane) * XP_L2E;
+        }
     }
 }
 #define XP_DTV(dtv, j) (dtv)[((j) >> 2) & 1][((j) & 3) + 4 * ((j) >> 3)]
 
 // Shared staging of one block's chunk(s): pixel indices and the xdbl rows of this route pair.
-template <int R>
+// UT: element type of u / xdbl / out in HBM — float, or _Float16 in the fast mixed-precision class (fp16 storage; every value is converted on load, and the
+// conversion on the out_norm store IS the recipe's `y.to(x.dtype)`, VMamba.py:646)
+template <int R, typename UT = float>
 __device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair, int chunk0, int* s_pix, int* s_off, float* s_x) {
     const int L = p.H * p.W;
     const int npx = p.cpb * p.T;
@@ -194,14 +205,14 @@ __device__ __forceinline__ void stage_chunk(const SS2DParams& p, int b, int pair
     for (int i = threadIdx.x; i < npx * XW; i += blockDim.x) {
         int pi = i / XW, e = i - pi * XW;
         int px = s_pix[pi];
-        s_x[i] = (px >= 0) ? p.xdbl[((int64_t)b * L + px) * XD + pair * XW + e] : 0.f;
+        s_x[i] = (px >= 0) ? (float)reinterpret_cast<const UT*>(p.xdbl)[((int64_t)b * L + px) * XD + pair * XW + e] : 0.f;
     }
     __syncthreads();
 }
 
 // FULL: every chunk of every block is complete (L % T == 0 and nc % cpb == 0 — all shapes of the 480 x 640 model): the per-step
 // validity selects (compare + two cndmask per step) are compiled out
-template <int R, bool FULL, bool AMP = false>
+template <int R, bool FULL, bool AMP = false, typename UT = float>
 __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     constexpr float WL2E = AMP ? 1.f : XP_L2E;        // factor folded into the dt weights and bias where they are loaded (see step_vals)
     extern __shared__ __align__(16) char smem[];
@@ -211,12 +222,12 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
     float* s_x = reinterpret_cast<float*>(smem + sizeof(int) * 2 * npx);
     constexpr int XW = 2 * (R + 2);
     const int b = blockIdx.y, pair = blockIdx.z, chunk0 = blockIdx.x * p.cpb;
-    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_off, s_x);
+    stage_chunk<R, UT>(p, b, pair, chunk0, s_pix, s_off, s_x);
     const int cl = threadIdx.x / p.C, c = threadIdx.x - cl * p.C;
     const int chunk = chunk0 + cl;
     if (chunk >= p.nc) return;
     const int L = p.H * p.W;
-    const float* ub = p.u + (int64_t)b * L * p.C + c;
+    const UT* ub = reinterpret_cast<const UT*>(p.u) + (int64_t)b * L * p.C + c;
     float P0 = 1.f, S0 = 0.f, Q1 = 1.f, S1 = 0.f;
     if constexpr (R < 16) {
         // small dt_rank (the wide, HBM-bound stages): both routes in one sweep over u
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
-                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : (float)ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];                       // element offset of the pixel row, -1 past the end
-                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : (float)ub[(FULL || px[k] >= 0) ? px[k] : 0];   // 32-bit offsets (host checks B*L*C < 2^31)
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(64 * P2_G) void ss2d_pass2(SS2DParams p) {
     for (; jj < j1; ++jj) { const int64_t o = off(jj); const float Pj = p.wsP[o], Sj = p.wsS[o]; p.wsS[o] = h; h = fmaf(Pj, h, Sj); }
 }
 
-template <int R, bool COLPAIR, bool FULL, bool AMP = false>
+template <int R, bool COLPAIR, bool FULL, bool AMP = false, typename UT = float>
 __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     constexpr float WL2E = AMP ? 1.f : XP_L2E;
     extern __shared__ __align__(16) char smem[];
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
     const int SY = p.C + 8;
     const int pair = COLPAIR ? 1 : 0;
     const int b = blockIdx.y, chunk0 = blockIdx.x * p.cpb;
-    stage_chunk<R>(p, b, pair, chunk0, s_pix, s_off, s_x);
+    stage_chunk<R, UT>(p, b, pair, chunk0, s_pix, s_off, s_x);
     const int cl = threadIdx.x / p.C, c = threadIdx.x - cl * p.C;
     const int chunk = chunk0 + cl;
     const int L = p.H * p.W;
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
         const float b0 = WL2E * p.dtb[(pair * 2 + 0) * p.C + c];
         const float A0 = XP_L2E * p.A[(pair * 2 + 0) * p.C + c];
         const float D0 = p.Dp[(pair * 2 + 0) * p.C + c];
-        const float* ub = p.u + (int64_t)b * L * p.C + c;
+        const UT* ub = reinterpret_cast<const UT*>(p.u) + (int64_t)b * L * p.C + c;
         const int64_t o = ((((int64_t)b * 2 + pair) * p.nc + chunk) * 2) * p.C + c;
         float h = p.wsS[o];
         // forward route
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 px[k] = s_off[cl * p.T + i0 + k];
-                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[(FULL || px[k] >= 0) ? px[k] : 0];
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : (float)ub[(FULL || px[k] >= 0) ? px[k] : 0];
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
             }
 #pragma unroll
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
             for (int k = 3; k >= 0; --k) {
                 px[k] = s_off[cl * p.T + i0 + k];
                 const int po = (FULL || px[k] >= 0) ? px[k] : 0;
-                const float t = (XP_SS2D_DBG & 8) ? 1.f : ub[po];
+                const float t = (XP_SS2D_DBG & 8) ? 1.f : (float)ub[po];
                 uv[k] = (FULL || px[k] >= 0) ? t : 0.f;
                 if (COLPAIR) pv[k] = (XP_SS2D_DBG & 2) ? 0.f : prev[po];
             }
@@ -462,14 +473,19 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
                 }
             v = xp_row8_sum(v);
             const float rstd = 1.f / sqrtf(v * invC + p.eps);
-            float* orow = p.out + ((int64_t)b * L + px) * p.C;
+            UT* orow = reinterpret_cast<UT*>(p.out) + ((int64_t)b * L + px) * p.C;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 if (j < nj) {
                     float4 o;
                     o.x = (r[j].x - mean) * rstd * gw[j].x + gb[j].x; o.y = (r[j].y - mean) * rstd * gw[j].y + gb[j].y;
                     o.z = (r[j].z - mean) * rstd * gw[j].z + gb[j].z; o.w = (r[j].w - mean) * rstd * gw[j].w + gb[j].w;
-                    *reinterpret_cast<float4*>(orow + 4 * (sub + 8 * j)) = o;
+                    if constexpr (std::is_same<UT, float>::value) *reinterpret_cast<float4*>(orow + 4 * (sub + 8 * j)) = o;
+                    else {
+                        union { _Float16 h[4]; uint2 u; } hh;
+                        hh.h[0] = (_Float16)o.x; hh.h[1] = (_Float16)o.y; hh.h[2] = (_Float16)o.z; hh.h[3] = (_Float16)o.w;
+                        *reinterpret_cast<uint2*>(orow + 4 * (sub + 8 * j)) = hh.u;
+                    }
                 }
         }
         return;
@@ -484,8 +500,8 @@ __global__ __launch_bounds__(768) void ss2d_pass3(SS2DParams p) {
         float v = 0.f;
         for (int cc = lane; cc < p.C; cc += 64) { float d = row[cc] - mean; v = fmaf(d, d, v); }
         const float rstd = 1.f / sqrtf(xp_wave_sum(v) / (float)p.C + p.eps);
-        float* orow = p.out + ((int64_t)b * L + px) * p.C;
-        for (int cc = lane; cc < p.C; cc += 64) orow[cc] = (row[cc] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+        UT* orow = reinterpret_cast<UT*>(p.out) + ((int64_t)b * L + px) * p.C;
+        for (int cc = lane; cc < p.C; cc += 64) orow[cc] = (UT)((row[cc] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc]);
     }
 }
 
@@ -609,7 +625,7 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan(SS2DParams p, float* __restr
 //    per access); pixels past the end get an out-of-range offset, which the buffer hardware turns into a dropped store / a zero load,
 //    so there is one code path for full and partial tiles;
 //  * the tile's xdbl rows are fetched one row per lane pair with immediate offsets (no address arithmetic).
-template <int R>
+template <int R, bool AMP = false>
 __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __restrict__ ys) {
     constexpr int RW = R + 2, NP = RW / 2, NPL = (NP + 1) / 2;          // float2 pieces per xdbl row of one route; pieces fetched by one lane
     __shared__ __align__(16) float s_x[2][SEQ_TP * RW];
@@ -619,7 +635,7 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __rest
     const int L = p.H * p.W, XD = 4 * RW;
     const int c = blockIdx.x * 64 + lane;                               // C % 64 == 0 (host)
     DtWeights<R> dw;
-    dt_load_weights<R>(dw, p.wdt + (int64_t)d * R * p.C, p.dtb + d * p.C, p.C, blockIdx.x * 64);
+    dt_load_weights<R, AMP>(dw, p.wdt + (int64_t)d * R * p.C, p.dtb + d * p.C, p.C, blockIdx.x * 64);
     const float Av = XP_L2E * p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
     const int plane_bytes = L * p.C * 4;                                // host: < 2^31
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + (int64_t)b * L * p.C), 0, plane_bytes, 0x00020000);
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __rest
         if (t + 1 < ntile) { tile_offsets(t + 1, offn, offx); load_tile(offn, offx, unext); }
         const float* sx = s_x[t & 1];
         float dtv[2][16];
-        dt_tile<R>(dw, sx, RW, dtv);                                    // dt of the tile on the matrix pipe
+        dt_tile<R, AMP>(dw, sx, RW, dtv);                               // dt of the tile on the matrix pipe
         // four steps at a time: their operand evaluation (softplus, exp) is independent and interleaves; only the h update is a chain
 #pragma unroll
         for (int j0 = 0; j0 < SEQ_TP; j0 += 4) {
@@ -702,6 +718,7 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __rest
 }
 
 // out[b][px][:] = LayerNorm_C((y0 + y2) + (y1 + y3)); one wave per pixel, the row held in registers (C <= 768)
+template <typename OT = float>
 __global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const float* __restrict__ ys) {
     const int lane = threadIdx.x & 63;
     const int64_t M = (int64_t)p.Bn * p.H * p.W;
@@ -725,11 +742,11 @@ __global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const flo
 #pragma unroll
     for (int q = 0; q < 12; ++q) if (q * 64 + lane < p.C) { const float dd = v[q] - mean; q2 = fmaf(dd, dd, q2); }
     const float rstd = 1.f / sqrtf(xp_wave_sum(q2) / (float)p.C + p.eps);
-    float* orow = p.out + row * p.C;
+    OT* orow = reinterpret_cast<OT*>(p.out) + row * p.C;
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int cc = q * 64 + lane;
-        if (cc < p.C) orow[cc] = (v[q] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+        if (cc < p.C) orow[cc] = (OT)((v[q] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc]);
     }
 }
 
@@ -739,8 +756,10 @@ bool seq_scan2_applies(int R, int H, int W, int C) {
     return !old_seq && R >= 16 && R % 8 == 0 && (int64_t)H * W * C < (1ll << 29) && (int64_t)H * W * 4 * (R + 2) < (1ll << 29);
 }
 
+// half_out: the fast mixed-precision class — u / xdbl are f32 COPIES of the half tensors (written beside them by their producers: the deep stages are
+// small), the dt projection rounds like step_vals<R, AMP>, out is stored as fp16
 template <int R>
-int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s) {
+int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s, bool half_out = false) {
     const double MC = (double)p.Bn * p.H * p.W * p.C, MX = (double)p.Bn * p.H * p.W * 4 * (R + 2);
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     const std::string sfx = by_shape ? "_C" + std::to_string(p.C) : std::string();
@@ -748,20 +767,25 @@ int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s) {
         XpProfScope prof(("ss2d_seq_scan" + sfx).c_str(), s, 4.0 * MC * (2.0 * R + 14.0), 4.0 * (8.0 * MC + MX));
         const bool v2 = seq_scan2_applies(R, p.H, p.W, p.C);
         if constexpr (R >= 16 && R % 8 == 0) {
-            if (v2) hipLaunchKernelGGL(ss2d_seq_scan2<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+            if (v2 && half_out) hipLaunchKernelGGL((ss2d_seq_scan2<R, true>), dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+            else if (v2) hipLaunchKernelGGL((ss2d_seq_scan2<R, false>), dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
         }
-        if (!v2) hipLaunchKernelGGL(ss2d_seq_scan<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+        if (!v2) {
+            if (half_out) { xp_set_error("xp_ss2d_core_fwd_f16: the sequential form needs dt_rank >= 16 (got %d)", R); return XP_ERR_ARG; }
+            hipLaunchKernelGGL(ss2d_seq_scan<R>, dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+        }
     }
     {
         XpProfScope prof(("ss2d_seq_merge_ln" + sfx).c_str(), s, 12.0 * MC, 4.0 * 5.0 * MC);
-        hipLaunchKernelGGL(ss2d_seq_merge_ln, dim3(xp_cdiv((int64_t)p.Bn * p.H * p.W, 4)), dim3(256), 0, s, p, ys);
+        if (half_out) hipLaunchKernelGGL(ss2d_seq_merge_ln<_Float16>, dim3(xp_cdiv((int64_t)p.Bn * p.H * p.W, 4)), dim3(256), 0, s, p, ys);
+        else hipLaunchKernelGGL(ss2d_seq_merge_ln<float>, dim3(xp_cdiv((int64_t)p.Bn * p.H * p.W, 4)), dim3(256), 0, s, p, ys);
     }
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
 
 template <int R>
-int launch_ss2d(const SS2DParams& p, hipStream_t s) {
+int launch_ss2d(const SS2DParams& p, hipStream_t s, bool half_io = false) {
     constexpr int XW = 2 * (R + 2);
     const int npx = p.cpb * p.T;
     const int threads = p.cpb * p.C;
@@ -776,7 +800,9 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     const double el = 4.0 * MC;   // (pixel, channel, direction) scan elements of the whole core
     {   // reads u + its half of xdbl for each of the two route pairs
         XpProfScope prof(("ss2d_pass1" + sfx).c_str(), s, el * (2.0 * R + 12.0) / 2.0, 4.0 * 2.0 * (MC + MX));
-        if (amp) hipLaunchKernelGGL((ss2d_pass1<R, false, true>), grid1, dim3(threads), sm1, s, p);
+        if (half_io && full) hipLaunchKernelGGL((ss2d_pass1<R, true, true, _Float16>), grid1, dim3(threads), sm1, s, p);
+        else if (half_io) hipLaunchKernelGGL((ss2d_pass1<R, false, true, _Float16>), grid1, dim3(threads), sm1, s, p);
+        else if (amp) hipLaunchKernelGGL((ss2d_pass1<R, false, true>), grid1, dim3(threads), sm1, s, p);
         else if (full) hipLaunchKernelGGL((ss2d_pass1<R, true>), grid1, dim3(threads), sm1, s, p);
         else hipLaunchKernelGGL((ss2d_pass1<R, false>), grid1, dim3(threads), sm1, s, p);
     }
@@ -786,13 +812,17 @@ int launch_ss2d(const SS2DParams& p, hipStream_t s) {
     }
     {   // read u, xdbl half; write ya
         XpProfScope prof(("ss2d_pass3_row" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (2.0 * MC + MX));
-        if (amp) hipLaunchKernelGGL((ss2d_pass3<R, false, false, true>), grid3, dim3(threads), sm3, s, p);
+        if (half_io && full) hipLaunchKernelGGL((ss2d_pass3<R, false, true, true, _Float16>), grid3, dim3(threads), sm3, s, p);
+        else if (half_io) hipLaunchKernelGGL((ss2d_pass3<R, false, false, true, _Float16>), grid3, dim3(threads), sm3, s, p);
+        else if (amp) hipLaunchKernelGGL((ss2d_pass3<R, false, false, true>), grid3, dim3(threads), sm3, s, p);
         else if (full) hipLaunchKernelGGL((ss2d_pass3<R, false, true>), grid3, dim3(threads), sm3, s, p);
         else hipLaunchKernelGGL((ss2d_pass3<R, false, false>), grid3, dim3(threads), sm3, s, p);
     }
     {   // read u, ya, xdbl half; write out (after out_norm)
         XpProfScope prof(("ss2d_pass3_col_ln" + sfx).c_str(), s, el * (2.0 * R + 14.0) / 4.0, 4.0 * (3.0 * MC + MX));
-        if (amp) hipLaunchKernelGGL((ss2d_pass3<R, true, false, true>), grid3, dim3(threads), sm3, s, p);
+        if (half_io && full) hipLaunchKernelGGL((ss2d_pass3<R, true, true, true, _Float16>), grid3, dim3(threads), sm3, s, p);
+        else if (half_io) hipLaunchKernelGGL((ss2d_pass3<R, true, false, true, _Float16>), grid3, dim3(threads), sm3, s, p);
+        else if (amp) hipLaunchKernelGGL((ss2d_pass3<R, true, false, true>), grid3, dim3(threads), sm3, s, p);
         else if (full) hipLaunchKernelGGL((ss2d_pass3<R, true, true>), grid3, dim3(threads), sm3, s, p);
         else hipLaunchKernelGGL((ss2d_pass3<R, true, false>), grid3, dim3(threads), sm3, s, p);
     }
@@ -819,24 +849,25 @@ extern "C" size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C) {
     return (size_t)(chunked > sequential ? chunked : sequential) * sizeof(float);
 }
 
-extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const float* dt_bias,
-                                const float* A, const float* Ds, const float* ln_w, const float* ln_b, float* out,
-                                float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
-                                int dstate, float eps, void* stream) {
-    XP_CHECK_ARG(u && xdbl && wdt && dt_bias && A && Ds && ln_w && ln_b && out && workspace, "xp_ss2d_core_fwd: null pointer");
-    XP_CHECK_ARG(dstate == 1, "xp_ss2d_core_fwd: only d_state == 1 (the XPoint config) is implemented in the fused core; "
-                              "use xp_selective_scan_fwd for general d_state (got %d)", dstate);
-    XP_CHECK_ARG(batch > 0 && H > 0 && W > 0, "xp_ss2d_core_fwd: bad shape");
-    XP_CHECK_ARG(C % 32 == 0 && C >= 32 && C <= 768, "xp_ss2d_core_fwd: C must be a multiple of 32 in [32,768] (got %d)", C);
-    XP_CHECK_ARG(workspace_bytes >= xp_ss2d_core_workspace_bytes(batch, H, W, C), "xp_ss2d_core_fwd: workspace too small");
-    XP_CHECK_ARG((int64_t)H * W * C < (1ll << 31), "xp_ss2d_core_fwd: one image plane (H*W*C) must stay below 2^31 elements");
+static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, const float* xdbl32, const float* wdt, const float* dt_bias,
+                          const float* A, const float* Ds, const float* ln_w, const float* ln_b, void* out,
+                          float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
+                          int dstate, float eps, bool half_io, void* stream) {
+    const char* who = half_io ? "xp_ss2d_core_fwd_f16" : "xp_ss2d_core_fwd";
+    XP_CHECK_ARG(u && xdbl && wdt && dt_bias && A && Ds && ln_w && ln_b && out && workspace, "%s: null pointer", who);
+    XP_CHECK_ARG(dstate == 1, "%s: only d_state == 1 (the XPoint config) is implemented in the fused core; "
+                              "use xp_selective_scan_fwd for general d_state (got %d)", who, dstate);
+    XP_CHECK_ARG(batch > 0 && H > 0 && W > 0, "%s: bad shape", who);
+    XP_CHECK_ARG(C % 32 == 0 && C >= 32 && C <= 768, "%s: C must be a multiple of 32 in [32,768] (got %d)", who, C);
+    XP_CHECK_ARG(workspace_bytes >= xp_ss2d_core_workspace_bytes(batch, H, W, C), "%s: workspace too small", who);
+    XP_CHECK_ARG((int64_t)H * W * C < (1ll << 31), "%s: one image plane (H*W*C) must stay below 2^31 elements", who);
     SS2DParams p;
-    p.u = u; p.xdbl = xdbl; p.wdt = wdt; p.dtb = dt_bias; p.A = A; p.Dp = Ds; p.ln_w = ln_w; p.ln_b = ln_b;
-    p.out = out; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
+    p.u = (const float*)u; p.xdbl = (const float*)xdbl; p.wdt = wdt; p.dtb = dt_bias; p.A = A; p.Dp = Ds; p.ln_w = ln_w; p.ln_b = ln_b;
+    p.out = (float*)out; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
     // threads = cpb * C must be a multiple of 64 and <= 768
     int cpb = 1;
     if (C < 192) { cpb = 192 / C; while ((cpb * C) % 64) ++cpb; }
-    XP_CHECK_ARG((cpb * C) % 64 == 0 && cpb * C <= 768, "xp_ss2d_core_fwd: unsupported C=%d", C);
+    XP_CHECK_ARG((cpb * C) % 64 == 0 && cpb * C <= 768, "%s: unsupported C=%d", who, C);
     p.cpb = cpb;
     // chunk length: keeps the pass-3 LDS tile (cpb*T*C floats) near 12 KB so that many workgroups share a CU (measured best on MI355X)
     static const int t_budget = getenv("XP_SS2D_TBUDGET") ? atoi(getenv("XP_SS2D_TBUDGET")) : 3072;
@@ -857,30 +888,60 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
     const int mode = g_ss2d_mode.load();
     static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
     const bool seq2 = seq_scan2_applies(R, H, W, C);
-    // (the mixed-precision class always takes the chunked form: its dt rounding lives in step_vals)
-    const bool seq = xp_amp_value() ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512))));
+    // (the f32-container mixed-precision class always takes the chunked form: its dt rounding lives in step_vals; the fp16-storage class takes the
+    //  sequential form when the caller supplied f32 copies of u and xdbl — xp_ss2d_core_f16_wants_f32_copies says when it will)
+    bool seq = (!half_io && xp_amp_value()) ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512))));
+    if (half_io && !(seq2 && u32 && xdbl32)) seq = false;
     if (seq && C <= 768 && C % 64 == 0) {
+        if (half_io) { p.u = u32; p.xdbl = xdbl32; }
         switch (R) {
-            case 2: return launch_ss2d_seq<2>(p, workspace, s);
-            case 4: return launch_ss2d_seq<4>(p, workspace, s);
-            case 6: return launch_ss2d_seq<6>(p, workspace, s);
-            case 8: return launch_ss2d_seq<8>(p, workspace, s);
-            case 12: return launch_ss2d_seq<12>(p, workspace, s);
-            case 16: return launch_ss2d_seq<16>(p, workspace, s);
-            case 24: return launch_ss2d_seq<24>(p, workspace, s);
-            case 48: return launch_ss2d_seq<48>(p, workspace, s);
+            case 2: return launch_ss2d_seq<2>(p, workspace, s, half_io);
+            case 4: return launch_ss2d_seq<4>(p, workspace, s, half_io);
+            case 6: return launch_ss2d_seq<6>(p, workspace, s, half_io);
+            case 8: return launch_ss2d_seq<8>(p, workspace, s, half_io);
+            case 12: return launch_ss2d_seq<12>(p, workspace, s, half_io);
+            case 16: return launch_ss2d_seq<16>(p, workspace, s, half_io);
+            case 24: return launch_ss2d_seq<24>(p, workspace, s, half_io);
+            case 48: return launch_ss2d_seq<48>(p, workspace, s, half_io);
             default: break;
         }
     }
     switch (R) {
-        case 2: return launch_ss2d<2>(p, s);
-        case 4: return launch_ss2d<4>(p, s);
-        case 6: return launch_ss2d<6>(p, s);
-        case 8: return launch_ss2d<8>(p, s);
-        case 12: return launch_ss2d<12>(p, s);
-        case 16: return launch_ss2d<16>(p, s);
-        case 24: return launch_ss2d<24>(p, s);
-        case 48: return launch_ss2d<48>(p, s);
-        default: xp_set_error("xp_ss2d_core_fwd: dt_rank %d not instantiated (2,4,6,8,12,16,24,48)", R); return XP_ERR_ARG;
+        case 2: return launch_ss2d<2>(p, s, half_io);
+        case 4: return launch_ss2d<4>(p, s, half_io);
+        case 6: return launch_ss2d<6>(p, s, half_io);
+        case 8: return launch_ss2d<8>(p, s, half_io);
+        case 12: return launch_ss2d<12>(p, s, half_io);
+        case 16: return launch_ss2d<16>(p, s, half_io);
+        case 24: return launch_ss2d<24>(p, s, half_io);
+        case 48: return launch_ss2d<48>(p, s, half_io);
+        default: xp_set_error("%s: dt_rank %d not instantiated (2,4,6,8,12,16,24,48)", who, R); return XP_ERR_ARG;
     }
+}
+
+extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const float* dt_bias,
+                                const float* A, const float* Ds, const float* ln_w, const float* ln_b, float* out,
+                                float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
+                                int dstate, float eps, void* stream) {
+    return ss2d_core_impl(u, xdbl, nullptr, nullptr, wdt, dt_bias, A, Ds, ln_w, ln_b, out, workspace, workspace_bytes, batch, H, W, C, R, dstate, eps, false, stream);
+}
+
+// Would xp_ss2d_core_fwd_f16 take the sequential (deep-stage) form for this per-image shape if it is given f32 copies of u and xdbl?  (A per-image
+// predicate like the f32 class's: never depends on the batch.)
+extern "C" int xp_ss2d_core_f16_wants_f32_copies(int H, int W, int C, int R) {
+    const int mode = g_ss2d_mode.load();
+    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
+    if (!(seq_scan2_applies(R, H, W, C) && C <= 768 && C % 64 == 0)) return 0;
+    return mode >= 0 ? (mode != 0) : (H * W <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512)));
+}
+
+// The fast mixed-precision class's core: u (batch,H,W,C) and xdbl (batch*H*W, 4*(R+2)) are fp16, out is fp16 (= out_norm's f32 result cast to half,
+// VMamba.py:646); the scan state, softplus / exp and out_norm run in f32 (csms6s.py:47-67); the dt projection's output is rounded to fp16 before the f32
+// bias (a half convolution under autocast).  u_f32 / xdbl_f32: optional f32 copies of the same tensors — when given and the shape is a deep-stage one
+// (xp_ss2d_core_f16_wants_f32_copies) the one-wave-per-route sequential kernels run on them.
+extern "C" int xp_ss2d_core_fwd_f16(const void* u, const void* xdbl, const float* u_f32, const float* xdbl_f32, const float* wdt, const float* dt_bias,
+                                    const float* A, const float* Ds, const float* ln_w, const float* ln_b, void* out,
+                                    float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
+                                    int dstate, float eps, void* stream) {
+    return ss2d_core_impl(u, xdbl, u_f32, xdbl_f32, wdt, dt_bias, A, Ds, ln_w, ln_b, out, workspace, workspace_bytes, batch, H, W, C, R, dstate, eps, true, stream);
 }

@@ -31,10 +31,12 @@ class _ModelCfg(ctypes.Structure):
 _LoadResult = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 _DIR_ORDER = [0, 2, 1, 3]   # device order of the four scan routes (row pair, then column pair)
-_DENSE_PRODUCTS = {"h2": 6, "x3": 6, "x2": 3, "bf16": 1, "f32": 6, "amp16": 6}   # gemm_mode -> partial products of the split-bf16 kernels
+_DENSE_PRODUCTS = {"h2": 6, "x3": 6, "x2": 3, "bf16": 1, "f32": 6, "amp16": 6, "amp16f": 6}   # gemm_mode -> partial products of the split-bf16 kernels
 _DENSE_ENGINE = {"h2": 1, "amp16": 1}                                 # gemm_mode -> xp_set_dense_engine (default 0 = x3)
 # "amp16": the reference's mixed_precision deployment class (XPoint.py:182, autocast; half is its default dtype) — xp_set_amp_mode(1): fp16 rounding
 # at every autocast boundary on the split-fp16 engine, weights of the convolutions / linear layers rounded to fp16 (what autocast casts).
+# "amp16f": the same recipe with HALF STORAGE (xp_xpoint_forward_f16: fp16 tensors in HBM, one-product fp16 MFMA GEMMs, csrc/gemm_f16.hip) — the fast
+# deployment class; same rounding points, same fixture (g20).
 
 
 class XPoint(torch.nn.Module):
@@ -439,7 +441,8 @@ class XPoint(torch.nn.Module):
             raise RuntimeError(f"XPoint.gemm_mode must be one of {sorted(_DENSE_PRODUCTS)}, got {self.gemm_mode!r}")
         mode = self.effective_gemm_mode()
         split_mode = mode != "f32"
-        amp = mode == "amp16"
+        amp = mode in ("amp16", "amp16f")
+        fast16 = mode == "amp16f"
         blob = self._blob_t if thermal else self._blob
         ws_split = self._wsplit_t if thermal else self._wsplit
         if amp:
@@ -451,7 +454,16 @@ class XPoint(torch.nn.Module):
                 b16 = self.pack_weights(("thermal" if thermal else "optical") if self.config['multispectral'] else None, amp=True).to(dev)
                 self._amp_w[key] = (b16, None)
             blob, ws_split = self._amp_w[key]
-        if split_mode and ws_split is None:
+        if fast16:
+            # fp16 (N, K) copies of the GEMM weights, converted on the device from the amp blob (whose values are fp16-exact already)
+            k16 = key + "/f16"
+            if k16 not in self._amp_w:
+                nb = lib.xp_f16_weights_bytes(self._ctx)
+                w16 = torch.empty(nb, dtype=torch.uint8, device=dev)
+                _lib.check(lib.xp_prepare_f16_weights(self._ctx, ptr(blob), ptr(w16), ctypes.c_size_t(nb), _lib.current_stream()), "xp_prepare_f16_weights")
+                self._amp_w[k16] = (w16, None)
+            w16 = self._amp_w[k16][0]
+        if split_mode and ws_split is None and not fast16:
             nb = lib.xp_split_weights_bytes(self._ctx)
             ws_split = torch.empty(nb, dtype=torch.uint8, device=dev)
             _lib.check(lib.xp_prepare_split_weights(self._ctx, ptr(blob), ptr(ws_split), ctypes.c_size_t(nb),
@@ -462,7 +474,7 @@ class XPoint(torch.nn.Module):
                 self._wsplit_t = ws_split
             else:
                 self._wsplit = ws_split
-        wsplit = ptr(ws_split) if split_mode else None
+        wsplit = ptr(ws_split) if (split_mode and not fast16) else None
         Hc = c_i(); Wc = c_i(); Ce = c_i()
         _lib.check(lib.xp_forward_shapes(self._ctx, n, H, W, ctypes.byref(Hc), ctypes.byref(Wc), ctypes.byref(Ce)), "xp_forward_shapes")
         Hc, Wc, Ce = Hc.value, Wc.value, Ce.value
@@ -478,6 +490,11 @@ class XPoint(torch.nn.Module):
         # the precision class is process-wide in the library and read when a kernel is launched: set for the duration of this
         # (host-synchronous) enqueue, then back to the default.  Not safe against OTHER host threads enqueueing dense kernels at the
         # same time: one enqueueing thread per process (the reference's scripts are single-threaded; multi-GPU = one process per GPU)
+        if fast16:      # its own entry point: no process-wide switches involved
+            _lib.check(lib.xp_xpoint_forward_f16(self._ctx, ptr(blob), ptr(w16), ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                 ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
+                                                 ptr(self.status_word(dev)), _lib.current_stream()), "xp_xpoint_forward_f16")
+            return out
         nprod = _DENSE_PRODUCTS[mode]
         engine = _DENSE_ENGINE.get(mode, 0)
         prev = int(lib.xp_get_dense_products())          # whatever XP_DENSE_PRODUCTS / an earlier caller left: restored afterwards
