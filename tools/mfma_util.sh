@@ -1,9 +1,10 @@
 #!/bin/bash
 # MFMA utilisation per kernel of one single-stream bench step: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/mfma_util; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d > $OUT/p1.log 2>&1 || echo "pass failed: $(tail -2 $OUT/p1.log)"
-python3 - "$OUT" > $R/gpurun_out/mfma_utilisation.txt <<'PY'
+# XP_MFMA_UTIL_ARGS: extra bench.py arguments (e.g. "--precision-class amp16f"); XP_MFMA_UTIL_TAG: suffix of the output files
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAGSFX=${XP_MFMA_UTIL_TAG:+_$XP_MFMA_UTIL_TAG}; OUT=$R/gpurun_out/mfma_util$TAGSFX; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d $XP_MFMA_UTIL_ARGS > $OUT/p1.log 2>&1 || echo "pass failed: $(tail -2 $OUT/p1.log)"
+python3 - "$OUT" "$TAGSFX" > $R/gpurun_out/mfma_utilisation$TAGSFX.txt <<'PY'
 import collections, csv, glob, os, re, sys
 d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
@@ -24,6 +25,6 @@ for _, k, n, cyc, ins, busy, u in sorted(rows, reverse=True):
 import json
 json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on bench.py --no-overlap; mfma_busy_frac = busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), per-launch average",
            "kernels": {k: {"launches": n, "kernel_cycles": cyc, "mfma_instr": ins, "mfma_busy_frac": u} for _, k, n, cyc, ins, busy, u in rows}},
-          open(os.path.join(os.path.dirname(sys.argv[1]), "pmc_mfma.json"), "w"), indent=1)
+          open(os.path.join(os.path.dirname(sys.argv[1]), "pmc_mfma" + sys.argv[2] + ".json"), "w"), indent=1)
 PY
-cat $R/gpurun_out/mfma_utilisation.txt
+cat $R/gpurun_out/mfma_utilisation$TAGSFX.txt

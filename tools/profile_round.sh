@@ -22,6 +22,13 @@ bash $R/tools/mfma_util.sh > /dev/null 2>&1
 cp $R/gpurun_out/mfma_utilisation.txt $OUT/
 cp $R/gpurun_out/pmc_mfma.json $OUT/; cp $R/gpurun_out/pmc_mfma.json $R/profiles/pmc_mfma.json
 python3 $R/tools/match_bench.py 4060 8192 8 > $OUT/match_microbench.txt 2>&1
+# the fast mixed-precision class (gemm_mode amp16f: half storage): its own bench line, kernel stats and MFMA-busy counters — never the headline
+python3 $R/bench.py --precision-class amp16f --no-cpu-baseline --no-h2d > $OUT/amp16f_bench.json 2> $OUT/amp16f_hip_event_breakdown.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats16 -- python3 $R/bench.py --precision-class amp16f --steps 5 --warmup 2 $COMMON > /dev/null 2>&1
+cp $(find $OUT/stats16 -name "*kernel_stats.csv" | head -1) $OUT/amp16f_kernel_stats.csv; rm -rf $OUT/stats16
+XP_MFMA_UTIL_ARGS="--precision-class amp16f" XP_MFMA_UTIL_TAG=amp16f bash $R/tools/mfma_util.sh > /dev/null 2>&1
+cp $R/gpurun_out/mfma_utilisation_amp16f.txt $OUT/amp16f_mfma_utilisation.txt; cp $R/gpurun_out/pmc_mfma_amp16f.json $OUT/amp16f_pmc_mfma.json
+GB_F16=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_f16_microbench.txt 2>&1
 GB_H2=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_h2_microbench.txt 2>&1
 GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1
 python3 $R/tools/scan_bench.py > $OUT/selective_scan_microbench.txt 2>&1

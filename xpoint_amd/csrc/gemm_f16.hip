@@ -26,8 +26,9 @@ typedef __attribute__((address_space(3))) void* f16_lds_ptr_t;
 
 namespace {
 
-constexpr int F16_BK = 64;             // halves per slab row = 128 bytes
-constexpr int F16_ROWB = 128;
+// Slab depth BK (halves): 64 (128-byte LDS rows, 8 slots, rows permuted by (r >> 1) & 7) for the K loops that keep the matrix pipe busy; 32 (64-byte rows, 4 slots,
+// permuted by (r >> 2) & 3) for the SHORT contractions (K <= 192: stage 0 / 1, where a tile's life is DMA latency + epilogue): half the LDS per workgroup — four
+// workgroups per CU instead of two — and K = 96 is three whole slabs instead of one and a half.
 
 struct F16Params {
     const _Float16* A; const _Float16* W; void* C;
@@ -42,21 +43,25 @@ __device__ __attribute__((aligned(64))) unsigned int g_f16_zero_page[16];      /
 
 __device__ __forceinline__ float f16_r(float v) { return (float)(_Float16)v; }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BK>
 struct F16Tile {
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64, NW = WM * WN;
-    static constexpr int PA = BM / 8, PB = BN / 8;                  // 1-KB DMA pieces (8 rows) per slab
+    static constexpr int ROWB = BK * 2, SLOTS = BK / 8, RPP = 1024 / ROWB;       // bytes per LDS row, 16-byte slots per row, rows per 1-KB DMA piece
+    static constexpr int PA = BM / RPP, PB = BN / RPP;              // DMA pieces per slab
     static constexpr int PA_W = (PA + NW - 1) / NW, PB_W = (PB + NW - 1) / NW;
-    static constexpr int kBufBytes = (BM + BN) * F16_ROWB;
+    static constexpr int kBufBytes = (BM + BN) * ROWB;
+    // slot permutation of row r (the same involution on the DMA source address and on the fragment read): 16 consecutive rows at one logical slot cover all banks
+    __device__ static __forceinline__ int swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
     static constexpr int WROWS = TM * 32, WCOLS = TN * 32;          // a wave's output tile
     static constexpr int kOutBytes = NW * WROWS * WCOLS * 2;
     static constexpr size_t kLdsBytes = (2 * kBufBytes > kOutBytes ? 2 * kBufBytes : kOutBytes);
 };
 
 // MODE 0: plain A (M, lda).  MODE 1: implicit 3x3 convolution.
-template <int WM, int WN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) {
-    using T = F16Tile<WM, WN, TM, TN>;
+template <int WM, int WN, int TM, int TN, int MODE, int BK>
+__global__ __launch_bounds__(WM * WN * 64, BK == 64 ? 2 : 4) void gemm_f16_kernel(F16Params p) {
+    using T = F16Tile<WM, WN, TM, TN, BK>;
+    constexpr int F16_BK = BK, F16_ROWB = T::ROWB;
     extern __shared__ __align__(16) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,8 +77,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) 
     const int m0 = (tile / ntn) * T::BM, n0 = (tile % ntn) * T::BN;
     const char* zero = reinterpret_cast<const char*>(g_f16_zero_page);
 
-    // ---- DMA plan: piece = 8 tile rows x 128 B; lane l of the issuing wave writes LDS row (l >> 3), physical slot (l & 7), and therefore FETCHES the
-    //      logical slot (l & 7) ^ ((row >> 1) & 7) of that row ----
+    // ---- DMA plan: piece = 1 KB = RPP tile rows; lane l of the issuing wave writes LDS row (l / SLOTS), physical slot (l % SLOTS), and therefore FETCHES the
+    //      logical slot (l % SLOTS) ^ swz(row) of that row ----
     const char* a_ptr[T::PA_W]; int a_klim[T::PA_W];          // MODE 0: byte pointer to (row, logical slot) at k = 0; k limit: slab t is real iff 64 t < klim
     const char* b_ptr[T::PB_W]; int b_klim[T::PB_W];
     int a_ls[T::PA_W];                                         // logical slot (MODE 1 needs it per slab)
@@ -81,8 +86,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) 
 #pragma unroll
     for (int i = 0; i < T::PA_W; ++i) {
         const int piece = wave + i * T::NW;
-        const int row = piece * 8 + (lane >> 3);
-        const int ls = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = piece * T::RPP + lane / T::SLOTS;
+        const int ls = (lane % T::SLOTS) ^ T::swz(row);
         const int grow = m0 + row;
         const bool ok = piece < T::PA && grow < p.M;
         a_ls[i] = ls;
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) 
 #pragma unroll
     for (int i = 0; i < T::PB_W; ++i) {
         const int piece = wave + i * T::NW;
-        const int row = piece * 8 + (lane >> 3);
-        const int ls = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = piece * T::RPP + lane / T::SLOTS;
+        const int ls = (lane % T::SLOTS) ^ T::swz(row);
         const int gcol = n0 + row;
         const bool ok = piece < T::PB && gcol < p.N;
         b_ptr[i] = reinterpret_cast<const char*>(p.W + (int64_t)(ok ? gcol : 0) * p.K + ls * 8);
@@ -152,9 +157,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment addresses: lane (fr, h) reads the 8 halves k = 16 ks + 8 h .. + 7 of row (base + fr): logical slot 2 ks + h, physical slot = logical ^ ((fr >> 1) & 7)
+    // fragment addresses: lane (fr, h) reads the 8 halves k = 16 ks + 8 h .. + 7 of row (base + fr): logical slot 2 ks + h, physical slot = logical ^ swz(fr)
+    // (tile row bases are multiples of 32, so swz(row) = swz(fr))
     const int fr = lane & 31, fh = lane >> 5;
-    const int cx = (fh ^ ((fr >> 1) & 7)) << 4;
+    const int cx = (fh ^ T::swz(fr)) << 4;
     const int a_frag = (wm * TM * 32 + fr) * F16_ROWB, b_frag = (T::BM + wn * TN * 32 + fr) * F16_ROWB;
 
     const int nslab = (p.K + F16_BK - 1) / F16_BK;
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) 
         };
         frags(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) frags(ks + 1, (ks + 1) & 1);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -258,34 +264,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_f16_kernel(F16Params p) 
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BK>
 void f16_launch(const F16Params& p, hipStream_t s) {
-    using T = F16Tile<WM, WN, TM, TN>;
+    using T = F16Tile<WM, WN, TM, TN, BK>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 0, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 1, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
         attr_set = true;
     }
     const int grid = xp_cdiv(p.M, T::BM) * xp_cdiv(p.N, T::BN);
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = std::string(p.Ci ? "conv3x3_f16_mfma_" : "gemm_f16_mfma_") + std::to_string(T::BM) + "x" + std::to_string(T::BN);
+    std::string tag = std::string(p.Ci ? "conv3x3_f16_mfma_" : "gemm_f16_mfma_") + std::to_string(T::BM) + "x" + std::to_string(T::BN) + (BK == 32 ? "_k32" : "");
     if (by_shape) tag += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K);
     const double in_elems = p.Ci ? (double)p.M / (p.Ho * p.Wo) * p.Hi * p.Wi * p.Ci : (double)p.M * p.K;
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * p.N * p.K, 2.0 * (in_elems + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)) + (p.c_f32 ? 2.0 * p.M * p.N : 0.0));
-    if (p.Ci) hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 1>), dim3(grid), dim3(T::NT), T::kLdsBytes, s, p);
-    else hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 0>), dim3(grid), dim3(T::NT), T::kLdsBytes, s, p);
+    if (p.Ci) hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 1, BK>), dim3(grid), dim3(T::NT), T::kLdsBytes, s, p);
+    else hipLaunchKernelGGL((gemm_f16_kernel<WM, WN, TM, TN, 0, BK>), dim3(grid), dim3(T::NT), T::kLdsBytes, s, p);
 }
 
 int f16_dispatch(const F16Params& p, hipStream_t s) {
     static const int force = getenv("XP_F16_TILE") ? atoi(getenv("XP_F16_TILE")) : -1;      // tuning experiments only
     const int N = p.N;
     const int sel = force >= 0 ? force : N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2 : 3;
-    switch (sel) {
-        case 0: f16_launch<4, 1, 1, 1>(p, s); break;       // 128 x 32
-        case 1: f16_launch<4, 1, 1, 2>(p, s); break;       // 128 x 64
-        case 2: f16_launch<4, 1, 1, 3>(p, s); break;       // 128 x 96
-        default: f16_launch<2, 2, 2, 2>(p, s); break;      // 128 x 128
+    // slab depth: a property of the layer (K), never of the batch.  K <= 192 (plain GEMMs of stages 0 / 1, whose tiles live on DMA latency + epilogue): 32
+    static const int force_bk = getenv("XP_F16_BK") ? atoi(getenv("XP_F16_BK")) : 0;
+    const bool k32 = force_bk ? force_bk == 32 : (p.K <= 192 && !p.Ci);
+    if (k32) {
+        switch (sel) {
+            case 0: f16_launch<4, 1, 1, 1, 32>(p, s); break;
+            case 1: f16_launch<4, 1, 1, 2, 32>(p, s); break;
+            case 2: f16_launch<4, 1, 1, 3, 32>(p, s); break;
+            default: f16_launch<2, 2, 2, 2, 32>(p, s); break;
+        }
+    } else {
+        switch (sel) {
+            case 0: f16_launch<4, 1, 1, 1, 64>(p, s); break;       // 128 x 32
+            case 1: f16_launch<4, 1, 1, 2, 64>(p, s); break;       // 128 x 64
+            case 2: f16_launch<4, 1, 1, 3, 64>(p, s); break;       // 128 x 96
+            default: f16_launch<2, 2, 2, 2, 64>(p, s); break;      // 128 x 128
+        }
     }
     XP_LAUNCH_CHECK();
     return XP_OK;
