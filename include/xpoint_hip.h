@@ -148,6 +148,11 @@ int xp_gemm_nt_f16(const void* A, const void* W, void* C, int c_f32, const float
 int xp_conv3x3_nhwc_f16(const void* x, const void* W, void* y, int y_f32, const float* bias, const float* scale, const float* shift,
                         int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
 
+/* Fused MLP of a VSS block in that class (csrc/mlp_f16.hip; VMamba.py:110-128, :1230-1234):  x += fc2(GELU(fc1(a)))  with a = LayerNorm(x) (M, C) fp16 given,
+ * x (M, C) fp16 updated in place, W1 (4C, C), W2 (C, 4C) fp16, biases f32; the hidden activation stays on chip; roundings as the two xp_gemm_nt_f16 calls it
+ * replaces.  C in {32, 64, 96, 192} (xp_mlp_fused_f16_supported). */
+int xp_mlp_fused_f16_supported(int C, int H4);
+int xp_mlp_fused_f16(const void* a, void* x, const void* W1, const float* b1, const void* W2, const float* b2, int M, int C, int H4, void* stream);
 /* Glue kernels of the same class (csrc/elementwise_f16.hip): half tensors in HBM, f32 arithmetic, one rounding per autocast boundary (= the store). */
 int xp_stem_conv_ln_gelu_f16(const float* img, const float* w9co, const float* bias, const float* ln_w, const float* ln_b, void* y,
                              int batch, int H, int W, int CO, float eps, void* stream);

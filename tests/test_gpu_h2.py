@@ -378,3 +378,35 @@ def test_conv3x3_f16(gpu_lib, B, H, W, Ci, Co, stride, reflect, act):
     noise = 4e-6 * 9 * Ci * 0.05 * (float(sc.abs().max()) if sc is not None else 1.0)          # bound on sum |x||w| x f32 accumulation noise
     assert float(((d - noise).clamp_min(0) / _ulp16(mag)).max()) <= 2.01, float(((d - noise).clamp_min(0) / _ulp16(mag)).max())
     assert float((d == 0).double().mean()) > 0.97
+
+
+@pytest.mark.parametrize("M,C", [(300, 96), (1000, 192), (129, 32), (4100, 96), (77, 64)])
+def test_mlp_fused_f16(gpu_lib, M, C):
+    """xp_mlp_fused_f16 (fc1 + GELU + fc2 + residual, hidden activation on chip) == the two xp_gemm_nt_f16 launches it replaces, up to the order of the f32
+    accumulation in fc2 (the hidden values themselves must be bit-identical: same products, same k order), and == the float64 evaluation of the recipe."""
+    L = _lib()
+    H4 = 4 * C
+    a = _u(f"ma{M}{C}", (M, C)).half(); x = _u(f"mx{M}{C}", (M, C), -2, 2).half()
+    W1 = _u(f"mw1{C}", (H4, C), -0.15, 0.15).half(); W2 = _u(f"mw2{C}", (C, H4), -0.1, 0.1).half()
+    b1 = _u(f"mb1{C}", (H4,), -0.5, 0.5); b2 = _u(f"mb2{C}", (C,), -0.5, 0.5)
+    ad, xd, W1d, W2d, b1d, b2d = a.cuda(), x.cuda(), W1.cuda(), W2.cuda(), b1.cuda(), b2.cuda()
+    # unfused reference path on the device
+    hid = torch.empty((M, H4), device="cuda", dtype=torch.float16)
+    L.call("xp_gemm_nt_f16", L.ptr(ad), L.ptr(W1d), L.ptr(hid), 0, L.ptr(b1d), None, None, None, M, H4, C, C, H4, 0, 1, L.current_stream())
+    x2 = xd.clone()
+    L.call("xp_gemm_nt_f16", L.ptr(hid), L.ptr(W2d), L.ptr(x2), 0, L.ptr(b2d), None, None, L.ptr(x2), M, C, H4, H4, C, C, 0, L.current_stream())
+    x1 = torch.cat([xd.clone(), torch.full((1, C), 777.0, device="cuda", dtype=torch.float16)])
+    L.call("xp_mlp_fused_f16", L.ptr(ad), L.ptr(x1), L.ptr(W1d), L.ptr(b1d), L.ptr(W2d), L.ptr(b2d), M, C, H4, L.current_stream())
+    assert bool((x1[M] == 777.0).all()), "row past M written"
+    d = (x1[:M].float() - x2.float()).abs()
+    mag = torch.maximum(x2.float().abs(), (x2.float() - xd.float()).abs())
+    assert float((d / _ulp16(mag.double()).float()).max()) <= 2.01 and float((d == 0).float().mean()) > 0.98, (float((d / _ulp16(mag.double()).float()).max()), float((d == 0).float().mean()))
+    # float64 evaluation of the recipe
+    h = _r16(F.gelu(_r16((F.linear(a.double(), W1.double()) + b1.double()).float())).float())
+    y = _r16((F.linear(h, W2.double()) + b2.double()).float())
+    ref = _r16((y + x.double()).float())
+    d = (x1[:M].cpu().double() - ref).abs()
+    mag = torch.maximum(ref.abs(), y.abs())
+    noise = 4e-6 * F.linear(h.abs(), W2.double().abs())
+    assert float(((d - noise).clamp_min(0) / _ulp16(mag)).max()) <= 2.01
+    assert float((d == 0).double().mean()) > 0.95

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "xp_xpoint_forward_ex": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p],
     "xp_xpoint_forward_f16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p],
     "xp_prepare_f16_weights": [c_p, c_p, c_p, c_sz, c_p],
+    "xp_mlp_fused_f16": [c_p] * 6 + [c_i] * 3 + [c_p],
     "xp_stem_conv_ln_gelu_f16": [c_p] * 6 + [c_i] * 4 + [c_f, c_p],
     "xp_layernorm_f16": [c_p] * 4 + [c_l, c_i, c_f, c_p],
     "xp_dwconv3x3_silu_f16": [c_p] * 4 + [c_i] * 4 + [c_p],
@@ -107,6 +108,7 @@ _SIZE_QUERIES = {
     "xp_split_weights_h2_bytes": (c_sz, [c_i] * 2),
     "xp_split_weights_bytes": (c_sz, [c_p]),
     "xp_f16_weights_bytes": (c_sz, [c_p]),
+    "xp_mlp_fused_f16_supported": (c_i, [c_i, c_i]),
     "xp_ss2d_core_f16_wants_f32_copies": (c_i, [c_i] * 4),
     "xp_mlp_fused_x3_supported": (c_i, [c_i, c_i]),
     "xp_get_dense_products": (c_i, []),

@@ -1,0 +1,213 @@
+// Fused MLP of a VSS block in the fast mixed-precision class:   x += fc2( GELU( fc1( a ) ) )   with a = LayerNorm(x) given (half),
+// reference xpoint/models/vmamba_src/VMamba.py:110-128 (Mlp) + :1230-1234 (residual) under autocast: fc1 -> half, GELU -> half, fc2 -> half, add -> half.
+// The (M, 4C) hidden activation never leaves the CU: stage 0 writes and re-reads 236 MB of it per block as two GEMMs (fc1 + GELU 136 us, fc2 + residual 92 us
+// at 16 images of 480 x 640), and both of those launches are bound by their epilogues, not by the matrix pipe.
+//
+// CDNA4 mapping.  A workgroup = 4 waves x 32 rows (128 rows of a / x); a wave owns its rows end to end ("row stationary").  The hidden dimension is walked
+// in chunks of HC units:
+//   fc1, TRANSPOSED:  hT[hid][m] = sum_k W1[hid][k] a[m][k]   — W1 chunk rows as the MFMA "A" operand, the wave's own a rows as "B": the accumulator lane then
+//                     holds ROW m and four consecutive hidden units per register group, i.e. exactly what the second GEMM's A operand needs contiguous;
+//   epilogue 1:       + b1 -> r16 -> GELU -> r16, four halves packed per ds_write_b64 into the wave's PRIVATE LDS tile H[m][hid] (no barrier: one wave
+//                     writes and reads it, LDS operations of a wave execute in order);
+//   fc2:              acc2[m][n] += sum_hid H[m][hid] W2[n][hid]   — accumulators (32 rows x C columns per wave: C / 32 tiles) live across all chunks;
+//   epilogue 2:       + b2 -> r16 -> + x -> r16, staged through LDS (the wave's own rows of the a image, no longer needed) for 16-byte row-contiguous
+//                     residual loads and stores, as csrc/gemm_f16.hip does.
+// Operands arrive by LDS-DMA (global_load_lds_dwordx4) into PADDED row images — row stride = row bytes + 16, an odd number of 16-byte slots, so every
+// ds_read_b128 of 16 consecutive rows covers all banks; the DMA writes lane-linear, so the lanes that land on a pad slot fetch from a zero page.  The a image
+// (128 x C) is loaded once; W1 / W2 chunk images are double-buffered, the DMA of chunk c + 1 in flight behind the 24 MFMAs and the GELUs of chunk c, one
+// barrier per chunk.  One workgroup per CU (C = 96: 99 KB of LDS; C = 192: 118 KB with 32-wide chunks); the kernel is bound by the GELU's vector work
+// (one wave per SIMD: VALU and MFMA of a wave do not overlap, coexec_probe), not by HBM.
+#include <string>
+
+#include "xp_common.h"
+#include "../../include/xpoint_hip.h"
+
+typedef _Float16 m16x8 __attribute__((ext_vector_type(8)));
+typedef float m16acc __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* m16_lds_ptr_t;
+
+namespace {
+
+__device__ __attribute__((aligned(64))) unsigned int g_m16_zero_page[16];
+__device__ __forceinline__ float m16_r(float v) { return (float)(_Float16)v; }
+
+struct Mlp16Params {
+    const _Float16* A;      // (M, C)  LayerNorm(x)
+    _Float16* X;            // (M, C)  residual in, result out
+    const _Float16* W1;     // (4C, C)
+    const _Float16* W2;     // (C, 4C)
+    const float* b1; const float* b2;
+    int M;
+};
+
+template <int C>
+struct Mlp16Cfg {
+    static constexpr int H4 = 4 * C;
+    static constexpr int HC = C <= 96 ? 64 : 32;                 // hidden units per chunk
+    static constexpr int NCH = H4 / HC;
+    static constexpr int SPA = C / 8 + 1;                        // 16-byte slots per row of a K = C image (a, W1), incl. the pad slot
+    static constexpr int SPH = HC / 8 + 1;                       // ... of a K = HC image (H, W2)
+    static constexpr int A_BYTES = 128 * SPA * 16;
+    static constexpr int W1_BYTES = HC * SPA * 16;
+    static constexpr int W2_BYTES = C * SPH * 16;
+    static constexpr int H_BYTES = 4 * 32 * SPH * 16;
+    static constexpr int B1_BYTES = H4 * 4;
+    static constexpr int pieces(int bytes) { return (bytes + 1023) / 1024; }
+    // image offsets; DMA pieces are whole KB, so every image is padded up to one
+    static constexpr int OFF_A = 0;
+    static constexpr int OFF_W1 = pieces(A_BYTES) * 1024;
+    static constexpr int OFF_W2 = OFF_W1 + 2 * pieces(W1_BYTES) * 1024;
+    static constexpr int OFF_H = OFF_W2 + 2 * pieces(W2_BYTES) * 1024;
+    static constexpr int OFF_B1 = OFF_H + H_BYTES;
+    static constexpr int LDS_BYTES = OFF_B1 + B1_BYTES;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void mlp_f16_kernel(Mlp16Params p) {
+    using T = Mlp16Cfg<C>;
+    constexpr int HC = T::HC, SPA = T::SPA, SPH = T::SPH, JN = C / 32, JH = HC / 32;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * 128;
+    const char* zero = reinterpret_cast<const char*>(g_m16_zero_page);
+
+    // generic image fill: `rows` rows of `spr - 1` real 16-byte slots (+ 1 pad slot) each, row r from base + r * ld_bytes; rows >= valid are zero
+    auto fill = [&](unsigned char* dst, const char* base, int64_t ld_bytes, int rows, int valid, int spr) {
+        const int np = (rows * spr * 16 + 1023) / 1024;
+        for (int pc = wave; pc < np; pc += 4) {
+            const int slot = pc * 64 + lane;
+            const int r = slot / spr, c = slot - r * spr;
+            const char* src = (r < valid && c < spr - 1) ? base + (int64_t)r * ld_bytes + c * 16 : zero;
+            __builtin_amdgcn_global_load_lds(src, (m16_lds_ptr_t)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+    const int mvalid = min(128, p.M - m0);
+    fill(lds + T::OFF_A, reinterpret_cast<const char*>(p.A + (int64_t)m0 * C), C * 2, 128, mvalid, SPA);
+    auto issue_chunk = [&](int ch, int buf) {
+        fill(lds + T::OFF_W1 + buf * T::pieces(T::W1_BYTES) * 1024, reinterpret_cast<const char*>(p.W1 + (int64_t)ch * HC * C), C * 2, HC, HC, SPA);
+        fill(lds + T::OFF_W2 + buf * T::pieces(T::W2_BYTES) * 1024, reinterpret_cast<const char*>(p.W2 + (int64_t)ch * HC), T::H4 * 2, C, C, SPH);
+    };
+    issue_chunk(0, 0);
+    for (int i = threadIdx.x; i < T::H4; i += 256) reinterpret_cast<float*>(lds + T::OFF_B1)[i] = p.b1[i];
+
+    m16acc acc2[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+
+    const unsigned char* a_rows = lds + T::OFF_A + (wave * 32 + fr) * (SPA * 16) + fh * 16;        // this lane's a row, k offset 8 fh
+    unsigned char* h_tile = lds + T::OFF_H + wave * (32 * SPH * 16);
+    const float* b1s = reinterpret_cast<const float*>(lds + T::OFF_B1);
+
+    for (int ch = 0; ch < T::NCH; ++ch) {
+        const int buf = ch & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk ch (and, the first time, of the a image) have landed
+        __syncthreads();                                        // ... everybody's; everybody is done with the other W buffers (chunk ch - 1)
+        if (ch + 1 < T::NCH) issue_chunk(ch + 1, buf ^ 1);
+        const unsigned char* w1 = lds + T::OFF_W1 + buf * T::pieces(T::W1_BYTES) * 1024 + fr * (SPA * 16) + fh * 16;
+        const unsigned char* w2 = lds + T::OFF_W2 + buf * T::pieces(T::W2_BYTES) * 1024 + fr * (SPH * 16) + fh * 16;
+        // ---- fc1 (transposed): hT[jh] = W1chunk . a^T ----
+        m16acc hT[JH];
+#pragma unroll
+        for (int jh = 0; jh < JH; ++jh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hT[jh][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+            const m16x8 bfr = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
+#pragma unroll
+            for (int jh = 0; jh < JH; ++jh) {
+                const m16x8 afr = *reinterpret_cast<const m16x8*>(w1 + jh * 32 * (SPA * 16) + ks * 32);
+                hT[jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, hT[jh], 0, 0, 0);
+            }
+        }
+        // ---- epilogue 1: register r of tile jh = hidden unit 32 jh + (r & 3) + 8 (r >> 2) + 4 fh of row m = fr ----
+#pragma unroll
+        for (int jh = 0; jh < JH; ++jh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int hid0 = jh * 32 + 8 * g4 + 4 * fh;
+                const float4 bb = *reinterpret_cast<const float4*>(b1s + ch * HC + hid0);
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+                union { _Float16 h[4]; uint2 u; } pk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk.h[q] = (_Float16)xp_gelu_fast(m16_r(hT[jh][4 * g4 + q] + bv[q]));
+                *reinterpret_cast<uint2*>(h_tile + fr * (SPH * 16) + hid0 * 2) = pk.u;
+            }
+        // ---- fc2: acc2[jn] += H . W2chunk^T ----
+#pragma unroll
+        for (int ks = 0; ks < HC / 16; ++ks) {
+            const m16x8 afr = *reinterpret_cast<const m16x8*>(h_tile + fr * (SPH * 16) + fh * 16 + ks * 32);
+#pragma unroll
+            for (int jn = 0; jn < JN; ++jn) {
+                const m16x8 bfr = *reinterpret_cast<const m16x8*>(w2 + jn * 32 * (SPH * 16) + ks * 32);
+                acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, acc2[jn], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue 2: the wave's 32 x C tile -> its own rows of the a image (free now) as halves, then row-contiguous + residual -> x ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned char* ot = lds + T::OFF_A + wave * 32 * (SPA * 16);          // 32 rows x (SPA * 16) bytes: row stride SPA * 16 >= C * 2
+    constexpr int RS = SPA * 16;
+#pragma unroll
+    for (int jn = 0; jn < JN; ++jn) {
+        const int cl = jn * 32 + fr;
+        const float bi = p.b2[cl];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            *reinterpret_cast<_Float16*>(ot + rl * RS + cl * 2) = (_Float16)(acc2[jn][r] + bi);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int CPR = C / 8;
+#pragma unroll
+    for (int it = 0; it < (32 * CPR + 63) / 64; ++it) {
+        const int idx = it * 64 + lane;
+        if ((32 * CPR) % 64 != 0 && idx >= 32 * CPR) break;
+        const int rl = idx / CPR, cc = idx - rl * CPR;
+        const int grow = m0 + wave * 32 + rl;
+        if (grow >= p.M) continue;
+        m16x8 v = *reinterpret_cast<const m16x8*>(ot + rl * RS + cc * 16);
+        _Float16* xp = p.X + (int64_t)grow * C + cc * 8;
+        const m16x8 rv = *reinterpret_cast<const m16x8*>(xp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[e]);
+        *reinterpret_cast<m16x8*>(xp) = v;
+    }
+}
+
+template <int C>
+int mlp16_launch(const Mlp16Params& p, hipStream_t s) {
+    using T = Mlp16Cfg<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        attr_set = true;
+    }
+    const std::string tag = "mlp_fused_f16_c" + std::to_string(C);
+    XpProfScope prof(tag.c_str(), s, 2.0 * p.M * C * 8.0 * C, 2.0 * 3.0 * p.M * C);
+    hipLaunchKernelGGL(mlp_f16_kernel<C>, dim3(xp_cdiv(p.M, 128)), dim3(256), T::LDS_BYTES, s, p);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+}  // namespace
+
+extern "C" int xp_mlp_fused_f16_supported(int C, int H4) { return (C == 96 || C == 192 || C == 32 || C == 64) && H4 == 4 * C; }
+
+extern "C" int xp_mlp_fused_f16(const void* a, void* x, const void* W1, const float* b1, const void* W2, const float* b2, int M, int C, int H4, void* stream) {
+    XP_CHECK_ARG(a && x && W1 && b1 && W2 && b2, "xp_mlp_fused_f16: null pointer");
+    XP_CHECK_ARG(M > 0 && xp_mlp_fused_f16_supported(C, H4), "xp_mlp_fused_f16: unsupported shape C = %d, H4 = %d (C in {32, 64, 96, 192}, H4 = 4 C)", C, H4);
+    XP_CHECK_ARG((((uintptr_t)a | (uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0, "xp_mlp_fused_f16: buffers must be 16-byte aligned");
+    Mlp16Params p{(const _Float16*)a, (_Float16*)x, (const _Float16*)W1, (const _Float16*)W2, b1, b2, M};
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 32: return mlp16_launch<32>(p, s);
+        case 64: return mlp16_launch<64>(p, s);
+        case 96: return mlp16_launch<96>(p, s);
+        default: return mlp16_launch<192>(p, s);
+    }
+}
