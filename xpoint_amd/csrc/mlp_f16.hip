@@ -15,8 +15,9 @@
 // Operands arrive by LDS-DMA (global_load_lds_dwordx4) into PADDED row images — row stride = row bytes + 16, an odd number of 16-byte slots, so every
 // ds_read_b128 of 16 consecutive rows covers all banks; the DMA writes lane-linear, so the lanes that land on a pad slot fetch from a zero page.  The a image
 // (128 x C) is loaded once; W1 / W2 chunk images are double-buffered, the DMA of chunk c + 1 in flight behind the 24 MFMAs and the GELUs of chunk c, one
-// barrier per chunk.  One workgroup per CU (C = 96: 99 KB of LDS; C = 192: 118 KB with 32-wide chunks); the kernel is bound by the GELU's vector work
-// (one wave per SIMD: VALU and MFMA of a wave do not overlap, coexec_probe), not by HBM.
+// barrier per chunk.  32-wide hidden chunks: C <= 96 takes 67 KB of LDS and <= 128 registers — two workgroups per CU, so one wave's GELUs run under the
+// other's MFMAs (VALU and MFMA of ONE wave do not overlap, coexec_probe); C = 192 (118 KB, 96 accumulator registers) stays at one.  Bound by the GELU's
+// vector work (118 M evaluations per stage-0 block), not by HBM.
 #include <string>
 
 #include "xp_common.h"
@@ -43,7 +44,7 @@ struct Mlp16Params {
 template <int C>
 struct Mlp16Cfg {
     static constexpr int H4 = 4 * C;
-    static constexpr int HC = C <= 96 ? 64 : 32;                 // hidden units per chunk
+    static constexpr int HC = 32;                                // hidden units per chunk (64 was measured with one workgroup per CU: 221 us at C = 96)
     static constexpr int NCH = H4 / HC;
     static constexpr int SPA = C / 8 + 1;                        // 16-byte slots per row of a K = C image (a, W1), incl. the pad slot
     static constexpr int SPH = HC / 8 + 1;                       // ... of a K = HC image (H, W2)
@@ -63,7 +64,7 @@ struct Mlp16Cfg {
 };
 
 template <int C>
-__global__ __launch_bounds__(256, 1) void mlp_f16_kernel(Mlp16Params p) {
+__global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Params p) {
     using T = Mlp16Cfg<C>;
     constexpr int HC = T::HC, SPA = T::SPA, SPH = T::SPH, JN = C / 32, JH = HC / 32;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -114,13 +115,19 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_kernel(Mlp16Params p) {
         for (int jh = 0; jh < JH; ++jh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hT[jh][r] = 0.f;
+        {   // fragments of k-step ks + 1 are read before the MFMAs of ks (two register sets)
+            m16x8 bfr[2], afr[2][JH];
+            auto rd = [&](int ks, int set) {
+                bfr[set] = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
 #pragma unroll
-        for (int ks = 0; ks < C / 16; ++ks) {
-            const m16x8 bfr = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
+                for (int jh = 0; jh < JH; ++jh) afr[set][jh] = *reinterpret_cast<const m16x8*>(w1 + jh * 32 * (SPA * 16) + ks * 32);
+            };
+            rd(0, 0);
 #pragma unroll
-            for (int jh = 0; jh < JH; ++jh) {
-                const m16x8 afr = *reinterpret_cast<const m16x8*>(w1 + jh * 32 * (SPA * 16) + ks * 32);
-                hT[jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, hT[jh], 0, 0, 0);
+            for (int ks = 0; ks < C / 16; ++ks) {
+                if (ks + 1 < C / 16) rd(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int jh = 0; jh < JH; ++jh) hT[jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1][jh], bfr[ks & 1], hT[jh], 0, 0, 0);
             }
         }
         // ---- epilogue 1: register r of tile jh = hidden unit 32 jh + (r & 3) + 8 (r >> 2) + 4 fh of row m = fr ----
@@ -137,14 +144,18 @@ __global__ __launch_bounds__(256, 1) void mlp_f16_kernel(Mlp16Params p) {
                 *reinterpret_cast<uint2*>(h_tile + fr * (SPH * 16) + hid0 * 2) = pk.u;
             }
         // ---- fc2: acc2[jn] += H . W2chunk^T ----
+        {   // all fragments of the chunk up front (HC / 16 = 2 k-steps: 2 + 2 JN reads), then the MFMAs
+            m16x8 afr[HC / 16], bfr[HC / 16][JN];
 #pragma unroll
-        for (int ks = 0; ks < HC / 16; ++ks) {
-            const m16x8 afr = *reinterpret_cast<const m16x8*>(h_tile + fr * (SPH * 16) + fh * 16 + ks * 32);
+            for (int ks = 0; ks < HC / 16; ++ks) {
+                afr[ks] = *reinterpret_cast<const m16x8*>(h_tile + fr * (SPH * 16) + fh * 16 + ks * 32);
 #pragma unroll
-            for (int jn = 0; jn < JN; ++jn) {
-                const m16x8 bfr = *reinterpret_cast<const m16x8*>(w2 + jn * 32 * (SPH * 16) + ks * 32);
-                acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, acc2[jn], 0, 0, 0);
+                for (int jn = 0; jn < JN; ++jn) bfr[ks][jn] = *reinterpret_cast<const m16x8*>(w2 + jn * 32 * (SPH * 16) + ks * 32);
             }
+#pragma unroll
+            for (int ks = 0; ks < HC / 16; ++ks)
+#pragma unroll
+                for (int jn = 0; jn < JN; ++jn) acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks], bfr[ks][jn], acc2[jn], 0, 0, 0);
         }
     }
     // ---- epilogue 2: the wave's 32 x C tile -> its own rows of the a image (free now) as halves, then row-contiguous + residual -> x ----
