@@ -87,6 +87,22 @@ def test_model_config_and_state_dict_errors():
     assert dict_update({"a": {"b": 1, "c": 2}}, {"a": {"b": 3}}) == {"a": {"b": 3, "c": 2}}
 
 
+def test_config_precision_opt_in(monkeypatch):
+    """The f32 class is the default whatever `mixed_precision` says (the parity target is the reference's CPU path, which never autocasts, XPoint.py:182);
+    use_config_precision() / XP_HONOR_MIXED_PRECISION=1 select what the reference runs on a GPU."""
+    from xpoint_amd import models
+    cfg = synth.xpoint_exp1_config(64, 96)
+    assert cfg["mixed_precision"] is True
+    net = models.XPoint(cfg)
+    assert net.gemm_mode == "h2" and net.use_config_precision().gemm_mode == "amp16f"
+    cfg2 = synth.xpoint_exp1_config(64, 96); cfg2["mixed_precision"] = False
+    assert models.XPoint(cfg2).use_config_precision().gemm_mode == "h2"
+    monkeypatch.setenv("XP_HONOR_MIXED_PRECISION", "1")
+    assert models.XPoint(cfg).gemm_mode == "amp16f" and models.XPoint(cfg2).gemm_mode == "h2"
+    monkeypatch.setenv("XP_GEMM_MODE", "x3")
+    assert models.XPoint(cfg).gemm_mode == "x3"
+
+
 def test_get_matches_host_errors():
     from xpoint_amd.utils import get_matches
     a = np.zeros((0, 256), np.float32)

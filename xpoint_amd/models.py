@@ -83,6 +83,11 @@ class XPoint(torch.nn.Module):
         # h2 needs dense-layer operands below 65504: every forward reports a violation through a device status word
         # (xp_xpoint_forward_ex), and the host then re-runs on "x3" and stays there for this weight set (self._h2_off).
         self.gemm_mode = os.environ.get("XP_GEMM_MODE", "h2")
+        # The reference wraps its forward in autocast when config['mixed_precision'] is set AND it runs on CUDA (XPoint.py:182); its CPU path — the parity
+        # target — never does.  Default here: the f32 class whatever the flag says.  Opt in to the reference's GPU behaviour with
+        # XP_HONOR_MIXED_PRECISION=1 (or net.use_config_precision()): mixed_precision: true then selects the fast half-storage class "amp16f".
+        if os.environ.get("XP_HONOR_MIXED_PRECISION", "0") not in ("", "0") and "XP_GEMM_MODE" not in os.environ:
+            self.use_config_precision()
         self._h2_off = False
         self._status: Dict[str, torch.Tensor] = {}
         # RegNet head beyond 256x256 (opt-in, NOT reference semantics: the reference's head only accepts 256x256 inputs, RegNet.py:38-52):
@@ -326,6 +331,12 @@ class XPoint(torch.nn.Module):
     def effective_gemm_mode(self) -> str:
         """gemm_mode, with "h2" replaced by "x3" once this weight set has tripped the split-fp16 range guard."""
         return "x3" if (self.gemm_mode == "h2" and self._h2_off) else self.gemm_mode
+
+    def use_config_precision(self):
+        """Select the arithmetic class the REFERENCE would run on a GPU for this config: `mixed_precision: true` -> autocast (XPoint.py:182) = gemm_mode
+        "amp16f" (VMamba encoder only; the conv backbones stay f32-grade), else the f32 class.  Returns self."""
+        self.gemm_mode = "amp16f" if (self.config.get('mixed_precision') and self._kind == "vmamba") else "h2"
+        return self
 
     def status_word(self, device) -> torch.Tensor:
         """The device status word (int32[1]) that every forward on `device` ORs its XP_STATUS_* bits into (sticky until cleared)."""
