@@ -167,6 +167,8 @@ def visible_gpus():
     # SHORT-LIVED CHILD (torch.cuda.device_count() there), so that this process still never loads it.
     import glob as _glob
     render = len(_glob.glob("/dev/dri/renderD*"))
+    if n == 0 and not os.path.exists("/dev/kfd"):
+        return 0                                   # no compute driver node at all: nothing to ask (and the refusal stays instant)
     if n == 0 or (render and render < n):
         import subprocess
         try:
