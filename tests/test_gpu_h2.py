@@ -410,3 +410,26 @@ def test_mlp_fused_f16(gpu_lib, M, C):
     noise = 4e-6 * F.linear(h.abs(), W2.double().abs())
     assert float(((d - noise).clamp_min(0) / _ulp16(mag)).max()) <= 2.01
     assert float((d == 0).double().mean()) > 0.95
+
+
+@pytest.mark.parametrize("M,C", [(300, 96), (1000, 192), (129, 32)])
+def test_ln_mlp_fused_f16(gpu_lib, M, C):
+    """xp_ln_mlp_fused_f16 (norm2 folded into the fused MLP's prologue) == xp_layernorm_f16 followed by xp_mlp_fused_f16 up to the order of the two row sums of
+    the LayerNorm (two lanes per row instead of LPR): the LayerNorm outputs may differ by one fp16 ulp on a vanishing fraction of elements."""
+    L = _lib()
+    H4 = 4 * C
+    x = _u(f"lx{M}{C}", (M, C), -2, 2).half(); lw = _u(f"lw{C}", (C,), 0.5, 1.5); lb = _u(f"lb{C}", (C,), -0.5, 0.5)
+    W1 = _u(f"lw1{C}", (H4, C), -0.15, 0.15).half(); W2 = _u(f"lw2{C}", (C, H4), -0.1, 0.1).half()
+    b1 = _u(f"lb1{C}", (H4,), -0.5, 0.5); b2 = _u(f"lb2{C}", (C,), -0.5, 0.5)
+    xd, lwd, lbd, W1d, W2d, b1d, b2d = x.cuda(), lw.cuda(), lb.cuda(), W1.cuda(), W2.cuda(), b1.cuda(), b2.cuda()
+    a = torch.empty_like(xd)
+    L.call("xp_layernorm_f16", L.ptr(xd), L.ptr(a), L.ptr(lwd), L.ptr(lbd), M, C, 1e-5, L.current_stream())
+    x2 = xd.clone()
+    L.call("xp_mlp_fused_f16", L.ptr(a), L.ptr(x2), L.ptr(W1d), L.ptr(b1d), L.ptr(W2d), L.ptr(b2d), M, C, H4, L.current_stream())
+    x1 = torch.cat([xd.clone(), torch.full((1, C), 777.0, device="cuda", dtype=torch.float16)])
+    L.call("xp_ln_mlp_fused_f16", L.ptr(x1), L.ptr(lwd), L.ptr(lbd), 1e-5, L.ptr(W1d), L.ptr(b1d), L.ptr(W2d), L.ptr(b2d), M, C, H4, L.current_stream())
+    assert bool((x1[M] == 777.0).all()), "row past M written"
+    d = (x1[:M].float() - x2.float()).abs()
+    delta = (x2.float() - xd.float()).abs()                       # size of the MLP's contribution
+    assert float((d == 0).float().mean()) > 0.97, float((d == 0).float().mean())
+    assert float(d.max()) <= 4e-3 * max(1.0, float(delta.max())), (float(d.max()), float(delta.max()))

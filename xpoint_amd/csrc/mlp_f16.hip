@@ -39,6 +39,7 @@ struct Mlp16Params {
     const _Float16* W2;     // (C, 4C)
     const float* b1; const float* b2;
     int M;
+    const float* ln_w; const float* ln_b; float eps;      // ln_w != NULL: a = LayerNorm(X) is computed here (A unused) — VMamba.py:1230 `self.norm2(x)` folded in
 };
 
 template <int C>
@@ -84,7 +85,45 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Para
         }
     };
     const int mvalid = min(128, p.M - m0);
-    fill(lds + T::OFF_A, reinterpret_cast<const char*>(p.A + (int64_t)m0 * C), C * 2, 128, mvalid, SPA);
+    if (p.ln_w == nullptr) fill(lds + T::OFF_A, reinterpret_cast<const char*>(p.A + (int64_t)m0 * C), C * 2, 128, mvalid, SPA);
+    else {
+        // LayerNorm of the wave's own 32 rows straight into its rows of the a image: two lanes per row, C / 16 chunks of 8 halves each; two-pass statistics in
+        // f32 (as xp_layernorm_f16), the store to LDS rounds to fp16 = the half tensor LayerNorm returns under autocast
+        constexpr int CPL = C / 16;
+        const int r = lane >> 1, hs = lane & 1, grow = m0 + wave * 32 + r;
+        const bool rok = grow < p.M;
+        const m16x8* xr = reinterpret_cast<const m16x8*>(p.X + (int64_t)(rok ? grow : 0) * C) + hs * CPL;
+        float v[CPL][8];
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const m16x8 t = xr[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = (float)t[e];
+            sm += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+        }
+        sm += xp_dpp_mov<0xB1>(sm);                              // the row's other lane (quad_perm [1,0,3,2])
+        const float mean = sm / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+        q += xp_dpp_mov<0xB1>(q);
+        const float rstd = 1.f / sqrtf(q / (float)C + p.eps);
+        unsigned char* dst = lds + T::OFF_A + (wave * 32 + r) * (SPA * 16) + hs * CPL * 16;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c8 = hs * CPL + i;
+            const float4 w0 = reinterpret_cast<const float4*>(p.ln_w)[2 * c8], w1v = reinterpret_cast<const float4*>(p.ln_w)[2 * c8 + 1];
+            const float4 b0 = reinterpret_cast<const float4*>(p.ln_b)[2 * c8], b1v = reinterpret_cast<const float4*>(p.ln_b)[2 * c8 + 1];
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1v.x, w1v.y, w1v.z, w1v.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+            m16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rok ? (_Float16)((v[i][e] - mean) * rstd * wv[e] + bv[e]) : (_Float16)0.f;
+            *reinterpret_cast<m16x8*>(dst + i * 16) = o;
+        }
+    }
     auto issue_chunk = [&](int ch, int buf) {
         fill(lds + T::OFF_W1 + buf * T::pieces(T::W1_BYTES) * 1024, reinterpret_cast<const char*>(p.W1 + (int64_t)ch * HC * C), C * 2, HC, HC, SPA);
         fill(lds + T::OFF_W2 + buf * T::pieces(T::W2_BYTES) * 1024, reinterpret_cast<const char*>(p.W2 + (int64_t)ch * HC), T::H4 * 2, C, C, SPH);
@@ -198,7 +237,7 @@ int mlp16_launch(const Mlp16Params& p, hipStream_t s) {
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
         attr_set = true;
     }
-    const std::string tag = "mlp_fused_f16_c" + std::to_string(C);
+    const std::string tag = std::string(p.ln_w ? "ln_mlp_fused_f16_c" : "mlp_fused_f16_c") + std::to_string(C);
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * C * 8.0 * C, 2.0 * 3.0 * p.M * C);
     hipLaunchKernelGGL(mlp_f16_kernel<C>, dim3(xp_cdiv(p.M, 128)), dim3(256), T::LDS_BYTES, s, p);
     XP_LAUNCH_CHECK();
@@ -213,7 +252,23 @@ extern "C" int xp_mlp_fused_f16(const void* a, void* x, const void* W1, const fl
     XP_CHECK_ARG(a && x && W1 && b1 && W2 && b2, "xp_mlp_fused_f16: null pointer");
     XP_CHECK_ARG(M > 0 && xp_mlp_fused_f16_supported(C, H4), "xp_mlp_fused_f16: unsupported shape C = %d, H4 = %d (C in {32, 64, 96, 192}, H4 = 4 C)", C, H4);
     XP_CHECK_ARG((((uintptr_t)a | (uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0, "xp_mlp_fused_f16: buffers must be 16-byte aligned");
-    Mlp16Params p{(const _Float16*)a, (_Float16*)x, (const _Float16*)W1, (const _Float16*)W2, b1, b2, M};
+    Mlp16Params p{(const _Float16*)a, (_Float16*)x, (const _Float16*)W1, (const _Float16*)W2, b1, b2, M, nullptr, nullptr, 0.f};
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 32: return mlp16_launch<32>(p, s);
+        case 64: return mlp16_launch<64>(p, s);
+        case 96: return mlp16_launch<96>(p, s);
+        default: return mlp16_launch<192>(p, s);
+    }
+}
+
+// The same with norm2 folded in:  x += fc2(GELU(fc1(LayerNorm(x))))  (VMamba.py:1230-1234) — one launch and one pass over x less per block.
+extern "C" int xp_ln_mlp_fused_f16(void* x, const float* ln_w, const float* ln_b, float eps, const void* W1, const float* b1, const void* W2, const float* b2,
+                                   int M, int C, int H4, void* stream) {
+    XP_CHECK_ARG(x && ln_w && ln_b && W1 && b1 && W2 && b2, "xp_ln_mlp_fused_f16: null pointer");
+    XP_CHECK_ARG(M > 0 && xp_mlp_fused_f16_supported(C, H4), "xp_ln_mlp_fused_f16: unsupported shape C = %d, H4 = %d (C in {32, 64, 96, 192}, H4 = 4 C)", C, H4);
+    XP_CHECK_ARG((((uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0, "xp_ln_mlp_fused_f16: buffers must be 16-byte aligned");
+    Mlp16Params p{nullptr, (_Float16*)x, (const _Float16*)W1, (const _Float16*)W2, b1, b2, M, ln_w, ln_b, eps};
     hipStream_t s = (hipStream_t)stream;
     switch (C) {
         case 32: return mlp16_launch<32>(p, s);

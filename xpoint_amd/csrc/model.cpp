@@ -442,12 +442,15 @@ extern "C" int xp_xpoint_forward_f16(void* ctx, const float* weights, const void
                                      T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
             RUN(gemm(T1, b + "out_w", X, 0, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
             // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
-            RUN(xp_layernorm_f16(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, stream));
-            static const bool no_fused16 = getenv("XP_NO_FUSED_MLP_F16") != nullptr && atoi(getenv("XP_NO_FUSED_MLP_F16")) != 0;      // A/B: the two-GEMM form everywhere
-            if (!no_fused16 && xp_mlp_fused_f16_supported(C, H4)) {      // stages 0 - 1 (C <= 192): fc1 + GELU + fc2 + residual in one launch, hidden activation on chip (csrc/mlp_f16.hip)
-                RUN(xp_mlp_fused_f16(T1, X, WH(b + "fc1_w"), P(b + "fc1_b"), WH(b + "fc2_w"), P(b + "fc2_b"), M, C, H4, stream));
+            static const int no_fused16 = getenv("XP_NO_FUSED_MLP_F16") ? atoi(getenv("XP_NO_FUSED_MLP_F16")) : 0;      // A/B: 1 = the two-GEMM form everywhere, 2 = fused MLP behind a separate LayerNorm launch
+            if (no_fused16 != 1 && xp_mlp_fused_f16_supported(C, H4)) {      // stages 0 - 1 (C <= 192): norm2 + fc1 + GELU + fc2 + residual in one launch, hidden activation on chip (csrc/mlp_f16.hip)
+                if (no_fused16 == 2) {
+                    RUN(xp_layernorm_f16(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, stream));
+                    RUN(xp_mlp_fused_f16(T1, X, WH(b + "fc1_w"), P(b + "fc1_b"), WH(b + "fc2_w"), P(b + "fc2_b"), M, C, H4, stream));
+                } else RUN(xp_ln_mlp_fused_f16(X, P(b + "ln2_w"), P(b + "ln2_b"), eps, WH(b + "fc1_w"), P(b + "fc1_b"), WH(b + "fc2_w"), P(b + "fc2_b"), M, C, H4, stream));
                 continue;
             }
+            RUN(xp_layernorm_f16(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, stream));
             RUN(gemm(T1, b + "fc1_w", HB, 0, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
             RUN(gemm(HB, b + "fc2_w", X, 0, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));
         }
