@@ -156,6 +156,8 @@ int xp_mlp_fused_f16(const void* a, void* x, const void* W1, const float* b1, co
 /* ... with norm2 folded in (a = LayerNorm(x) computed in the kernel's prologue, rounded to fp16 like xp_layernorm_f16's output). */
 int xp_ln_mlp_fused_f16(void* x, const float* ln_w, const float* ln_b, float eps, const void* W1, const float* b1, const void* W2, const float* b2,
                         int M, int C, int H4, void* stream);
+/* norm + in_proj of a VSS block in one launch (VMamba.py:1225, :649):  y = LayerNorm(x) W^T,  x, y (M, C) fp16, W (C, C) fp16; C in {32, 64, 96, 192}. */
+int xp_ln_proj_f16(const void* x, const float* ln_w, const float* ln_b, float eps, const void* W, void* y, int M, int C, void* stream);
 /* Glue kernels of the same class (csrc/elementwise_f16.hip): half tensors in HBM, f32 arithmetic, one rounding per autocast boundary (= the store). */
 int xp_stem_conv_ln_gelu_f16(const float* img, const float* w9co, const float* bias, const float* ln_w, const float* ln_b, void* y,
                              int batch, int H, int W, int CO, float eps, void* stream);

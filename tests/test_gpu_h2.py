@@ -433,3 +433,21 @@ def test_ln_mlp_fused_f16(gpu_lib, M, C):
     delta = (x2.float() - xd.float()).abs()                       # size of the MLP's contribution
     assert float((d == 0).float().mean()) > 0.97, float((d == 0).float().mean())
     assert float(d.max()) <= 4e-3 * max(1.0, float(delta.max())), (float(d.max()), float(delta.max()))
+
+
+@pytest.mark.parametrize("M,C", [(300, 96), (1000, 192), (129, 32), (77, 64)])
+def test_ln_proj_f16(gpu_lib, M, C):
+    """xp_ln_proj_f16 (norm + in_proj in one launch) == xp_layernorm_f16 followed by xp_gemm_nt_f16, up to the order of the LayerNorm's row sums."""
+    L = _lib()
+    x = _u(f"px{M}{C}", (M, C), -2, 2).half(); lw = _u(f"pw{C}", (C,), 0.5, 1.5); lb = _u(f"pb{C}", (C,), -0.5, 0.5)
+    W = _u(f"pW{C}", (C, C), -0.15, 0.15).half()
+    xd, lwd, lbd, Wd = x.cuda(), lw.cuda(), lb.cuda(), W.cuda()
+    a = torch.empty_like(xd); y2 = torch.empty_like(xd)
+    L.call("xp_layernorm_f16", L.ptr(xd), L.ptr(a), L.ptr(lwd), L.ptr(lbd), M, C, 1e-5, L.current_stream())
+    L.call("xp_gemm_nt_f16", L.ptr(a), L.ptr(Wd), L.ptr(y2), 0, None, None, None, None, M, C, C, C, C, 0, 0, L.current_stream())
+    y1 = torch.full((M + 1, C), 777.0, device="cuda", dtype=torch.float16)
+    L.call("xp_ln_proj_f16", L.ptr(xd), L.ptr(lwd), L.ptr(lbd), 1e-5, L.ptr(Wd), L.ptr(y1), M, C, L.current_stream())
+    assert bool((y1[M] == 777.0).all()), "row past M written"
+    d = (y1[:M].float() - y2.float()).abs()
+    assert float((d == 0).float().mean()) > 0.97, float((d == 0).float().mean())
+    assert float(d.max()) <= 4e-3 * max(1.0, float(y2.float().abs().max())), float(d.max())

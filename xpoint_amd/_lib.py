@@ -74,6 +74,7 @@ _SIGNATURES = {
     "xp_xpoint_forward_f16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_p, c_p, c_p, c_p, c_p],
     "xp_prepare_f16_weights": [c_p, c_p, c_p, c_sz, c_p],
     "xp_mlp_fused_f16": [c_p] * 6 + [c_i] * 3 + [c_p],
+    "xp_ln_proj_f16": [c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_p],
     "xp_ln_mlp_fused_f16": [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p] + [c_i] * 3 + [c_p],
     "xp_stem_conv_ln_gelu_f16": [c_p] * 6 + [c_i] * 4 + [c_f, c_p],
     "xp_layernorm_f16": [c_p] * 4 + [c_l, c_i, c_f, c_p],

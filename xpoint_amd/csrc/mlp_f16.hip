@@ -64,6 +64,47 @@ struct Mlp16Cfg {
     static constexpr int LDS_BYTES = OFF_B1 + B1_BYTES;
 };
 
+// LayerNorm of a wave's own 32 rows (rows m0 + 32 wave ..) of x straight into its rows of a padded a image: two lanes per row, C / 16 chunks of 8 halves each;
+// two-pass statistics in f32 (as xp_layernorm_f16), the store to LDS rounds to fp16 = the half tensor LayerNorm returns under autocast.  Rows past M are zeros.
+template <int C>
+__device__ __forceinline__ void mlp16_ln_rows(const _Float16* __restrict__ X, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M,
+                                              int m0, int wave, int lane, unsigned char* a_image, int SPA) {
+    constexpr int CPL = C / 16;
+    const int r = lane >> 1, hs = lane & 1, grow = m0 + wave * 32 + r;
+    const bool rok = grow < M;
+    const m16x8* xr = reinterpret_cast<const m16x8*>(X + (int64_t)(rok ? grow : 0) * C) + hs * CPL;
+    float v[CPL][8];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const m16x8 t = xr[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = (float)t[e];
+        sm += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    }
+    sm += xp_dpp_mov<0xB1>(sm);                              // the row's other lane (quad_perm [1,0,3,2])
+    const float mean = sm / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+    q += xp_dpp_mov<0xB1>(q);
+    const float rstd = 1.f / sqrtf(q / (float)C + eps);
+    unsigned char* dst = a_image + (wave * 32 + r) * (SPA * 16) + hs * CPL * 16;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c8 = hs * CPL + i;
+        const float4 w0 = reinterpret_cast<const float4*>(ln_w)[2 * c8], w1v = reinterpret_cast<const float4*>(ln_w)[2 * c8 + 1];
+        const float4 b0 = reinterpret_cast<const float4*>(ln_b)[2 * c8], b1v = reinterpret_cast<const float4*>(ln_b)[2 * c8 + 1];
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1v.x, w1v.y, w1v.z, w1v.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+        m16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rok ? (_Float16)((v[i][e] - mean) * rstd * wv[e] + bv[e]) : (_Float16)0.f;
+        *reinterpret_cast<m16x8*>(dst + i * 16) = o;
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Params p) {
     using T = Mlp16Cfg<C>;
@@ -87,42 +128,7 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Para
     const int mvalid = min(128, p.M - m0);
     if (p.ln_w == nullptr) fill(lds + T::OFF_A, reinterpret_cast<const char*>(p.A + (int64_t)m0 * C), C * 2, 128, mvalid, SPA);
     else {
-        // LayerNorm of the wave's own 32 rows straight into its rows of the a image: two lanes per row, C / 16 chunks of 8 halves each; two-pass statistics in
-        // f32 (as xp_layernorm_f16), the store to LDS rounds to fp16 = the half tensor LayerNorm returns under autocast
-        constexpr int CPL = C / 16;
-        const int r = lane >> 1, hs = lane & 1, grow = m0 + wave * 32 + r;
-        const bool rok = grow < p.M;
-        const m16x8* xr = reinterpret_cast<const m16x8*>(p.X + (int64_t)(rok ? grow : 0) * C) + hs * CPL;
-        float v[CPL][8];
-        float sm = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const m16x8 t = xr[i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = (float)t[e];
-            sm += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
-        }
-        sm += xp_dpp_mov<0xB1>(sm);                              // the row's other lane (quad_perm [1,0,3,2])
-        const float mean = sm / (float)C;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
-        q += xp_dpp_mov<0xB1>(q);
-        const float rstd = 1.f / sqrtf(q / (float)C + p.eps);
-        unsigned char* dst = lds + T::OFF_A + (wave * 32 + r) * (SPA * 16) + hs * CPL * 16;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c8 = hs * CPL + i;
-            const float4 w0 = reinterpret_cast<const float4*>(p.ln_w)[2 * c8], w1v = reinterpret_cast<const float4*>(p.ln_w)[2 * c8 + 1];
-            const float4 b0 = reinterpret_cast<const float4*>(p.ln_b)[2 * c8], b1v = reinterpret_cast<const float4*>(p.ln_b)[2 * c8 + 1];
-            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1v.x, w1v.y, w1v.z, w1v.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
-            m16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rok ? (_Float16)((v[i][e] - mean) * rstd * wv[e] + bv[e]) : (_Float16)0.f;
-            *reinterpret_cast<m16x8*>(dst + i * 16) = o;
-        }
+        mlp16_ln_rows<C>(p.X, p.ln_w, p.ln_b, p.eps, p.M, m0, wave, lane, lds + T::OFF_A, SPA);
     }
     auto issue_chunk = [&](int ch, int buf) {
         fill(lds + T::OFF_W1 + buf * T::pieces(T::W1_BYTES) * 1024, reinterpret_cast<const char*>(p.W1 + (int64_t)ch * HC * C), C * 2, HC, HC, SPA);
@@ -244,6 +250,93 @@ int mlp16_launch(const Mlp16Params& p, hipStream_t s) {
     return XP_OK;
 }
 
+// ---- norm + in_proj of a VSS block in one launch (VMamba.py:1225, :649):  y = LayerNorm(x) W^T  (no bias), y (M, N) half.  Same row-stationary layout: the
+//      wave's LayerNorm-ed rows as the MFMA "A" operand from the padded a image, the WHOLE weight matrix (N x C, N <= 192: <= 77 KB) by one LDS-DMA fill, the
+//      32 x N result of a wave staged through its own a rows for 16-byte stores. ----
+struct LnProj16Params { const _Float16* X; _Float16* Y; const _Float16* W; const float* ln_w; const float* ln_b; float eps; int M; };
+
+template <int C>
+__global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void ln_proj_f16_kernel(LnProj16Params p) {
+    constexpr int N = C, SPA = C / 8 + 1, JN = N / 32;
+    constexpr int A_BYTES = (128 * SPA * 16 + 1023) / 1024 * 1024;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * 128;
+    const char* zero = reinterpret_cast<const char*>(g_m16_zero_page);
+    {   // weight image: N rows of SPA slots
+        constexpr int np = (N * SPA * 16 + 1023) / 1024;
+        for (int pc = wave; pc < np; pc += 4) {
+            const int slot = pc * 64 + lane;
+            const int r = slot / SPA, c = slot - r * SPA;
+            const char* src = (r < N && c < SPA - 1) ? reinterpret_cast<const char*>(p.W) + (int64_t)r * (C * 2) + c * 16 : zero;
+            __builtin_amdgcn_global_load_lds(src, (m16_lds_ptr_t)(lds + A_BYTES + pc * 1024), 16, 0, 0);
+        }
+    }
+    mlp16_ln_rows<C>(p.X, p.ln_w, p.ln_b, p.eps, p.M, m0, wave, lane, lds, SPA);
+    m16acc acc[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* a_rows = lds + (wave * 32 + fr) * (SPA * 16) + fh * 16;
+    const unsigned char* w_rows = lds + A_BYTES + fr * (SPA * 16) + fh * 16;
+    {
+        m16x8 afr[2], bfr[2][JN];
+        auto rd = [&](int ks, int set) {
+            afr[set] = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
+#pragma unroll
+            for (int j = 0; j < JN; ++j) bfr[set][j] = *reinterpret_cast<const m16x8*>(w_rows + j * 32 * (SPA * 16) + ks * 32);
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+            if (ks + 1 < C / 16) rd(ks + 1, (ks + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < JN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1], bfr[ks & 1][j], acc[j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned char* ot = lds + wave * 32 * (SPA * 16);          // the wave's own a rows: only this wave reads them
+    constexpr int RS = SPA * 16;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            *reinterpret_cast<_Float16*>(ot + rl * RS + (j * 32 + fr) * 2) = (_Float16)acc[j][r];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int CPR = N / 8;
+#pragma unroll
+    for (int it = 0; it < (32 * CPR + 63) / 64; ++it) {
+        const int idx = it * 64 + lane;
+        if ((32 * CPR) % 64 != 0 && idx >= 32 * CPR) break;
+        const int rl = idx / CPR, cc = idx - rl * CPR;
+        const int grow = m0 + wave * 32 + rl;
+        if (grow >= p.M) continue;
+        *reinterpret_cast<m16x8*>(p.Y + (int64_t)grow * N + cc * 8) = *reinterpret_cast<const m16x8*>(ot + rl * RS + cc * 16);
+    }
+}
+
+template <int C>
+int lnproj16_launch(const LnProj16Params& p, hipStream_t s) {
+    constexpr int SPA = C / 8 + 1;
+    constexpr int LDS = (128 * SPA * 16 + 1023) / 1024 * 1024 + (C * SPA * 16 + 1023) / 1024 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_proj_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const std::string tag = "ln_proj_f16_c" + std::to_string(C);
+    XpProfScope prof(tag.c_str(), s, 2.0 * p.M * C * (double)C, 2.0 * 2.0 * p.M * C);
+    hipLaunchKernelGGL(ln_proj_f16_kernel<C>, dim3(xp_cdiv(p.M, 128)), dim3(256), LDS, s, p);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
 }  // namespace
 
 extern "C" int xp_mlp_fused_f16_supported(int C, int H4) { return (C == 96 || C == 192 || C == 32 || C == 64) && H4 == 4 * C; }
@@ -275,5 +368,20 @@ extern "C" int xp_ln_mlp_fused_f16(void* x, const float* ln_w, const float* ln_b
         case 64: return mlp16_launch<64>(p, s);
         case 96: return mlp16_launch<96>(p, s);
         default: return mlp16_launch<192>(p, s);
+    }
+}
+
+// norm + in_proj:  y = LayerNorm(x) W^T,  x (M, C) and y (M, C) fp16, W (C, C) fp16; C in {32, 64, 96, 192}.
+extern "C" int xp_ln_proj_f16(const void* x, const float* ln_w, const float* ln_b, float eps, const void* W, void* y, int M, int C, void* stream) {
+    XP_CHECK_ARG(x && ln_w && ln_b && W && y, "xp_ln_proj_f16: null pointer");
+    XP_CHECK_ARG(M > 0 && (C == 32 || C == 64 || C == 96 || C == 192), "xp_ln_proj_f16: C must be 32, 64, 96 or 192 (got %d)", C);
+    XP_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)W | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15) == 0, "xp_ln_proj_f16: buffers must be 16-byte aligned");
+    LnProj16Params p{(const _Float16*)x, (_Float16*)y, (const _Float16*)W, ln_w, ln_b, eps, M};
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 32: return lnproj16_launch<32>(p, s);
+        case 64: return lnproj16_launch<64>(p, s);
+        case 96: return lnproj16_launch<96>(p, s);
+        default: return lnproj16_launch<192>(p, s);
     }
 }

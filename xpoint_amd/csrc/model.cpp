@@ -433,8 +433,13 @@ extern "C" int xp_xpoint_forward_f16(void* ctx, const float* weights, const void
         for (int j = 0; j < c->cfg.depths[s]; ++j) {
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
-            RUN(xp_layernorm_f16(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, stream));
-            RUN(gemm(T1, b + "in_w", T2, 0, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
+            static const bool no_lnproj16 = getenv("XP_NO_LN_PROJ_F16") != nullptr && atoi(getenv("XP_NO_LN_PROJ_F16")) != 0;      // A/B: LayerNorm and in_proj as two launches
+            if (!no_lnproj16 && xp_mlp_fused_f16_supported(C, H4)) {     // stages 0 - 1: norm + in_proj in one row-stationary launch (csrc/mlp_f16.hip)
+                RUN(xp_ln_proj_f16(X, P(b + "ln1_w"), P(b + "ln1_b"), eps, WH(b + "in_w"), T2, M, C, stream));
+            } else {
+                RUN(xp_layernorm_f16(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, stream));
+                RUN(gemm(T1, b + "in_w", T2, 0, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
+            }
             RUN(xp_dwconv3x3_silu_f16(T2, P(b + "dw_w"), T3, T3f, batch, sh.H[s], sh.W[s], C, stream));
             RUN(gemm(T3, b + "xproj_w", XD, 0, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
             if (seq) RUN(gemm(T3, b + "xproj_w", XDf, 1, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));     // the same half values in f32 containers (M <= a few thousand rows)
