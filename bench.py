@@ -222,12 +222,22 @@ def dt_hint(region_dt):
     return sorted(region_dt)[(len(region_dt) - 1) // 2]
 
 
-def gpu_clock_mhz():
-    """Current shader clock of the first amdgpu device, MHz (sysfs pp_dpm_sclk: the level marked '*'; rocm-smi as a fallback), or None.
+def gpu_clock_mhz(local=0):
+    """Current shader clock of THIS rank's GPU, MHz: the visible GPU's KFD node (the nodes of GPUs that are not mapped into the container are unreadable) names
+    its DRM render minor -> /sys/class/drm/renderD<minor>/device/pp_dpm_sclk, the level marked '*'; rocm-smi as a fallback; None when neither answers.
     Read before, in the middle of and after the sustained region: the matrix pipe's peak assumes 2.4 GHz, the part throttles under dense MFMA load."""
     import glob
     import re
-    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    minors = []
+    for prop in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda q: int(q.split("/")[-2])):
+        try:
+            kv = dict(line.split()[:2] for line in open(prop) if len(line.split()) >= 2)
+        except OSError:
+            continue                                   # another tenant's GPU
+        if int(kv.get("simd_count", "0")) > 0 and "drm_render_minor" in kv:
+            minors.append(int(kv["drm_render_minor"]))
+    paths = [f"/sys/class/drm/renderD{minors[local]}/device/pp_dpm_sclk"] if local < len(minors) else []
+    for path in paths:
         try:
             for line in open(path):
                 if "*" in line:
@@ -238,10 +248,7 @@ def gpu_clock_mhz():
             pass
     try:
         import subprocess
-        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=15)
-        m = re.search(r'"sclk clock speed:?"\s*:\s*"\((\d+)Mhz\)"', r.stdout)
-        if m:
-            return int(m.group(1))
+        r = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks"], capture_output=True, text=True, timeout=15)
         m = re.search(r"sclk[^\n]*?\((\d+)Mhz\)", r.stdout + r.stderr)
         return int(m.group(1)) if m else None
     except Exception:
@@ -497,8 +504,8 @@ def main():
             # (b) sustained: one region of >= 10 s with the shader clock read before, in the middle and after (DVFS under sustained MFMA load)
             import threading
             n_sus = max(args.steps, int(10.5 / (dt_hint(region_dt) / args.steps)))
-            clocks = {"before_mhz": gpu_clock_mhz()}
-            timer = threading.Timer(5.0, lambda: clocks.__setitem__("mid_region_mhz", gpu_clock_mhz()))
+            clocks = {"before_mhz": gpu_clock_mhz(local)}
+            timer = threading.Timer(5.0, lambda: clocks.__setitem__("mid_region_mhz", gpu_clock_mhz(local)))
             sync_all()
             timer.start()
             t5 = time.perf_counter()
@@ -506,7 +513,7 @@ def main():
                 pipe.run(opt, thr, mo, mt)
             sync_all()
             t_sus = time.perf_counter() - t5
-            clocks["after_mhz"] = gpu_clock_mhz()
+            clocks["after_mhz"] = gpu_clock_mhz(local)
             timer.cancel()
             pipe.verify()
             hygiene["sustained_pairs_per_s"] = round(B * n_sus / t_sus, 2)
@@ -523,6 +530,10 @@ def main():
     if not args.no_h2d and args.config == "c2":
         ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
         with torch.no_grad():
+            for _ in range(3):                                                 # untimed: the first download_async() calls allocate their pinned host buffers (two sets) —
+                pipe.run(ho, ht, mo, mt)                                       # with the rank's CPU mask narrowed that allocation took ~0.3 s and sat inside this region
+                bufs, ev = pipe.download_async()                               # (PCIe-inclusive 1 455 -> 780 pairs/s for a 0.5 s region; the copies themselves run at
+                ev.synchronize()                                               # 52 GB/s either way: tools/h2d_affinity_probe.py, tools/pcie_affinity_probe.py)
             sync_all()
             t1 = time.perf_counter()
             prev = None

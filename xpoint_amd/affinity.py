@@ -139,6 +139,9 @@ def pin_rank(local_rank: int, local_world: int, sysfs_root: str = "/sys", apply:
     dev = visible_device_indices(len(gpus)) if gpus else None
     sets = plan(local_world, allowed, gpus, dev)
     mine = sets[local_rank] if 0 <= local_rank < len(sets) else sorted(allowed)
+    override = os.environ.get("XP_RANK_CPUS")            # experiments: "0-63,128-191" pins every rank to that list (intersected with the allowed set)
+    if override:
+        mine = [c for c in parse_cpulist(override) if c in allowed] or mine
     known = bool(gpus) and dev is not None and local_rank < len(dev) and dev[local_rank] < len(gpus) and bool(gpus[dev[local_rank]])
     info = {"cpus": format_cpulist(mine), "count": len(mine), "source": "kfd + pci local_cpulist" if known else "even split of the allowed set",
             "applied": False, "previous": format_cpulist(sorted(allowed))}
