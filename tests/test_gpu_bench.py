@@ -45,6 +45,33 @@ def test_bench_launcher_rccl_world():
     assert 0 < pr["min"] <= pr["max"] and pr["max"] * world >= out["value"] * 0.99
     assert out["weight_bcast_first_ms"] > 0
     assert out["roofline"].get("traffic") or out["roofline"].get("traffic_error")        # a PMC lookup failure is reported, never swallowed
+    # round 4: matcher nomination statistics, per-rank CPU masks, precision class label
+    assert out["match_candidates_per_row"]["mean"] >= 1.0 and out["match_candidates_per_row"]["max"] >= 1 and out["match_overflow_rows"] >= 0
+    aff = out["rank_cpu_affinity"]
+    assert len(aff["cpus_per_rank"]) == world and aff["rank0"]["count"] >= 1 and aff["rank0"]["applied"] in (True, False)
+    assert out["precision_class"] == "f32" and "NOT the headline" not in out["metric"]
+
+
+def test_bench_hygiene_keys_and_fast_class_label():
+    """The default line carries the rotating-input and sustained-region rates (with the shader clock) and the reduced-precision classes incl. amp16f; a
+    `--precision-class amp16f` run labels itself as not the headline."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["rotating_inputs_pairs_per_s"] > 0.8 * out["value"]
+    assert out["sustained_pairs_per_s"] > 0.8 * out["value"] and out["sustained_region"]["seconds"] >= 10.0
+    clk = out["sustained_region"]["shader_clock"]
+    assert clk["mid_region_mhz"] is None or 500 <= clk["mid_region_mhz"] <= 3000, clk
+    cls = out["reduced_precision_classes"]["pairs_per_s"]
+    assert cls["amp16f"] > out["value"] and cls["amp16f"] > cls["amp16"], cls          # the half-storage class is the FAST one
+    assert out["pcie_inclusive_pairs_per_s"] > 0.6 * out["value"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-h2d", "--precision-class", "amp16f"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["precision_class"] == "amp16f" and "NOT the headline" in out["metric"] and out["dtype"].startswith("f16 storage")
+    assert "_f16" in out["roofline"]["kernel"] and out["roofline"]["peak"] == 2500.0
 
 
 def test_bench_launcher_refuses_more_gpus_than_visible():
