@@ -599,6 +599,19 @@ def main():
         except Exception as e:
             if roof["bound"] == "mfma":
                 roof["frac_mfma_busy_pmc_error"] = f"{type(e).__name__}: {e}"
+        # which resource the dominant GEMM actually saturates: L2-side read counters of its largest shape, committed by tools/gemm_l2.sh
+        try:
+            l2 = json.load(open(os.path.join(ROOT, "profiles", "pmc_gemm_l2.json")))["kernels"]
+            fam = "gemm_f16" if "_f16" in dominant else ("gemm_h2" if "_h2" in dominant else None)
+            if fam in l2 and dominant.startswith("gemm"):
+                e = l2[fam]
+                roof["saturated_resource"] = {"resource": "L2 -> LDS read bandwidth", "l2_read_tb_s": round(e["l2_read_tb_s"], 2), "l2_hit_rate": round(e["l2_hit_rate"], 3),
+                                              "ceiling_tb_s": round(e["l2_ceiling_tb_s"], 1), "frac": round(e["frac_of_l2_ceiling"], 3), "shape_MNK": e["shape"],
+                                              "source": "profiles/pmc_gemm_l2.json (rocprofv3 --pmc TCC_READ_sum / TCC_HIT_sum / TCC_MISS_sum on tools/gemm_bench.py; ceiling = the "
+                                                        "hit-rate-weighted blend of MI355X_MICROARCH.md's L2 (16.8-18.8 TB/s) and Infinity-Cache (8.6 TB/s) read rates): a 128 x 128 tile "
+                                                        "moves 32 KB from L2 per slab, so the matrix-pipe fraction above is what this bandwidth allows, not a scheduling slack"}
+        except Exception:
+            pass
         roof.update({"avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom["launches"]})
         if overlap or args.graph:
             roof["measured_in"] = ("3 single-stream eager passes of the same step next to the timed region: " +
