@@ -59,7 +59,7 @@ struct F16Tile {
 
 // MODE 0: plain A (M, lda).  MODE 1: implicit 3x3 convolution.
 template <int WM, int WN, int TM, int TN, int MODE, int BK>
-__global__ __launch_bounds__(WM * WN * 64, BK == 64 ? 2 : 4) void gemm_f16_kernel(F16Params p) {
+__global__ __launch_bounds__(WM * WN * 64, (BK == 64 ? 2 : 4) / (WM * WN > 4 ? 2 : 1)) void gemm_f16_kernel(F16Params p) {
     using T = F16Tile<WM, WN, TM, TN, BK>;
     constexpr int F16_BK = BK, F16_ROWB = T::ROWB;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -286,7 +286,16 @@ void f16_launch(const F16Params& p, hipStream_t s) {
 int f16_dispatch(const F16Params& p, hipStream_t s) {
     static const int force = getenv("XP_F16_TILE") ? atoi(getenv("XP_F16_TILE")) : -1;      // tuning experiments only
     const int N = p.N;
-    const int sel = force >= 0 ? force : N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2 : 3;
+    // Tile by LAYER (N, K) only — every tile walks K in the same slab order, so the choice never changes a result bit, and it never depends on the batch.
+    // Measured on the deep-stage layers (tools/gemm_bench.py, GB_F16=1, XP_F16_TILE=3/4/5): 128 x 192 wins where it covers N in fewer column tiles at short K
+    // (N 192, K 768: 54.1 -> 49.8 us; N 1536, K 384 + GELU: 64.3 -> 57.4), 256 x 128 where K is long and N narrow (N 384, K 1536: 40.5 -> 35.7: the L2-read-bound
+    // case of profiles/r4_03_gemm_l2_counters.txt, A re-read halves); 128 x 128 everywhere else (M 4 800 rows: larger tiles leave CUs idle).
+    int sel = N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2 : 3;
+    if (!p.Ci && p.K > 192) {
+        if ((N == 192 && p.K >= 512) || (N == 1536 && p.K <= 512)) sel = 4;
+        else if (N == 384 && p.K >= 1024) sel = 5;
+    }
+    if (force >= 0) sel = force;
     // slab depth: a property of the layer (K), never of the batch.  K <= 192 (plain GEMMs of stages 0 / 1, whose tiles live on DMA latency + epilogue): 32
     static const int force_bk = getenv("XP_F16_BK") ? atoi(getenv("XP_F16_BK")) : 0;
     const bool k32 = force_bk ? force_bk == 32 : (p.K <= 192 && !p.Ci);
@@ -302,6 +311,8 @@ int f16_dispatch(const F16Params& p, hipStream_t s) {
             case 0: f16_launch<4, 1, 1, 1, 64>(p, s); break;       // 128 x 32
             case 1: f16_launch<4, 1, 1, 2, 64>(p, s); break;       // 128 x 64
             case 2: f16_launch<4, 1, 1, 3, 64>(p, s); break;       // 128 x 96
+            case 4: f16_launch<2, 2, 2, 3, 64>(p, s); break;       // 128 x 192 (experiment, XP_F16_TILE=4): A re-read N / 192 times instead of N / 128
+            case 5: f16_launch<4, 2, 2, 2, 64>(p, s); break;       // 256 x 128, 8 waves (experiment, XP_F16_TILE=5)
             default: f16_launch<2, 2, 2, 2, 64>(p, s); break;      // 128 x 128
         }
     }
