@@ -14,10 +14,12 @@
 //                     residual loads and stores, as csrc/gemm_f16.hip does.
 // Operands arrive by LDS-DMA (global_load_lds_dwordx4) into PADDED row images — row stride = row bytes + 16, an odd number of 16-byte slots, so every
 // ds_read_b128 of 16 consecutive rows covers all banks; the DMA writes lane-linear, so the lanes that land on a pad slot fetch from a zero page.  The a image
-// (128 x C) is loaded once; W1 / W2 chunk images are double-buffered, the DMA of chunk c + 1 in flight behind the 24 MFMAs and the GELUs of chunk c, one
-// barrier per chunk.  32-wide hidden chunks: C <= 96 takes 67 KB of LDS and <= 128 registers — two workgroups per CU, so one wave's GELUs run under the
-// other's MFMAs (VALU and MFMA of ONE wave do not overlap, coexec_probe); C = 192 (118 KB, 96 accumulator registers) stays at one.  Bound by the GELU's
-// vector work (118 M evaluations per stage-0 block), not by HBM.
+// (128 x C) exists only in the prologue: every wave lifts its rows' operand fragments into registers (C / 16 x 4 VGPRs, resident for all chunks) and the image's
+// bytes then serve as the double-buffered W1 / W2 chunk images (the DMA of chunk c + 1 in flight behind the MFMAs and the GELUs of chunk c, one barrier per
+// chunk) and, at the end, as the output staging tiles.  32-wide hidden chunks.  LDS 42.5 KB / 124 registers at C = 96 (three workgroups per CU), 70.7 KB / 196
+// registers at C = 192 (two): one wave's GELUs run under another's MFMAs (VALU and MFMA of ONE wave do not overlap, coexec_probe).  With the a image resident
+// in LDS (first version: 67 / 118 KB, two / one workgroups per CU) the launches took 166 / 196 us at 16 images of 480 x 640; now 143 / 141 us.  Bound by the
+// GELU's vector work (118 M evaluations per stage-0 block; identity instead of GELU: 111 us at C = 96, tools/mlp16_dbg.sh), not by HBM.
 #include <string>
 
 #include "xp_common.h"
@@ -26,6 +28,10 @@
 typedef _Float16 m16x8 __attribute__((ext_vector_type(8)));
 typedef float m16acc __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* m16_lds_ptr_t;
+
+#ifndef XP_MLP16_DBG
+#define XP_MLP16_DBG 0   /* timing experiments only (wrong results): 1 GELU replaced by the identity */
+#endif
 
 namespace {
 
@@ -55,13 +61,17 @@ struct Mlp16Cfg {
     static constexpr int H_BYTES = 4 * 32 * SPH * 16;
     static constexpr int B1_BYTES = H4 * 4;
     static constexpr int pieces(int bytes) { return (bytes + 1023) / 1024; }
-    // image offsets; DMA pieces are whole KB, so every image is padded up to one
+    // image offsets; DMA pieces are whole KB, so every image is padded up to one.  The a image lives only in the PROLOGUE (each wave lifts its rows' MFMA
+    // fragments into registers: C / 16 x 4 VGPRs) and the 4 x 32 x C output staging only in the EPILOGUE: both alias the W1 / W2 chunk buffers of the main loop.
+    static constexpr int W_REGION = 2 * pieces(W1_BYTES) * 1024 + 2 * pieces(W2_BYTES) * 1024;
+    static constexpr int Z_BYTES = pieces(A_BYTES) * 1024 > W_REGION ? pieces(A_BYTES) * 1024 : W_REGION;
     static constexpr int OFF_A = 0;
-    static constexpr int OFF_W1 = pieces(A_BYTES) * 1024;
-    static constexpr int OFF_W2 = OFF_W1 + 2 * pieces(W1_BYTES) * 1024;
-    static constexpr int OFF_H = OFF_W2 + 2 * pieces(W2_BYTES) * 1024;
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_W2 = 2 * pieces(W1_BYTES) * 1024;
+    static constexpr int OFF_H = Z_BYTES;
     static constexpr int OFF_B1 = OFF_H + H_BYTES;
     static constexpr int LDS_BYTES = OFF_B1 + B1_BYTES;
+    static_assert(4 * 32 * SPA * 16 <= Z_BYTES, "output staging must fit the aliased region");
 };
 
 // LayerNorm of a wave's own 32 rows (rows m0 + 32 wave ..) of x straight into its rows of a padded a image: two lanes per row, C / 16 chunks of 8 halves each;
@@ -106,7 +116,7 @@ __device__ __forceinline__ void mlp16_ln_rows(const _Float16* __restrict__ X, co
 }
 
 template <int C>
-__global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Params p) {
+__global__ __launch_bounds__(256, C <= 96 ? 3 : 2) void mlp_f16_kernel(Mlp16Params p) {
     using T = Mlp16Cfg<C>;
     constexpr int HC = T::HC, SPA = T::SPA, SPH = T::SPH, JN = C / 32, JH = HC / 32;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -134,7 +144,6 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Para
         fill(lds + T::OFF_W1 + buf * T::pieces(T::W1_BYTES) * 1024, reinterpret_cast<const char*>(p.W1 + (int64_t)ch * HC * C), C * 2, HC, HC, SPA);
         fill(lds + T::OFF_W2 + buf * T::pieces(T::W2_BYTES) * 1024, reinterpret_cast<const char*>(p.W2 + (int64_t)ch * HC), T::H4 * 2, C, C, SPH);
     };
-    issue_chunk(0, 0);
     for (int i = threadIdx.x; i < T::H4; i += 256) reinterpret_cast<float*>(lds + T::OFF_B1)[i] = p.b1[i];
 
     m16acc acc2[JN];
@@ -143,10 +152,20 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Para
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
 
-    const unsigned char* a_rows = lds + T::OFF_A + (wave * 32 + fr) * (SPA * 16) + fh * 16;        // this lane's a row, k offset 8 fh
-    unsigned char* h_tile = lds + T::OFF_H + wave * (32 * SPH * 16);
+    // the wave's a rows as MFMA operand fragments, resident for the whole kernel: lane = row fr, k = 16 ks + 8 fh ..+8
+    m16x8 afrag[C / 16];
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // the a image is complete (DMA pieces come from every wave)
+        const unsigned char* a_rows = lds + T::OFF_A + (wave * 32 + fr) * (SPA * 16) + fh * 16;
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) afrag[ks] = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                        // everybody has its fragments: the image's bytes become the W chunk buffers
+    }
+    issue_chunk(0, 0);
+    unsigned char* h_tile = lds + T::OFF_H + wave * 32 * (SPH * 16);
     const float* b1s = reinterpret_cast<const float*>(lds + T::OFF_B1);
-
     for (int ch = 0; ch < T::NCH; ++ch) {
         const int buf = ch & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk ch (and, the first time, of the a image) have landed
@@ -160,19 +179,18 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Para
         for (int jh = 0; jh < JH; ++jh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hT[jh][r] = 0.f;
-        {   // fragments of k-step ks + 1 are read before the MFMAs of ks (two register sets)
-            m16x8 bfr[2], afr[2][JH];
+        {   // W1 fragments of k-step ks + 1 are read before the MFMAs of ks (two register sets); the a fragments are registers
+            m16x8 wfr[2][JH];
             auto rd = [&](int ks, int set) {
-                bfr[set] = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
 #pragma unroll
-                for (int jh = 0; jh < JH; ++jh) afr[set][jh] = *reinterpret_cast<const m16x8*>(w1 + jh * 32 * (SPA * 16) + ks * 32);
+                for (int jh = 0; jh < JH; ++jh) wfr[set][jh] = *reinterpret_cast<const m16x8*>(w1 + jh * 32 * (SPA * 16) + ks * 32);
             };
             rd(0, 0);
 #pragma unroll
             for (int ks = 0; ks < C / 16; ++ks) {
                 if (ks + 1 < C / 16) rd(ks + 1, (ks + 1) & 1);
 #pragma unroll
-                for (int jh = 0; jh < JH; ++jh) hT[jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1][jh], bfr[ks & 1], hT[jh], 0, 0, 0);
+                for (int jh = 0; jh < JH; ++jh) hT[jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfr[ks & 1][jh], afrag[ks], hT[jh], 0, 0, 0);
             }
         }
         // ---- epilogue 1: register r of tile jh = hidden unit 32 jh + (r & 3) + 8 (r >> 2) + 4 fh of row m = fr ----
@@ -185,26 +203,31 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void mlp_f16_kernel(Mlp16Para
                 const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
                 union { _Float16 h[4]; uint2 u; } pk;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pk.h[q] = (_Float16)xp_gelu_fast(m16_r(hT[jh][4 * g4 + q] + bv[q]));
+                for (int q = 0; q < 4; ++q) pk.h[q] = (XP_MLP16_DBG & 1) ? (_Float16)(hT[jh][4 * g4 + q] + bv[q]) : (_Float16)xp_gelu_fast(m16_r(hT[jh][4 * g4 + q] + bv[q]));
                 *reinterpret_cast<uint2*>(h_tile + fr * (SPH * 16) + hid0 * 2) = pk.u;
             }
         // ---- fc2: acc2[jn] += H . W2chunk^T ----
-        {   // all fragments of the chunk up front (HC / 16 = 2 k-steps: 2 + 2 JN reads), then the MFMAs
-            m16x8 afr[HC / 16], bfr[HC / 16][JN];
+        {   // H fragments of both k-steps up front; W2 fragments of output tile jn + 1 are read before the MFMAs of tile jn (two register sets — with the
+            // a fragments resident, all 2 JN of them up front would not fit two workgroups' registers at C = 192)
+            m16x8 hfr[HC / 16], wfr[2][HC / 16];
 #pragma unroll
-            for (int ks = 0; ks < HC / 16; ++ks) {
-                afr[ks] = *reinterpret_cast<const m16x8*>(h_tile + fr * (SPH * 16) + fh * 16 + ks * 32);
+            for (int ks = 0; ks < HC / 16; ++ks) hfr[ks] = *reinterpret_cast<const m16x8*>(h_tile + fr * (SPH * 16) + fh * 16 + ks * 32);
+            auto rd = [&](int jn, int set) {
 #pragma unroll
-                for (int jn = 0; jn < JN; ++jn) bfr[ks][jn] = *reinterpret_cast<const m16x8*>(w2 + jn * 32 * (SPH * 16) + ks * 32);
+                for (int ks = 0; ks < HC / 16; ++ks) wfr[set][ks] = *reinterpret_cast<const m16x8*>(w2 + jn * 32 * (SPH * 16) + ks * 32);
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int jn = 0; jn < JN; ++jn) {
+                if (jn + 1 < JN) rd(jn + 1, (jn + 1) & 1);
+#pragma unroll
+                for (int ks = 0; ks < HC / 16; ++ks) acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hfr[ks], wfr[jn & 1][ks], acc2[jn], 0, 0, 0);
             }
-#pragma unroll
-            for (int ks = 0; ks < HC / 16; ++ks)
-#pragma unroll
-                for (int jn = 0; jn < JN; ++jn) acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks], bfr[ks][jn], acc2[jn], 0, 0, 0);
         }
     }
-    // ---- epilogue 2: the wave's 32 x C tile -> its own rows of the a image (free now) as halves, then row-contiguous + residual -> x ----
+    // ---- epilogue 2: the wave's 32 x C tile -> its own 32 staging rows (the W buffers' bytes, free now) as halves, then row-contiguous + residual -> x ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                                      // every wave is done with the last chunk's W2 image: its bytes become the staging tiles
     unsigned char* ot = lds + T::OFF_A + wave * 32 * (SPA * 16);          // 32 rows x (SPA * 16) bytes: row stride SPA * 16 >= C * 2
     constexpr int RS = SPA * 16;
 #pragma unroll
