@@ -106,7 +106,11 @@ def pmc_kernel_for_tag(tag, names):
     """HIP-event tag of the library (csrc/*: XpProfScope) -> kernel name as rocprofv3 prints it (tools/pmc_summary.py `short`).  Raises KeyError
     with the candidates when nothing (or more than one kernel) matches, so a renamed template shows up in the bench line instead of a null."""
     import re
-    if "mlp_fused" in tag or tag.startswith("ln_proj"):
+    m16 = re.match(r"(ln_mlp_fused|mlp_fused|ln_proj)_f16_c(\d+)$", tag)
+    if m16:
+        # fast mixed-precision class (csrc/mlp_f16.hip): (ln_)mlp_fused_f16_c<C> <-> mlp_f16_kernel<C>, ln_proj_f16_c<C> <-> ln_proj_f16_kernel<C>
+        pat = re.compile(rf"{'ln_proj_f16_kernel' if m16.group(1) == 'ln_proj' else 'mlp_f16_kernel'}<{m16.group(2)}>$")
+    elif "mlp_fused" in tag or tag.startswith("ln_proj"):
         # (proj_)mlp_fused_{h2|x3}_c<C>, ln_proj_{h2|x3}_c<C>  <->  mlp_fused_kernel<C, NW, MODE, NP, H2>; MODE 0 = MLP, 1 = out_proj + MLP, 2 = LN + projection
         m = re.match(r"(proj_mlp_fused|mlp_fused|ln_proj)_(h2|x3)_c(\d+)$", tag)
         if not m:
@@ -117,17 +121,19 @@ def pmc_kernel_for_tag(tag, names):
         # ping-pong / wave-specialised schedules of the split-fp16 GEMM: one (non-template) kernel each
         pat = re.compile(rf"{tag.split('_mfma_')[0]}_kernel$")
     elif tag.startswith(("gemm", "conv3x3")):
-        m = re.match(r"(gemm|conv3x3)(_h2r|_h2|_x3|_f16|)_mfma_(\d+)x(\d+)$", tag)
-        if not m:
+        m = re.match(r"(gemm|conv3x3)(_h2r|_h2|_x3|_f16|)_mfma_(\d+)x(\d+)(_k32)?$", tag)
+        if not m or (m.group(5) and m.group(2) != "_f16"):
             raise KeyError(f"unrecognised GEMM tag {tag!r}")
-        cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2", ("128", "32"): "4, 1, 1, 1"}
+        cfgs = {("128", "128"): "2, 2, 2, 2", ("128", "96"): "4, 1, 1, 3", ("64", "128"): "2, 2, 1, 2", ("128", "64"): "4, 1, 1, 2", ("128", "32"): "4, 1, 1, 1",
+                ("128", "192"): "2, 2, 2, 3", ("256", "128"): "4, 2, 2, 2"}
         conv = 1 if m.group(1) == "conv3x3" else 0
         eng = m.group(2)
         if eng == "_h2r":         # row-stationary split-fp16 kernel: gemm_h2r_kernel<TN, MODE>
             pat = re.compile(rf"gemm_h2r_kernel<{int(m.group(4)) // 32}, {conv}>$")
         else:
             base = {"_h2": "gemm_h2_kernel", "_x3": "gemm_x3_kernel", "": "gemm_kernel", "_f16": "gemm_f16_kernel"}[eng]
-            pat = re.compile(rf"{base}<{cfgs[(m.group(3), m.group(4))]}, {conv}(, \d+)?>$")
+            bk = (", 32" if m.group(5) else ", 64") if eng == "_f16" else r"(, \d+)?"        # gemm_f16_kernel<WM, WN, TM, TN, MODE, BK>
+            pat = re.compile(rf"{base}<{cfgs[(m.group(3), m.group(4))]}, {conv}{bk}>$")
     else:
         pat = re.compile(re.escape(tag) + r"(_kernel)?(<.*>)?$")
     hits = [n for n in names if pat.search(n)]
@@ -426,7 +432,8 @@ def main():
         pipe.verify()
         if args.config == "c5":
             sstep.verify()                  # the head's own status word (its forward runs from its own graph): read once, after the timed region
-        if args.config != "c2" or world > 1 or args.precision_class != "f32":
+        want_hygiene = args.config == "c2" and world == 1 and not args.no_other_backend and not args.graph      # (before the override below: a precision-class
+        if args.config != "c2" or world > 1 or args.precision_class != "f32":                                     #  run keeps the rotating-input / sustained regions)
             args.no_other_backend = True        # the extra passes (other back ends, precision classes, PCIe-inclusive) are single-GPU records: an N-rank run stays short
         if world > 1:
             args.no_h2d = True
@@ -483,7 +490,7 @@ def main():
             pipe.run(opt, thr, mo, mt)          # leave the buffers holding the headline back end's results
             torch.cuda.synchronize()
     hygiene = {}
-    if args.config == "c2" and world == 1 and not args.no_other_backend and not args.graph:
+    if want_hygiene:
         with torch.no_grad():
             # (a) rotating inputs: the 64 pairs of BASELINE config C3 resident in HBM, a different batch of 8 every step (the headline region replays one batch;
             #     other pairs carry other keypoint counts and NMS chains)
@@ -580,22 +587,23 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 3)}
+        pmc_suffix = "" if args.precision_class == "f32" else "_" + args.precision_class      # the precision-class runs have their own counter files
         # HBM traffic and MFMA-busy fraction of that kernel from the committed rocprofv3 PMC runs (counters cannot be collected from inside this
         # process).  A tag that matches no kernel of the PMC files is reported in the line (traffic_error), never swallowed.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic{pmc_suffix}.json")))["kernels"]
             kname = pmc_kernel_for_tag(dominant, list(pmc))
             roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
             roof["traffic_kernel"] = kname
-            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
+            roof["traffic_source"] = f"profiles/pmc_traffic{pmc_suffix}.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
         except Exception as e:
             roof["traffic_error"] = f"{type(e).__name__}: {e}"
             sys.stderr.write(f"bench.py: roofline.traffic unavailable for {dominant}: {e}\n")
         try:
-            mf = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))["kernels"]
+            mf = json.load(open(os.path.join(ROOT, "profiles", f"pmc_mfma{pmc_suffix}.json")))["kernels"]
             kname = pmc_kernel_for_tag(dominant, list(mf))
             roof["frac_mfma_busy_pmc"] = round(mf[kname]["mfma_busy_frac"], 4)
-            roof["frac_mfma_busy_pmc_source"] = "profiles/pmc_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), tools/mfma_util.sh)"
+            roof["frac_mfma_busy_pmc_source"] = f"profiles/pmc_mfma{pmc_suffix}.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), tools/mfma_util.sh)"
         except Exception as e:
             if roof["bound"] == "mfma":
                 roof["frac_mfma_busy_pmc_error"] = f"{type(e).__name__}: {e}"

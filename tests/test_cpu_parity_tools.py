@@ -222,6 +222,15 @@ def test_bench_pmc_lookup_covers_the_committed_counter_files():
         for tag in ("gemm_h2p_mfma_128x128", "gemm_h2_mfma_128x128", "gemm_h2_mfma_64x128", "proj_mlp_fused_h2_c192", "proj_mlp_fused_h2_c96",
                     "conv3x3_h2r_mfma_128x96", "conv3x3_h2r_mfma_128x128"):
             assert bench.pmc_kernel_for_tag(tag, names) in names, (fn, tag)
+    # the fast mixed-precision class has its own counter files (bench.py --precision-class amp16f reads pmc_*_amp16f.json)
+    for fn in ("pmc_mfma_amp16f.json", "pmc_traffic_amp16f.json"):
+        path = os.path.join(root, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        names = list(json.load(open(path))["kernels"])
+        for tag in ("gemm_f16_mfma_128x128", "gemm_f16_mfma_128x96_k32", "gemm_f16_mfma_128x192", "gemm_f16_mfma_256x128", "conv3x3_f16_mfma_128x128",
+                    "conv3x3_f16_mfma_128x96", "ln_mlp_fused_f16_c96", "ln_mlp_fused_f16_c192", "ln_proj_f16_c96", "ln_proj_f16_c192"):
+            assert bench.pmc_kernel_for_tag(tag, names) in names, (fn, tag)
     names = list(json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["kernels"])
     for tag in ("ss2d_pass2", "dwconv3x3_silu", "layernorm"):          # HBM-bound tags: traffic file only
         try:

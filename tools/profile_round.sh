@@ -28,6 +28,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats16 -- python3 
 cp $(find $OUT/stats16 -name "*kernel_stats.csv" | head -1) $OUT/amp16f_kernel_stats.csv; rm -rf $OUT/stats16
 XP_MFMA_UTIL_ARGS="--precision-class amp16f" XP_MFMA_UTIL_TAG=amp16f bash $R/tools/mfma_util.sh > /dev/null 2>&1
 cp $R/gpurun_out/mfma_utilisation_amp16f.txt $OUT/amp16f_mfma_utilisation.txt; cp $R/gpurun_out/pmc_mfma_amp16f.json $OUT/amp16f_pmc_mfma.json
+cp $R/gpurun_out/pmc_mfma_amp16f.json $R/profiles/pmc_mfma_amp16f.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch16 -- python3 $R/bench.py --precision-class amp16f --steps 2 --warmup 1 $COMMON > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write16 -- python3 $R/bench.py --precision-class amp16f --steps 2 --warmup 1 $COMMON > /dev/null 2>&1
+python3 $R/tools/pmc_summary.py $(find $OUT/fetch16 -name "*counter_collection.csv" | head -1) $(find $OUT/write16 -name "*counter_collection.csv" | head -1) $OUT/amp16f_pmc_traffic.json > $OUT/amp16f_pmc_hbm_traffic.txt
+rm -rf $OUT/fetch16 $OUT/write16
+cp $OUT/amp16f_pmc_traffic.json $R/profiles/pmc_traffic_amp16f.json
+# the class's line again with its own counter files in place (roofline.traffic, frac_mfma_busy_pmc)
+python3 $R/bench.py --precision-class amp16f --no-cpu-baseline --no-h2d > $OUT/amp16f_bench.json 2> $OUT/amp16f_hip_event_breakdown.txt
 GB_F16=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_f16_microbench.txt 2>&1
 GB_H2=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_h2_microbench.txt 2>&1
 GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1
