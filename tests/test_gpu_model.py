@@ -674,6 +674,22 @@ def test_fp16_range_overflow_falls_back_to_x3(gpu_lib):
             got = pipe.fetch()
         assert net.effective_gemm_mode() == "x3"
         assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"]) and got[0]["match_q"].tolist() == ref[0]["match_q"].tolist()
+        # every pipeline owns its status word: a trip raised by a step in flight on pipeline A is not consumed by pipeline B's verify() on the
+        # same model, nor by reading / clearing the model's shared word (what an eager forward's check does); A still finds and repairs it
+        net = _net(cfg, sd)
+        pipe_a = PairPipeline(net, B, H, W, cap=4096)
+        pipe_b = PairPipeline(net, B, H, W, cap=4096)
+        assert pipe_a.status_word().data_ptr() != pipe_b.status_word().data_ptr() != net.status_word("cuda").data_ptr()
+        pipe_a.run(*args)                                       # trips (h2), nobody has looked yet
+        torch.cuda.synchronize()
+        assert int(pipe_a.status_word().item()) != 0 and int(pipe_b.status_word().item()) == 0 and int(net.status_word("cuda").item()) == 0
+        assert pipe_b._settle_engine() is False                 # B's own check (the first thing its verify() does): nothing to settle, and A's bits stay where they are
+        net.status_word("cuda").zero_()
+        assert int(pipe_a.status_word().item()) != 0 and net.effective_gemm_mode() == "h2"
+        with pytest.warns(RuntimeWarning, match="re-running on gemm_mode 'x3'"):
+            got = pipe_a.fetch()
+        assert net.effective_gemm_mode() == "x3" and int(pipe_a.status_word().item()) == 0
+        assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"]) and got[0]["match_q"].tolist() == ref[0]["match_q"].tolist()
         # genuinely non-finite weights: no engine can help -> raise, on every engine
         sd_nan = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
         sd_nan["encoder.layers.1.blocks.0.mlp.fc1.bias"][3] = float("nan")

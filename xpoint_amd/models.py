@@ -367,30 +367,33 @@ class XPoint(torch.nn.Module):
                            "non-finite activations")
 
     def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
-                    is_optical=None, check=True):
+                    is_optical=None, check=True, status=None):
         """See _forward_raw.  Runs with the images' device as the current device, so every launch below goes to THAT
         device's current stream (the model may live on cuda:N while another device is current).
         check=True (default; ignored during stream capture): read the forward's status word (one 4-byte download = a host
         synchronisation) and, if the split-fp16 engine's range guard tripped, run the forward again on "x3" — the call never returns
-        overflowed results.  Stream-ordered callers (PairPipeline) pass check=False and test the word at their own synchronisation point."""
+        overflowed results.  Stream-ordered callers (PairPipeline) pass check=False and test the word at their own synchronisation point.
+        status: an int32[1] device tensor OWNED BY THE CALLER that this forward ORs its XP_STATUS_* bits into instead of the model's shared word
+        (status_word): a pipeline with forwards in flight must not have its bits read and cleared by somebody else's check (another pipeline on the same
+        model, an eager call); with check=True the given word is the one read and cleared."""
         if not images.is_cuda:
             raise RuntimeError("xpoint_amd.XPoint runs on the GPU only (no CPU fallback): move the data to 'cuda'")
         with torch.cuda.device(images.device):
-            res = self._forward_raw(images, want_prob, want_desc, want_logits, out, workspace, is_optical)
+            res = self._forward_raw(images, want_prob, want_desc, want_logits, out, workspace, is_optical, status)
             if check and not torch.cuda.is_current_stream_capturing():
-                word = self.status_word(images.device)
+                word = self.status_word(images.device) if status is None else status
                 st = int(word.item())
                 if st:
                     word.zero_()
                     if self.handle_status(st, "forward"):
-                        res = self._forward_raw(images, want_prob, want_desc, want_logits, res if out is None else out, workspace, is_optical)
+                        res = self._forward_raw(images, want_prob, want_desc, want_logits, res if out is None else out, workspace, is_optical, status)
                         st = int(word.item())
                         word.zero_()
                         self.handle_status(st, "forward, second run")       # raises when "x3" is non-finite as well
             return res
 
     def _forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,
-                     is_optical=None):
+                     is_optical=None, status=None):
         """images (N,1,H,W) float32 on the GPU -> dict of NHWC device tensors (no layout exports):
         prob (N,H,W), desc_nhwc (N,Hc,Wc,D), enc_nhwc (N,Hc,Wc,E/2), logits_nhwc (N,Hc,Wc,65).
         out: a dict returned by an earlier call with the same shapes -> its tensors are overwritten instead of
@@ -428,8 +431,8 @@ class XPoint(torch.nn.Module):
                 thermal = True
             else:       # mixed batch: run each spectrum's images through its encoder and scatter the results back
                 idx_o = torch.nonzero(flags).reshape(-1).to(dev); idx_t = torch.nonzero(~flags).reshape(-1).to(dev)
-                ro = self._forward_raw(images[idx_o], want_prob, want_desc, want_logits, None, workspace, [True] * int(idx_o.numel()))
-                rt = self._forward_raw(images[idx_t], want_prob, want_desc, want_logits, None, workspace, [False] * int(idx_t.numel()))
+                ro = self._forward_raw(images[idx_o], want_prob, want_desc, want_logits, None, workspace, [True] * int(idx_o.numel()), status)
+                rt = self._forward_raw(images[idx_t], want_prob, want_desc, want_logits, None, workspace, [False] * int(idx_t.numel()), status)
                 res = {}
                 for k, v in ro.items():
                     if v is None:
@@ -504,7 +507,7 @@ class XPoint(torch.nn.Module):
         if fast16:      # its own entry point: no process-wide switches involved
             _lib.check(lib.xp_xpoint_forward_f16(self._ctx, ptr(blob), ptr(w16), ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                                  ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
-                                                 ptr(self.status_word(dev)), _lib.current_stream()), "xp_xpoint_forward_f16")
+                                                 ptr(self.status_word(dev) if status is None else status), _lib.current_stream()), "xp_xpoint_forward_f16")
             return out
         nprod = _DENSE_PRODUCTS[mode]
         engine = _DENSE_ENGINE.get(mode, 0)
@@ -520,7 +523,7 @@ class XPoint(torch.nn.Module):
         try:
             _lib.check(lib.xp_xpoint_forward_ex(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                                 ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
-                                                ptr(self.status_word(dev)), _lib.current_stream()), "xp_xpoint_forward_ex")
+                                                ptr(self.status_word(dev) if status is None else status), _lib.current_stream()), "xp_xpoint_forward_ex")
         finally:
             if int(amp) != prev_amp:
                 _lib.call("xp_set_amp_mode", prev_amp)

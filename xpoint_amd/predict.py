@@ -205,7 +205,7 @@ class PairPipeline:
                     view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
                     fl = self._flags()
                     self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
-                                         is_optical=None if fl is None else fl[sl], check=False)
+                                         is_optical=None if fl is None else fl[sl], check=False, **self._status_kw())
                     self.encs_done[k][h].record()
                 self.post_stream.wait_event(self.encs_done[k][h])
         else:
@@ -255,7 +255,7 @@ class PairPipeline:
         ws = self.alt_ws[k] if getattr(self, "alternate", False) else None
         # check=False: stream-ordered, no host synchronisation here; the forward's status word is read in verify() / fetch() / download_async()
         self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], workspace=ws, is_optical=self._flags(),
-                                             check=False)
+                                             check=False, **self._status_kw())
 
     def _post(self, k, masked=False, _unused=None):
         B, H, W, n = self.B, self.H, self.W, 2 * self.B
@@ -384,7 +384,7 @@ class PairPipeline:
                         view = {kk: (v[sl] if v is not None else None) for kk, v in self.raw_b[k].items()}
                         fl = self._flags()
                         self.net.forward_raw(self.images_b[k][sl], want_prob=True, want_desc=True, out=view, workspace=self.group_ws[h],
-                                             is_optical=None if fl is None else fl[sl], check=False)
+                                             is_optical=None if fl is None else fl[sl], check=False, **self._status_kw())
                     else:
                         self._encode(k, None, None)
                 enc_g.append(g)
@@ -395,6 +395,20 @@ class PairPipeline:
         self._graphs = graphs
         torch.cuda.synchronize()
 
+    def status_word(self):
+        """This pipeline's OWN forward status word (int32[1] on its device): its forwards OR their XP_STATUS_* bits into it and only its own
+        verify() / fetch() reads and clears it — another pipeline on the same model, or an eager forward, cannot consume a trip raised by a step
+        that is still in flight here.  Models without a status word (the conv back-bones) get the model's shared behaviour."""
+        if getattr(self, "_status", None) is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._status
+
+    def _status_kw(self):
+        import inspect
+        if not hasattr(self, "_status_ok"):
+            self._status_ok = hasattr(self.net, "status_word") and "status" in inspect.signature(self.net.forward_raw).parameters
+        return {"status": self.status_word()} if self._status_ok else {}
+
     def _settle_engine(self):
         """After a device-wide synchronisation: read and clear the forward status word.  Non-zero on the split-fp16 engine = an operand left
         the fp16 range: the model switches to "x3" for this weight set (warning), captured graphs are re-captured on it, and the latest call
@@ -402,7 +416,7 @@ class PairPipeline:
         engine raises (models.XPoint.handle_status).  Returns True when it re-ran."""
         if not hasattr(self.net, "status_word"):
             return False
-        word = self.net.status_word(self.device)
+        word = self.status_word()
         st = int(word.item())
         if st == 0:
             return False
@@ -433,7 +447,7 @@ class PairPipeline:
                 src = dict(counts=self.counts, kp=self.kp, match_count=self.m["match_count"], match_q=self.m["match_q"], match_t=self.m["match_t"],
                            match_d=self.m["match_d"])
                 if hasattr(self.net, "status_word"):
-                    src["status"] = self.net.status_word(self.device)      # XP_STATUS_* bits of the forwards so far: non-zero = call verify()
+                    src["status"] = self.status_word()                     # XP_STATUS_* bits of THIS pipeline's forwards so far: non-zero = call verify()
                 if self.estimate_homography:
                     src.update(H_est=self.hg["H"], n_inliers=self.hg["n_inliers"], matchesMask=self.hg["mask"])
                 self._host_src = src
