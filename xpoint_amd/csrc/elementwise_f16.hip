@@ -126,7 +126,13 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const _Float16* __re
 // ---- depthwise 3x3 (zero pad 1, no bias) + SiLU: a 4 x 4 pixel block x 4 channels per thread (elementwise.hip's scheme), 8-byte accesses.
 //      (An 8-channel / 16-byte form with packed-half operands and mixed-precision FMAs was built and measured SLOWER: 0.245 vs 0.219 ms per step at 172 registers;
 //      the kernel is not load-width-bound.) ----
-constexpr int DWH_PW = 4, DWH_PH = 4;
+#ifndef XP_DWH_PW
+#define XP_DWH_PW 4
+#endif
+#ifndef XP_DWH_PH
+#define XP_DWH_PH 4
+#endif
+constexpr int DWH_PW = XP_DWH_PW, DWH_PH = XP_DWH_PH;      // (-D overrides: tools/dwconv16_dbg.sh)
 template <bool F32COPY>
 __global__ __launch_bounds__(256) void dwconv3x3_silu_f16_kernel(const _Float16* __restrict__ x, const float* __restrict__ w, _Float16* __restrict__ y,
                                                                  float* __restrict__ y32, int B, int H, int W, int C) {
