@@ -71,7 +71,11 @@ def test_bench_hygiene_keys_and_fast_class_label():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["precision_class"] == "amp16f" and "NOT the headline" in out["metric"] and out["dtype"].startswith("f16 storage")
-    assert "_f16" in out["roofline"]["kernel"] and out["roofline"]["peak"] == 2500.0
+    # the class's dominant kernel is whichever tag holds most of the step: the one-product GEMM (matrix-pipe roofline, 2.5 PF/s) or, since the fused MLPs and
+    # the GEMM tiles got faster, an SS2D pass (HBM roofline) — the two are within a few per cent of each other
+    roof = out["roofline"]
+    assert ("_f16" in roof["kernel"] and roof["peak"] == 2500.0 and roof["bound"] == "mfma") or (roof["kernel"].startswith("ss2d_") and roof["bound"] == "hbm"), roof
+    assert 0 < roof["frac"] < 1
 
 
 def test_bench_launcher_refuses_more_gpus_than_visible():
