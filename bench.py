@@ -142,6 +142,21 @@ def pmc_kernel_for_tag(tag, names):
     return hits[0]
 
 
+def pmc_family_for_tag(tag, names):
+    """Tags that cover SEVERAL template instances in one step (the chunked SS2D passes run once per stage: dt_rank 6 / 12 / 24): all kernels of the family,
+    under both spellings rocprofv3 prints (demangled `ss2d_pass3<6, true, ...>`, or the raw mangled name when the demangler gives up on _Float16)."""
+    import re
+    fam = {"ss2d_pass1": (r"ss2d_pass1<\d+,", r"ss2d_pass1ILi\d+E"), "ss2d_pass2": (r"ss2d_pass2$", r"ss2d_pass2E"),
+           "ss2d_pass3_row": (r"ss2d_pass3<\d+, false,", r"ss2d_pass3ILi\d+ELb0E"), "ss2d_pass3_col_ln": (r"ss2d_pass3<\d+, true,", r"ss2d_pass3ILi\d+ELb1E")}.get(tag)
+    if fam is None:
+        return [pmc_kernel_for_tag(tag, names)]
+    pats = [re.compile(f) for f in fam]
+    hits = [n for n in names if any(p.search(n) for p in pats)]
+    if not hits:
+        raise KeyError(f"tag {tag!r} matches no kernel of the PMC file (patterns {fam})")
+    return hits
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -592,9 +607,10 @@ def main():
         # process).  A tag that matches no kernel of the PMC files is reported in the line (traffic_error), never swallowed.
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic{pmc_suffix}.json")))["kernels"]
-            kname = pmc_kernel_for_tag(dominant, list(pmc))
-            roof["traffic"] = round(pmc[kname]["hbm_bytes_per_launch"])
-            roof["traffic_kernel"] = kname
+            knames = pmc_family_for_tag(dominant, list(pmc))
+            nl = sum(pmc[k]["launches"] for k in knames)            # launch-weighted mean over the tag's template instances, like `achieved`
+            roof["traffic"] = round(sum(pmc[k]["hbm_bytes_per_launch"] * pmc[k]["launches"] for k in knames) / nl)
+            roof["traffic_kernel"] = knames[0] if len(knames) == 1 else knames
             roof["traffic_source"] = f"profiles/pmc_traffic{pmc_suffix}.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
         except Exception as e:
             roof["traffic_error"] = f"{type(e).__name__}: {e}"

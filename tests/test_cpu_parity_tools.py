@@ -231,6 +231,16 @@ def test_bench_pmc_lookup_covers_the_committed_counter_files():
         for tag in ("gemm_f16_mfma_128x128", "gemm_f16_mfma_128x96_k32", "gemm_f16_mfma_128x192", "gemm_f16_mfma_256x128", "conv3x3_f16_mfma_128x128",
                     "conv3x3_f16_mfma_128x96", "ln_mlp_fused_f16_c96", "ln_mlp_fused_f16_c192", "ln_proj_f16_c96", "ln_proj_f16_c192"):
             assert bench.pmc_kernel_for_tag(tag, names) in names, (fn, tag)
+    # tags that cover one template instance per stage (the chunked SS2D passes) resolve to the whole family, in either spelling of the kernel name
+    for fn in ("pmc_traffic.json", "pmc_traffic_amp16f.json"):
+        path = os.path.join(root, "profiles", fn)
+        if os.path.exists(path):
+            names = list(json.load(open(path))["kernels"])
+            for tag in ("ss2d_pass1", "ss2d_pass3_row", "ss2d_pass3_col_ln"):
+                fam = bench.pmc_family_for_tag(tag, names)
+                assert len(fam) == 3 and all(n in names for n in fam), (fn, tag, fam)
+            assert len(bench.pmc_family_for_tag("ss2d_pass2", names)) == 1
+            assert set(bench.pmc_family_for_tag("ss2d_pass3_row", names)).isdisjoint(bench.pmc_family_for_tag("ss2d_pass3_col_ln", names))
     names = list(json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["kernels"])
     for tag in ("ss2d_pass2", "dwconv3x3_silu", "layernorm"):          # HBM-bound tags: traffic file only
         try:
