@@ -18,3 +18,12 @@ for (M, C) in [(307200, 96), (76800, 192)]:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"M {M:7d} C {C:4d} H {H4:5d}: ln_mlp_fused_f16 {ms*1e3:8.1f} us  {4.0*M*C*H4/ms/1e9:7.1f} TF/s", flush=True)
+    Y = torch.empty(M, C, device="cuda", dtype=torch.float16); W0 = (torch.randn(C, C, device="cuda") * 0.05).half()
+    def runp(): L.call("xp_ln_proj_f16", L.ptr(X), L.ptr(lw), L.ptr(lb), 1e-5, L.ptr(W0), L.ptr(Y), M, C, st)
+    for _ in range(3): runp()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20): runp()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"M {M:7d} C {C:4d}        : ln_proj_f16      {ms*1e3:8.1f} us  {4.0*M*C/ms/1e9:7.2f} TB/s", flush=True)

@@ -274,29 +274,38 @@ int mlp16_launch(const Mlp16Params& p, hipStream_t s) {
 }
 
 // ---- norm + in_proj of a VSS block in one launch (VMamba.py:1225, :649):  y = LayerNorm(x) W^T  (no bias), y (M, N) half.  Same row-stationary layout: the
-//      wave's LayerNorm-ed rows as the MFMA "A" operand from the padded a image, the WHOLE weight matrix (N x C, N <= 192: <= 77 KB) by one LDS-DMA fill, the
-//      32 x N result of a wave staged through its own a rows for 16-byte stores. ----
+//      wave's LayerNorm-ed rows go through a padded a image into operand fragments in registers; the image's bytes then take the WHOLE weight matrix
+//      (N x C, N <= 192: <= 77 KB) by one LDS-DMA fill and finally the 32 x N staging tile of every wave for 16-byte stores: ONE LDS region, three uses —
+//      26 KB at C = 96 (four workgroups per CU), 77 KB at C = 192 (two; 128 KB and one with separate images). ----
 struct LnProj16Params { const _Float16* X; _Float16* Y; const _Float16* W; const float* ln_w; const float* ln_b; float eps; int M; };
 
 template <int C>
-__global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void ln_proj_f16_kernel(LnProj16Params p) {
+__global__ __launch_bounds__(256, C <= 96 ? 4 : 2) void ln_proj_f16_kernel(LnProj16Params p) {
     constexpr int N = C, SPA = C / 8 + 1, JN = N / 32;
-    constexpr int A_BYTES = (128 * SPA * 16 + 1023) / 1024 * 1024;
-    extern __shared__ __align__(16) unsigned char lds[];
+    extern __shared__ __align__(16) unsigned char lds[];      // ONE region: the a image (prologue) -> the weight image (MFMA phase) -> the output staging tiles
     const int lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * 128;
     const char* zero = reinterpret_cast<const char*>(g_m16_zero_page);
+    mlp16_ln_rows<C>(p.X, p.ln_w, p.ln_b, p.eps, p.M, m0, wave, lane, lds, SPA);
+    // the wave's LayerNorm-ed rows as operand fragments in registers (each wave wrote and reads only its own rows: LDS operations of a wave execute in order)
+    m16x8 afrag[C / 16];
+    {
+        const unsigned char* a_rows = lds + (wave * 32 + fr) * (SPA * 16) + fh * 16;
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) afrag[ks] = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                       // every wave has its fragments: the image's bytes become the weight image
+    }
     {   // weight image: N rows of SPA slots
         constexpr int np = (N * SPA * 16 + 1023) / 1024;
         for (int pc = wave; pc < np; pc += 4) {
             const int slot = pc * 64 + lane;
             const int r = slot / SPA, c = slot - r * SPA;
             const char* src = (r < N && c < SPA - 1) ? reinterpret_cast<const char*>(p.W) + (int64_t)r * (C * 2) + c * 16 : zero;
-            __builtin_amdgcn_global_load_lds(src, (m16_lds_ptr_t)(lds + A_BYTES + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src, (m16_lds_ptr_t)(lds + pc * 1024), 16, 0, 0);
         }
     }
-    mlp16_ln_rows<C>(p.X, p.ln_w, p.ln_b, p.eps, p.M, m0, wave, lane, lds, SPA);
     m16acc acc[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j)
@@ -304,12 +313,10 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void ln_proj_f16_kernel(LnPro
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned char* a_rows = lds + (wave * 32 + fr) * (SPA * 16) + fh * 16;
-    const unsigned char* w_rows = lds + A_BYTES + fr * (SPA * 16) + fh * 16;
+    const unsigned char* w_rows = lds + fr * (SPA * 16) + fh * 16;
     {
-        m16x8 afr[2], bfr[2][JN];
+        m16x8 bfr[2][JN];
         auto rd = [&](int ks, int set) {
-            afr[set] = *reinterpret_cast<const m16x8*>(a_rows + ks * 32);
 #pragma unroll
             for (int j = 0; j < JN; ++j) bfr[set][j] = *reinterpret_cast<const m16x8*>(w_rows + j * 32 * (SPA * 16) + ks * 32);
         };
@@ -318,11 +325,12 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void ln_proj_f16_kernel(LnPro
         for (int ks = 0; ks < C / 16; ++ks) {
             if (ks + 1 < C / 16) rd(ks + 1, (ks + 1) & 1);
 #pragma unroll
-            for (int j = 0; j < JN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1], bfr[ks & 1][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < JN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[ks], bfr[ks & 1][j], acc[j], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    unsigned char* ot = lds + wave * 32 * (SPA * 16);          // the wave's own a rows: only this wave reads them
+    __syncthreads();                                           // everybody is done with the weight image: its bytes become the staging tiles
+    unsigned char* ot = lds + wave * 32 * (SPA * 16);          // the wave's own 32 staging rows
     constexpr int RS = SPA * 16;
 #pragma unroll
     for (int j = 0; j < JN; ++j)
@@ -347,7 +355,8 @@ __global__ __launch_bounds__(256, C <= 96 ? 2 : 1) void ln_proj_f16_kernel(LnPro
 template <int C>
 int lnproj16_launch(const LnProj16Params& p, hipStream_t s) {
     constexpr int SPA = C / 8 + 1;
-    constexpr int LDS = (128 * SPA * 16 + 1023) / 1024 * 1024 + (C * SPA * 16 + 1023) / 1024 * 1024;
+    constexpr int A_IMG = (128 * SPA * 16 + 1023) / 1024 * 1024, W_IMG = (C * SPA * 16 + 1023) / 1024 * 1024;
+    constexpr int LDS = A_IMG > W_IMG ? A_IMG : W_IMG;         // one region, three uses (see the kernel)
     static bool attr_set = false;
     if (!attr_set) {
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_proj_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
