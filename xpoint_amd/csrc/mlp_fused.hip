@@ -553,7 +553,32 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     // second one) puts two waves on every SIMD; the narrower ones run two 4-wave workgroups per CU.
     static const bool nw4 = getenv("XP_MLP_H2_NW4") != nullptr && atoi(getenv("XP_MLP_H2_NW4")) != 0;      // A/B: 0.716 (8 waves) vs 0.747 ms (4 waves) per two launches
     if (p.s2 || (MODE == 2 && p.s0)) {
-        if (C == 192 && !nw4) return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(p, s);
+        if (C == 192 && !nw4) {
+            // One 256-row workgroup per CU: M = 76 800 rows (16 images of 480 x 640 at stage 1) is 300 workgroups = one full round of the chip + 44 workgroups
+            // that take as long again.  When the last round would be less than half full, its rows run as 128-row (4-wave) workgroups in a second launch —
+            // twice as many CUs for them, 0.69 of the time per round (XP_MLP_H2_NW4 A/B).  Every wave owns its 32 rows end to end in both instances, so the
+            // split never changes a result bit (and the batch-invariance tests compare exactly such calls); XP_MLP_TAIL=0 turns it off.
+            static const bool tail_split = !(getenv("XP_MLP_TAIL") && atoi(getenv("XP_MLP_TAIL")) == 0);
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int dev = 0, v = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                n_cu = v;
+            }
+            const int round_rows = n_cu * 256;
+            const int rem = p.M % round_rows;
+            if (tail_split && p.M > round_rows && rem > 0 && rem <= round_rows / 2) {
+                MlpParams a = p, b = p;
+                a.M = p.M - rem;
+                b.M = rem;
+                b.X = p.X + (int64_t)a.M * C;
+                if (p.T1) b.T1 = p.T1 + (int64_t)a.M * C;
+                if (p.Out) b.Out = p.Out + (int64_t)a.M * p.Nout;
+                const int rc = launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(a, s);
+                return rc != XP_OK ? rc : launch_mlp_np<C, 4, MODE, 3, true>(b, s);
+            }
+            return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(p, s);
+        }
         return launch_mlp_np<C, 4, MODE, 3, true>(p, s);
     }
     switch (xp_dense_products_value()) {      // precision class of the dense kernels (xp_set_dense_products)
