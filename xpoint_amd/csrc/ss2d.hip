@@ -16,7 +16,9 @@
 //           in the reference's order (y0 + y2) + (y1 + y3) (csm_triton.py:60-62) and applies out_norm
 //           (LayerNorm over C, VMamba.py:644) before the single store.
 // Directions are stored in the order (0, 2, 1, 3) so that a pair's operands are adjacent.
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <string>
@@ -869,10 +871,22 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     if (C < 192) { cpb = 192 / C; while ((cpb * C) % 64) ++cpb; }
     XP_CHECK_ARG((cpb * C) % 64 == 0 && cpb * C <= 768, "%s: unsupported C=%d", who, C);
     p.cpb = cpb;
-    // chunk length: keeps the pass-3 LDS tile (cpb*T*C floats) near 12 KB so that many workgroups share a CU (measured best on MI355X)
-    static const int t_budget = getenv("XP_SS2D_TBUDGET") ? atoi(getenv("XP_SS2D_TBUDGET")) : 3072;
+    // chunk length per LAYER (C only, never the batch).  Round 4 re-measured it in the overlapped step instead of alone: 32 pixels at C <= 96, 16 at C = 192 / 384
+    // (round 1-3: 16 / 16 / 8, chosen on the stand-alone core) — alone the core times are equal within 2 % at stages 0 - 1, but half as many chunks are half as
+    // many workgroups, carry entries and aggregate stores, and with three encoders in flight that is what the step pays for: 1 674 - 1 677 -> 1 707 - 1 708
+    // pairs/s on one box (64 / 32 / 16: 1 662; 64 / 64 / 32: 1 653).  XP_SS2D_TBUDGET / XP_SS2D_T ("96:16,384:8") override for A/B runs.
+    static const int t_budget = getenv("XP_SS2D_TBUDGET") ? atoi(getenv("XP_SS2D_TBUDGET")) : 6144;
     int T = t_budget / (cpb * C);
     T = T >= 64 ? 64 : (T >= 32 ? 32 : (T >= 16 ? 16 : 8));
+    if (!getenv("XP_SS2D_TBUDGET") && cpb == 1 && T > 16) T = 16;          // C = 192: 16 (32 measured equal in the step, slower alone)
+    if (const char* tl = getenv("XP_SS2D_T")) {          // experiments: "96:32,192:16,384:16" = chunk length per channel count
+        for (const char* q = tl; q && *q;) {
+            int cc = 0, tt = 0;
+            if (sscanf(q, "%d:%d", &cc, &tt) == 2 && cc == C && (tt == 8 || tt == 16 || tt == 32 || tt == 64)) T = tt;
+            q = strchr(q, ',');
+            if (q) ++q;
+        }
+    }
     p.T = T;
     const int L = H * W;
     p.nc = xp_cdiv(L, T);
