@@ -262,10 +262,16 @@ int dispatch(const GemmParams& p_in, hipStream_t s) {
         p.ngroup = force_g >= 0 ? force_g : g;
     }
     static const int force = getenv("XP_H2_TILE") ? atoi(getenv("XP_H2_TILE")) : -1;   // tuning experiments only
+    // 64 x 128 tiles (twice the workgroups) only when there are fewer than 128 tiles of 128 x 128 — i.e. at small batches, where the launch would leave most
+    // CUs idle.  Rounds 2-3 used "< 256, or < 512 for wide N at M <= 8192", tuned on stand-alone launches; in the overlapped step the other streams fill the idle
+    // CUs and the 128 x 128 tile's lower cost per FLOP wins: +0.5 to +1.5 % at 8 pairs, equal at 1 - 2 pairs (XP_H2_NO64 = 0 old rule, 1 never, 2 this rule).
+    // Every tile and both engines walk K in the same order: the choice never changes a result bit (tools checked by CRC), so it MAY depend on M.
+    static const int no64 = getenv("XP_H2_NO64") ? atoi(getenv("XP_H2_NO64")) : 2;
+    const int64_t t128 = (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128);
+    const bool want64 = no64 == 1 ? false : no64 == 2 ? t128 < 128 : ((p.M <= 8192 && N >= 512 && t128 < 512) || t128 < 256);
     const int sel = force >= 0 ? force
                   : N <= 32 ? 0 : N <= 64 ? 1 : (N <= 96 || (N % 96 == 0 && (N / 96) % 4 != 0)) ? 2
-                  : ((p.M <= 8192 && N >= 512 && (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 512) ||
-                     (int64_t)xp_cdiv(p.M, 128) * xp_cdiv(N, 128) < 256) ? 3 : 4;       // fewer 128 x 128 tiles than CUs (x_proj of the deep stages: N = 104 / 200): 64 x 128
+                  : want64 ? 3 : 4;       // fewer 128 x 128 tiles than CUs (x_proj of the deep stages: N = 104 / 200): 64 x 128
     // Row-stationary engine for the implicit-GEMM convolutions (measured: 0.55 vs 0.71 ms for the four big convs of a step; the gathered
     // A rows cost the tile engine an LDS round trip they do not need), the tile engine for plain GEMMs (equal at K >= 384, 15 % faster at
     // K = 96 where the row-stationary lane-per-row loads touch 32 cache lines per instruction).  XP_H2_ENGINE = rs | lds forces one (A/B).
