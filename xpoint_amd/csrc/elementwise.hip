@@ -121,7 +121,13 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 // once (36 float4 loads per 16 outputs; a thread per output row re-reads two of its three rows: 72).  0.285 -> 0.244 ms per step.  Every output still
 // accumulates its taps in (kh, kw) order with padded taps skipped — input rows arrive in ascending order, and an input row ih
 // is tap kh = ih - oh + 1 of output row oh — so results are bit-identical to the one-row form.
-constexpr int DW_PW = 4, DW_PH = 4;
+#ifndef XP_DW_PW
+#define XP_DW_PW 4
+#endif
+#ifndef XP_DW_PH
+#define XP_DW_PH 4
+#endif
+constexpr int DW_PW = XP_DW_PW, DW_PH = XP_DW_PH;      // (-D overrides: tools/instep_ab.sh)
 __device__ __forceinline__ float ew_r16(float v) { return (float)(_Float16)v; }
 // AMP (xp_set_amp_mode): the convolution's output and the SiLU's output are half tensors under autocast: both rounded to fp16
 template <bool AMP>

@@ -115,8 +115,14 @@ __device__ __forceinline__ void mlp16_ln_rows(const _Float16* __restrict__ X, co
     }
 }
 
+#ifndef XP_MLP16_WG96
+#define XP_MLP16_WG96 3
+#endif
+#ifndef XP_MLP16_WG192
+#define XP_MLP16_WG192 2
+#endif
 template <int C>
-__global__ __launch_bounds__(256, C <= 96 ? 3 : 2) void mlp_f16_kernel(Mlp16Params p) {
+__global__ __launch_bounds__(256, C <= 96 ? XP_MLP16_WG96 : XP_MLP16_WG192) void mlp_f16_kernel(Mlp16Params p) {
     using T = Mlp16Cfg<C>;
     constexpr int HC = T::HC, SPA = T::SPA, SPH = T::SPH, JN = C / 32, JH = HC / 32;
     extern __shared__ __align__(16) unsigned char lds[];

@@ -31,6 +31,9 @@
 #define XP_SS2D_DBG 0   /* timing experiments only (wrong results): 1 no out_norm tail, 2 no loads of the row pair's partial sums, 4 no step arithmetic (projection, softplus, exp), 8 no u loads */
 #endif
 
+// L bound of the sequential (one wave per route) form, per image: see ss2d_core_impl
+#define XP_SS2D_SEQ_DEFAULT_MAXL 2048
+
 namespace {
 
 constexpr float XP_L2E = 1.44269504088896340736f;   // log2(e): folded into the dt weights, the dt bias and A where they are loaded
@@ -307,7 +310,10 @@ __global__ __launch_bounds__(768) void ss2d_pass1(SS2DParams p) {
 // pass 2: carry over chunks, per (image, pair, direction, channel).  Two-level so that the sequential depth is
 // ~2*nc/G + G instead of nc: G groups of consecutive chunks are composed in parallel, a short serial pass gives the
 // state entering each group, then every group re-walks its chunks storing the state entering each chunk (over S).
-constexpr int P2_G = 16;
+#ifndef XP_SS2D_P2G
+#define XP_SS2D_P2G 16
+#endif
+constexpr int P2_G = XP_SS2D_P2G;      // (-D override: tools/instep_ab.sh)
 __global__ __launch_bounds__(64 * P2_G) void ss2d_pass2(SS2DParams p) {
     __shared__ float s_P[P2_G][64], s_S[P2_G][64];
     const int lane = threadIdx.x, g = threadIdx.y;
@@ -896,15 +902,18 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     // Deep stages -> the sequential form.  The choice uses per-image quantities only (dt_rank, L), never the batch: the two forms differ
     // by rounding (~1e-7), and a result that changed with the number of images sharing a call would make grouped / split / single-image
     // runs of the same image disagree.  tools/ss2d_bench.py: C = 768, L = 300: 44 / 46 / 56 / 103 us for 2 / 4 / 16 / 32 images against
-    // 51 / 65 / 169 / 292 us chunked; C = 768, L = 1024, 8 images: 131 vs 248 us; C = 384, L = 1200 is a draw in the timed step
-    // (148 vs 195 us alone at 16 images, 117 vs 47 us at 2) and stays chunked.  XP_SS2D_SEQ_MAXL overrides the L bound of the
-    // matrix-pipe kernel; xp_ss2d_core_set_mode / XP_SS2D_SEQ force one form.
+    // 51 / 65 / 169 / 292 us chunked; C = 768, L = 1024, 8 images: 131 vs 248 us.  C = 384, L = 1200 (stage 2 of a 480 x 640 image): 148 vs 195 us alone at
+    // 16 images but 117 vs 47 us at 2 — the sequential form's time is the route's length, whatever the batch.  Rounds 2-3 called it a draw in the step and kept
+    // it chunked (bound 512); re-measured in round 4 in the three-stream step it is +1.6 % at 8 pairs per call (1 671-1 673 -> 1 698, three alternations), 0 at
+    // 4, -0.9 % at 2 and -4.8 % at ONE pair per call (0.99 -> 1.03 ms per pair).  The bound is now 2 048 for every dt_rank >= 16 shape — the configurations
+    // this path is measured on run >= 8 pairs per GPU — and XP_SS2D_SEQ_MAXL=512 restores the one-pair-at-a-time optimum.  xp_ss2d_core_set_mode / XP_SS2D_SEQ
+    // force one form.
     const int mode = g_ss2d_mode.load();
     static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
     const bool seq2 = seq_scan2_applies(R, H, W, C);
     // (the f32-container mixed-precision class always takes the chunked form: its dt rounding lives in step_vals; the fp16-storage class takes the
     //  sequential form when the caller supplied f32 copies of u and xdbl — xp_ss2d_core_f16_wants_f32_copies says when it will)
-    bool seq = (!half_io && xp_amp_value()) ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512))));
+    bool seq = (!half_io && xp_amp_value()) ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL)));
     if (half_io && !(seq2 && u32 && xdbl32)) seq = false;
     if (seq && C <= 768 && C % 64 == 0) {
         if (half_io) { p.u = u32; p.xdbl = xdbl32; }
@@ -946,7 +955,7 @@ extern "C" int xp_ss2d_core_f16_wants_f32_copies(int H, int W, int C, int R) {
     const int mode = g_ss2d_mode.load();
     static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
     if (!(seq_scan2_applies(R, H, W, C) && C <= 768 && C % 64 == 0)) return 0;
-    return mode >= 0 ? (mode != 0) : (H * W <= (max_l >= 0 ? max_l : (R >= 48 ? 1024 : 512)));
+    return mode >= 0 ? (mode != 0) : (H * W <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL));
 }
 
 // The fast mixed-precision class's core: u (batch,H,W,C) and xdbl (batch*H*W, 4*(R+2)) are fp16, out is fp16 (= out_norm's f32 result cast to half,
