@@ -874,7 +874,8 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     p.out = (float*)out; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
     // threads = cpb * C must be a multiple of 64 and <= 768
     int cpb = 1;
-    if (C < 192) { cpb = 192 / C; while ((cpb * C) % 64) ++cpb; }
+    static const int blk_threads = getenv("XP_SS2D_THREADS") ? atoi(getenv("XP_SS2D_THREADS")) : 192;      // experiments: threads per workgroup of the chunked passes
+    if (C < blk_threads) { cpb = blk_threads / C; while ((cpb * C) % 64) ++cpb; }
     XP_CHECK_ARG((cpb * C) % 64 == 0 && cpb * C <= 768, "%s: unsupported C=%d", who, C);
     p.cpb = cpb;
     // chunk length per LAYER (C only, never the batch).  Round 4 re-measured it in the overlapped step instead of alone: 32 pixels at C <= 96, 16 at C = 192 / 384
