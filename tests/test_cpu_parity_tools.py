@@ -238,7 +238,7 @@ def test_bench_pmc_lookup_covers_the_committed_counter_files():
             names = list(json.load(open(path))["kernels"])
             for tag in ("ss2d_pass1", "ss2d_pass3_row", "ss2d_pass3_col_ln"):
                 fam = bench.pmc_family_for_tag(tag, names)
-                assert len(fam) == 3 and all(n in names for n in fam), (fn, tag, fam)
+                assert len(fam) >= 2 and all(n in names for n in fam), (fn, tag, fam)      # stages 0 and 1 (stage 2 took the sequential form in round 4)
             assert len(bench.pmc_family_for_tag("ss2d_pass2", names)) == 1
             assert set(bench.pmc_family_for_tag("ss2d_pass3_row", names)).isdisjoint(bench.pmc_family_for_tag("ss2d_pass3_col_ln", names))
     names = list(json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["kernels"])
