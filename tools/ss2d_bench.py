@@ -41,7 +41,9 @@ for (C, H, W) in shapes:
         us = e0.elapsed_time(e1) / n * 1e3
         outs[mode] = out.clone()
         by = 4.0 * M * (7 * C + 4 * (R + 2))
-        print(f"C{C:4d} {H}x{W} R{R:2d} mode {mode:2d}: {us:7.1f} us  {by/us/1e6:6.2f} TB/s algorithmic", flush=True)
+        import zlib
+        crc = zlib.crc32(out.cpu().numpy().tobytes())
+        print(f"C{C:4d} {H}x{W} R{R:2d} mode {mode:2d}: {us:7.1f} us  {by/us/1e6:6.2f} TB/s algorithmic   crc {crc:08x}", flush=True)
     L.call("xp_ss2d_core_set_mode", -1)
     if len(outs) > 1:
         ks = list(outs)

@@ -725,6 +725,121 @@ __global__ __launch_bounds__(64) void ss2d_seq_scan2(SS2DParams p, float* __rest
     }
 }
 
+// The same sequential recurrence PIPELINED OVER THE WAVES OF A WORKGROUP (round 4).  ss2d_seq_scan2 is one wave per (image, route, 64 channels): its time is the
+// route's length — ~100 instructions per step of issue latency, 117 us for L = 1 200 whatever the batch — although only two of those instructions (h = a h + b,
+// y = C h + D u) form the chain; the projection, softplus and exp of a step depend on nothing before it.  Here NW waves share the route: wave w takes the tiles
+// w, w + NW, ... — loads, matrix-pipe dt projection and the (a, b, C, D u) of all 32 steps of its tile into registers, in parallel with the other waves' tiles —
+// then waits for its turn (an LDS counter), takes the running state from LDS, runs the 32 chain steps + stores, and passes the state on.  The chain itself is the
+// same instruction sequence in the same order (h = a * h + b; y = C * h + D u with the same operands), so the results are bit-identical to ss2d_seq_scan2;
+// what changes is that the chain's length, not the evaluation's, sets the time.  All NW waves of a workgroup are resident together, so the turn wait cannot
+// deadlock; a waiting wave sleeps (s_sleep) on a SIMD nobody else of the workgroup uses.
+template <int R, bool AMP, int NW>
+__global__ __launch_bounds__(64 * NW) void ss2d_seq_scan3(SS2DParams p, float* __restrict__ ys) {
+    constexpr int RW = R + 2, NP = RW / 2, NPL = (NP + 1) / 2;
+    __shared__ __align__(16) float s_x[NW][2][SEQ_TP * RW];
+    __shared__ float s_h[64];
+    __shared__ int s_turn;
+    const int lane = threadIdx.x & 63, d = blockIdx.y, b = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = d >> 1, back = d & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int L = p.H * p.W, XD = 4 * RW;
+    const int c = blockIdx.x * 64 + lane;
+    if (threadIdx.x < 64) s_h[lane] = 0.f;
+    if (threadIdx.x == 0) s_turn = 0;
+    __syncthreads();
+    DtWeights<R> dw;
+    dt_load_weights<R, AMP>(dw, p.wdt + (int64_t)d * R * p.C, p.dtb + d * p.C, p.C, blockIdx.x * 64);
+    const float Av = XP_L2E * p.A[d * p.C + c], Dv = p.Dp[d * p.C + c];
+    const int plane_bytes = L * p.C * 4;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + (int64_t)b * L * p.C), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(ys + ((int64_t)d * p.Bn + b) * L * p.C), 0, plane_bytes, 0x00020000);
+    const int cbyte = c * 4;
+    const char* xb = reinterpret_cast<const char*>(p.xdbl + (int64_t)b * L * XD + pair * 2 * RW + back * RW) + fh * (NPL * 8);
+    const float invH = 1.f / (float)p.H;
+    auto tile_offsets = [&](int t, int& off_uy, int& off_x) {           // as ss2d_seq_scan2
+        const int i = t * SEQ_TP + fr;
+        const int ic = min(i, L - 1);
+        const int l = back ? L - 1 - ic : ic;
+        int px = l;
+        if (pair == 1) {
+            const int ww = (int)(((float)l + 0.5f) * invH);
+            px = (l - ww * p.H) * p.W + ww;
+        }
+        off_uy = i < L ? px * (p.C * 4) : 0x7fffffff;
+        off_x = px * (XD * 4);
+    };
+    float ucur[SEQ_TP], unext[SEQ_TP];
+    float2 xreg[NPL];
+    int offc = 0, offn = 0, offx = 0;
+    auto load_tile = [&](int off_uy, int off_x, float (&uv)[SEQ_TP]) {
+#pragma unroll
+        for (int j = 0; j < SEQ_TP; ++j)
+            uv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, cbyte, __builtin_amdgcn_readlane(off_uy, j), 0));
+        const char* xr = xb + off_x;
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) {
+            const int pe = (e == NPL - 1 && 2 * NPL > NP) ? (fh ? e - 1 : e) : e;
+            xreg[e] = *reinterpret_cast<const float2*>(xr + pe * 8);
+        }
+    };
+    const int xdst = fr * RW + fh * (NPL * 2);
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) {
+            const int pe = (e == NPL - 1 && 2 * NPL > NP) ? (fh ? e - 1 : e) : e;
+            *reinterpret_cast<float2*>(&s_x[wave][buf][xdst + pe * 2]) = xreg[e];
+        }
+    };
+    const int ntile = (L + SEQ_TP - 1) / SEQ_TP;
+    if (wave < ntile) {
+        tile_offsets(wave, offc, offx);
+        load_tile(offc, offx, ucur);
+        store_x(0);
+    }
+    int it = 0;
+    for (int t = wave; t < ntile; t += NW, ++it) {
+        if (t + NW < ntile) { tile_offsets(t + NW, offn, offx); load_tile(offn, offx, unext); }
+        const float* sx = s_x[wave][it & 1];                            // (written and read by this wave only: LDS operations of a wave execute in order)
+        float dtv[2][16];
+        dt_tile<R, AMP>(dw, sx, RW, dtv);
+        float a[SEQ_TP], bb[SEQ_TP], cv[SEQ_TP];
+#pragma unroll
+        for (int j = 0; j < SEQ_TP; ++j) {
+            const float2 bc = *reinterpret_cast<const float2*>(sx + j * RW + R);
+            float delta;
+            xp_softplus_decay_l2_nb(XP_DTV(dtv, j), Av, delta, a[j]);
+            bb[j] = delta * bc.x * ucur[j];
+            cv[j] = bc.y;
+            ucur[j] = Dv * ucur[j];                                     // D u: the second product of y = C h + D u, rounded as before
+        }
+        // (pin the tile's operand evaluation BEFORE the turn wait: they are pure arithmetic, which the compiler may otherwise sink past the wait, into the chain)
+#pragma unroll
+        for (int j = 0; j < SEQ_TP; ++j) asm volatile("" :: "v"(a[j]), "v"(bb[j]), "v"(cv[j]), "v"(ucur[j]));
+        // my turn: every tile before t has passed its state on
+        // (LDS only, and LDS operations of a wave execute in order: plain volatile accesses + compiler barriers.  An acquire / release pair at workgroup
+        //  scope would also drain the wave's outstanding GLOBAL stores and prefetch loads — s_waitcnt vmcnt(0) — into the chain: measured 1.5x instead of 3x)
+        while (*reinterpret_cast<volatile int*>(&s_turn) != t) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        float h = *reinterpret_cast<volatile float*>(&s_h[lane]);
+#pragma unroll
+        for (int j = 0; j < SEQ_TP; ++j) {
+            h = a[j] * h + bb[j];
+            const float y = cv[j] * h + ucur[j];                        // y = C*h + D*u (csms6s.py:61,67)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), ry, cbyte, __builtin_amdgcn_readlane(offc, j), 0);
+        }
+        *reinterpret_cast<volatile float*>(&s_h[lane]) = h;
+        asm volatile("" ::: "memory");
+        *reinterpret_cast<volatile int*>(&s_turn) = t + 1;
+        if (t + NW < ntile) {
+            store_x((it + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < SEQ_TP; ++j) ucur[j] = unext[j];
+            offc = offn;
+        }
+    }
+}
+
 // out[b][px][:] = LayerNorm_C((y0 + y2) + (y1 + y3)); one wave per pixel, the row held in registers (C <= 768)
 template <typename OT = float>
 __global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const float* __restrict__ ys) {
@@ -775,8 +890,28 @@ int launch_ss2d_seq(const SS2DParams& p, float* ys, hipStream_t s, bool half_out
         XpProfScope prof(("ss2d_seq_scan" + sfx).c_str(), s, 4.0 * MC * (2.0 * R + 14.0), 4.0 * (8.0 * MC + MX));
         const bool v2 = seq_scan2_applies(R, p.H, p.W, p.C);
         if constexpr (R >= 16 && R % 8 == 0) {
-            if (v2 && half_out) hipLaunchKernelGGL((ss2d_seq_scan2<R, true>), dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
-            else if (v2) hipLaunchKernelGGL((ss2d_seq_scan2<R, false>), dim3(xp_cdiv(p.C, 64), 4, p.Bn), dim3(64), 0, s, p, ys);
+            // waves per route (ss2d_seq_scan3): XP_SS2D_SEQ_NW = 1 selects the one-wave kernel (bit-identical results)
+            // as many waves per route as the chip has idle SIMDs for: 4 while 4 x routes fit the SIMDs once, else 2, else the one-wave kernel (more waves than
+            // SIMDs only add turn waits: 16 images at C = 384: 142 / 99 / 109 us with 1 / 2 / 4; at C = 768: 54 / 62 / 66; 2 images at C = 384: 116 / 70 / 46).
+            // Bit-identical for every NW (tools/ss2d_bench.py prints the CRC), so the choice may depend on the batch.
+            static const int force_nw = getenv("XP_SS2D_SEQ_NW") ? atoi(getenv("XP_SS2D_SEQ_NW")) : 0;
+            static int n_simd = 0;
+            if (n_simd == 0) {
+                int dev = 0, v = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                n_simd = 4 * v;
+            }
+            const dim3 grid(xp_cdiv(p.C, 64), 4, p.Bn);
+            const int64_t routes = (int64_t)grid.x * grid.y * grid.z;
+            const int nw = force_nw ? force_nw : (routes * 4 <= n_simd ? 4 : (routes * 2 <= n_simd ? 2 : 1));
+            if (v2 && nw == 4) {
+                if (half_out) hipLaunchKernelGGL((ss2d_seq_scan3<R, true, 4>), grid, dim3(256), 0, s, p, ys);
+                else hipLaunchKernelGGL((ss2d_seq_scan3<R, false, 4>), grid, dim3(256), 0, s, p, ys);
+            } else if (v2 && nw == 2) {
+                if (half_out) hipLaunchKernelGGL((ss2d_seq_scan3<R, true, 2>), grid, dim3(128), 0, s, p, ys);
+                else hipLaunchKernelGGL((ss2d_seq_scan3<R, false, 2>), grid, dim3(128), 0, s, p, ys);
+            } else if (v2 && half_out) hipLaunchKernelGGL((ss2d_seq_scan2<R, true>), grid, dim3(64), 0, s, p, ys);
+            else if (v2) hipLaunchKernelGGL((ss2d_seq_scan2<R, false>), grid, dim3(64), 0, s, p, ys);
         }
         if (!v2) {
             if (half_out) { xp_set_error("xp_ss2d_core_fwd_f16: the sequential form needs dt_rank >= 16 (got %d)", R); return XP_ERR_ARG; }
@@ -907,8 +1042,8 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     // 16 images but 117 vs 47 us at 2 — the sequential form's time is the route's length, whatever the batch.  Rounds 2-3 called it a draw in the step and kept
     // it chunked (bound 512); re-measured in round 4 in the three-stream step it is +1.6 % at 8 pairs per call (1 671-1 673 -> 1 698, three alternations), 0 at
     // 4, -0.9 % at 2 and -4.8 % at ONE pair per call (0.99 -> 1.03 ms per pair).  The bound is now 2 048 for every dt_rank >= 16 shape — the configurations
-    // this path is measured on run >= 8 pairs per GPU — and XP_SS2D_SEQ_MAXL=512 restores the one-pair-at-a-time optimum.  xp_ss2d_core_set_mode / XP_SS2D_SEQ
-    // force one form.
+    // this path is measured on run >= 8 pairs per GPU; the wave-pipelined kernel (ss2d_seq_scan3) then removed the one-pair cost as well (965 -> 1 029 pairs/s,
+    // above the chunked form's 1 022).  xp_ss2d_core_set_mode / XP_SS2D_SEQ force one form.
     const int mode = g_ss2d_mode.load();
     static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
     const bool seq2 = seq_scan2_applies(R, H, W, C);
