@@ -883,3 +883,20 @@ def test_cross_scan_merge_ops_vs_reference_g22(gpu_lib, golden, capsys):
             kernels.cross_scan_fn(x, **bad)
     with pytest.raises(RuntimeError):
         kernels.cross_scan_fn(x.cpu())
+
+
+def test_ss2d_sequential_wave_pipelined_is_bit_identical(gpu_lib):
+    """ss2d_seq_scan3 spreads one route's recurrence over NW = 2 / 4 waves of a workgroup (evaluation in parallel, the chain handed from wave to wave through
+    LDS) and picks NW from the batch — allowed only because it returns the bits of the one-wave kernel.  tools/ss2d_bench.py (mode 1 = sequential form) prints
+    a CRC of the core's output per shape; one child process per XP_SS2D_SEQ_NW (read once), ragged shapes (L % 32 != 0, a single tile, fewer tiles than
+    waves) and both deep-stage ranks."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    crcs = {}
+    for nw in ("1", "2", "4", "0"):                     # 0 = the automatic choice
+        env = dict(os.environ, XP_SS2D_SEQ_NW=nw, SB_BATCH="3", SB_SHAPES="384,33,29;768,7,9;384,14,20;768,4,5;384,30,40")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ss2d_bench.py"), "1"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        crcs[nw] = re.findall(r"crc ([0-9a-f]{8})", r.stdout)
+        assert len(crcs[nw]) == 5, r.stdout[-1500:]
+    assert crcs["2"] == crcs["1"] and crcs["4"] == crcs["1"] and crcs["0"] == crcs["1"], crcs
