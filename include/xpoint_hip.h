@@ -268,6 +268,10 @@ int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_t n, void* 
 int xp_stage_pair_batch(const float* optical, const float* thermal, float* images, const uint8_t* mask_optical,
                         const uint8_t* mask_thermal, uint8_t* masks, int64_t n, void* stream);
 int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream);
+/* RegNet's cost volume followed by its global average pool (reference xpoint/models/RegNet.py:44-52: bmm(x1^T, x2) -> view(N, hw, H', W') ->
+   adaptive_avg_pool2d(., 1)), without materialising the (hw, hw) volume:  v[n][p] = a[n][p] . mean_q b[n][q];  a, b (batch, hw, C) row-major
+   (channel-normalised feature rows of the two images), v (batch, hw). */
+int xp_costvolume_mean(const float* a, const float* b, float* v, int batch, int hw, int C, void* stream);
 /* Data ingest (reference datasets/ImagePairDataset.py:199-208 cv2.imread + COLOR_BGR2GRAY + / 255.0, :254-274 crop):
  * src = decoded 8-bit image on the device, (H0, W0, channels) interleaved with channels 1 (gray), 3 (R,G,B) or 4 (R,G,B,A);
  * dst (h, w) f32 = lut256[gray] of the crop at (top, left), gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14 (OpenCV's 8-bit

@@ -154,3 +154,16 @@ def test_regnet_adaptive_pool_generalisation(gpu_lib, golden):
         net.regnet_adaptive_pool = True
         _, _, hm = net(d)
     assert hm.shape == (1, 8) and bool(torch.isfinite(hm).all())
+
+
+def test_costvolume_mean_equals_bmm_then_pool(gpu_lib):
+    """xp_costvolume_mean: v[n][p] = a[n][p] . mean_q b[n][q]  ==  adaptive_avg_pool2d(bmm(x1^T, x2).view(N, hw, H', W'), 1) of the reference
+    (RegNet.py:44-52), evaluated here in float64 from the same unit rows; ragged sizes (hw not a multiple of the wave count, C not a multiple of 64)."""
+    from xpoint_amd import nnops as ops
+    for (B, hw, C) in [(3, 256, 192), (2, 77, 100), (1, 5, 64)]:
+        g = torch.Generator().manual_seed(B * 1000 + hw)
+        a = torch.nn.functional.normalize(torch.randn(B, hw, C, generator=g), dim=2)
+        b = torch.nn.functional.normalize(torch.randn(B, hw, C, generator=g), dim=2)
+        ref = torch.bmm(a.double(), b.double().transpose(1, 2)).mean(dim=2)          # (B, hw): mean over the second image's positions
+        got = ops.costvolume_mean(a.cuda().contiguous(), b.cuda().contiguous()).cpu().double()
+        assert float((got - ref).abs().max()) < 2e-7, (B, hw, C, float((got - ref).abs().max()))

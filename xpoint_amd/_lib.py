@@ -64,6 +64,7 @@ _SIGNATURES = {
     "xp_mul_mask": [c_p] * 3 + [c_l, c_p],
     "xp_stage_pair_batch": [c_p] * 6 + [c_l, c_p],
     "xp_maxpool2_nhwc": [c_p] * 2 + [c_i] * 4 + [c_p],
+    "xp_costvolume_mean": [c_p] * 3 + [c_i] * 3 + [c_p],
     "xp_ingest_u8": [c_p] + [c_i] * 7 + [c_p] * 3,
     "xp_ctx_create": [c_p, ctypes.POINTER(c_p)],
     "xp_ctx_destroy": [c_p],

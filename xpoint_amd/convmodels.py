@@ -144,6 +144,8 @@ def regnet_weights(ref_state, device):
     w = {"c1": ops.conv_w(s[p + "layer1.0.weight"]).to(device), "c2": ops.conv_w(s[p + "layer1.3.weight"]).to(device)}
     w["bn1"] = [t.to(device) for t in ops.bn_affine(s, p + "layer1.1.")]
     w["bn2"] = [t.to(device) for t in ops.bn_affine(s, p + "layer1.4.")]
+    # the two convolutions run on the split-fp16 engine (f32-grade, 3x the exact-f32 MFMA kernel's rate): offline two-plane split of (Co, 9 Ci)
+    w["c1_h2"] = ops.split_h2(w["c1"].reshape(w["c1"].shape[0], -1)); w["c2_h2"] = ops.split_h2(w["c2"].reshape(w["c2"].shape[0], -1))
     w["fc1"] = (s[p + "fc.1.weight"].float().contiguous().to(device), s[p + "fc.1.bias"].float().to(device))
     w["fc2"] = (s[p + "fc.4.weight"].float().contiguous().to(device), s[p + "fc.4.bias"].float().to(device))
     return w
@@ -164,18 +166,23 @@ def _adaptive_pool_matrix(Hh, Wh, out_h, out_w, device):
     return P.to(device)
 
 
-def regnet_forward(w, enc1_nhwc, enc2_nhwc, adaptive_pool=False):
+def regnet_forward(w, enc1_nhwc, enc2_nhwc, adaptive_pool=False, enc_both=None):
     """RegNet.forward (RegNet.py:32-52), eval mode.  enc (B, H', W', 48) NHWC -> (B, 8).  The cost volume's channel count
     must equal fc.1's input (256), i.e. (H'/2)*(W'/2) == 256 <=> a 256x256 image: raises otherwise, like the
     reference's Linear does.
     adaptive_pool=True (NOT reference semantics — the reference has none beyond 256x256): the pooled cost-volume vector, which is a
     (H'/2, W'/2) map over the FIRST image's positions, is adaptive-average-pooled to the 16 x 16 grid the FC layer was sized for, so the head
     accepts any image size; at 256x256 the pooling matrix is the identity and the result is the reference's (tests: g9)."""
-    def layer1(x):      # conv (no bias) -> BN -> ReLU, twice, then MaxPool2d(2)
-        x = ops.conv3x3(x, w["c1"], None, w["bn1"][0], w["bn1"][1], 1, False, "relu_after_affine")
-        x = ops.conv3x3(x, w["c2"], None, w["bn2"][0], w["bn2"][1], 1, False, "relu_after_affine")
+    def layer1(x):      # conv (no bias) -> BN -> ReLU, twice, then MaxPool2d(2); BOTH images in one batch (2B crops per launch)
+        x = ops.conv3x3_h2(x, w["c1_h2"], w["c1"].shape[0], None, w["bn1"][0], w["bn1"][1], 1, False, "relu_after_affine")
+        x = ops.conv3x3_h2(x, w["c2_h2"], w["c2"].shape[0], None, w["bn2"][0], w["bn2"][1], 1, False, "relu_after_affine")
         return ops.maxpool2(x)
-    a, b = layer1(enc1_nhwc.contiguous()), layer1(enc2_nhwc.contiguous())
+    B0 = enc1_nhwc.shape[0]
+    if enc_both is not None:      # the caller's single (2B, H', W', 48) encoder output (models.predict_homography): both images in one batch, no copy
+        ab = layer1(enc_both.contiguous())
+    else:
+        ab = None
+    a, b = (ab[:B0], ab[B0:]) if ab is not None else (layer1(enc1_nhwc.contiguous()), layer1(enc2_nhwc.contiguous()))
     B, Hh, Wh, C = a.shape
     hw = Hh * Wh
     n_in = w["fc1"][0].shape[1]
@@ -183,11 +190,9 @@ def regnet_forward(w, enc1_nhwc, enc2_nhwc, adaptive_pool=False):
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{hw} and {n_in}x{w['fc1'][0].shape[0]})")
     an = ops.l2norm_rows(a.view(B * hw, C), 1e-12).view(B, hw, C)      # F.normalize over channels
     bn = ops.l2norm_rows(b.view(B * hw, C), 1e-12).view(B, hw, C)
-    mean_w = torch.full((1, hw), 1.0 / hw, device=a.device)            # adaptive_avg_pool2d over the (H', W') axes of cv
-    v = torch.empty((B, hw), device=a.device)
-    for i in range(B):
-        cv = ops.linear(an[i], bn[i])                                  # bmm(x1^T, x2): (hw, hw), RegNet.py:50
-        ops.linear(cv, mean_w, out=v[i].view(hw, 1), ldc=1)
+    # bmm(x1^T, x2) (hw, hw) then adaptive_avg_pool2d over the second image's positions (RegNet.py:50-52) = each row of x1 against the MEAN row of x2:
+    # one launch for the batch, the volume is never formed (round 4; before: two GEMM launches per sample)
+    v = ops.costvolume_mean(an, bn)
     if hw != n_in:
         g = int(round(n_in ** 0.5))
         if g * g != n_in:

@@ -646,6 +646,44 @@ extern "C" int xp_mul_mask(const float* x, const uint8_t* mask, float* y, int64_
     return XP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RegNet cost volume + global average pool without the volume (reference RegNet.py:44-52: cv = bmm(x1^T, x2) (hw, hw), then
+// adaptive_avg_pool2d(cv.view(N, hw, H', W'), 1) = the mean over the SECOND image's positions):
+//     v[b][p] = (1 / hw) sum_q  a[b][p] . b[b][q]  =  a[b][p] . mean_q b[b][q]
+// — O(hw C) instead of O(hw^2 C), one launch for the whole batch instead of two GEMM launches per sample.  One workgroup per sample: column means of b
+// (thread = channel, rows in ascending order), then a wave per row of a (lane partial sums over c = lane, lane + 64, ..., wave reduction).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void costvolume_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ v, int hw, int C) {
+    extern __shared__ float s_mean[];                     // C floats
+    const int n = blockIdx.x;
+    const float* bb = b + (int64_t)n * hw * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < hw; ++q) s += bb[(int64_t)q * C + c];
+        s_mean[c] = s / (float)hw;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float* aa = a + (int64_t)n * hw * C;
+    for (int p = wave; p < hw; p += nw) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(aa[(int64_t)p * C + c], s_mean[c], s);
+        s = xp_wave_sum(s);
+        if (lane == 0) v[(int64_t)n * hw + p] = s;
+    }
+}
+}  // namespace
+
+extern "C" int xp_costvolume_mean(const float* a, const float* b, float* v, int batch, int hw, int C, void* stream) {
+    XP_CHECK_ARG(a && b && v, "xp_costvolume_mean: null pointer");
+    XP_CHECK_ARG(batch > 0 && hw > 0 && C > 0 && C <= 8192, "xp_costvolume_mean: bad shape batch %d, hw %d, C %d", batch, hw, C);
+    XpProfScope prof("costvolume_mean", (hipStream_t)stream, 4.0 * batch * hw * (double)C, 4.0 * batch * hw * (2.0 * C + 1.0));
+    hipLaunchKernelGGL(costvolume_mean_kernel, dim3(batch), dim3(256), (size_t)C * sizeof(float), (hipStream_t)stream, a, b, v, hw, C);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
 extern "C" int xp_maxpool2_nhwc(const float* x, float* y, int batch, int H, int W, int C, void* stream) {
     XP_CHECK_ARG(x && y, "xp_maxpool2_nhwc: null pointer");
     const int64_t total = (int64_t)batch * (H / 2) * (W / 2) * C;

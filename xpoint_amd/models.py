@@ -586,7 +586,8 @@ class XPoint(torch.nn.Module):
                 raise NotImplementedError("only homography_regression_head.type 'RegNet' (XPoint-EXP1 params) is implemented")
             if self._regnet_w is None:
                 self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
-            pred_hm = regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:], adaptive_pool=self.regnet_adaptive_pool)
+            pred_hm = regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:], adaptive_pool=self.regnet_adaptive_pool,
+                                  enc_both=raw["enc_nhwc"] if raw["enc_nhwc"].shape[0] == 2 * B else None)
         return pred_optical, pred_thermal, pred_hm
 
     def predict_homography(self, optical, thermal):
@@ -601,4 +602,5 @@ class XPoint(torch.nn.Module):
         raw = self.forward_raw(torch.cat([optical, thermal], 0), want_prob=False, want_desc=False, is_optical=flags)
         if self._regnet_w is None:
             self._regnet_w = regnet_weights(self._ref_state, raw["enc_nhwc"].device)
-        return regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:], adaptive_pool=self.regnet_adaptive_pool)
+        return regnet_forward(self._regnet_w, raw["enc_nhwc"][:B], raw["enc_nhwc"][B:], adaptive_pool=self.regnet_adaptive_pool,
+                                  enc_both=raw["enc_nhwc"] if raw["enc_nhwc"].shape[0] == 2 * B else None)

@@ -21,6 +21,34 @@ def conv3x3(x, w_ohwi, bias=None, scale=None, shift=None, stride=1, reflect=Fals
     return y
 
 
+def split_h2(w_nk):
+    """Offline two-plane fp16 split of a weight matrix (N, K) for the split-fp16 dense engine (xp_split_weights_h2)."""
+    import ctypes
+    N, K = w_nk.shape
+    out = torch.empty(_lib.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device=w_nk.device)
+    _lib.call("xp_split_weights_h2", ptr(w_nk.contiguous()), ctypes.c_void_p(out.data_ptr()), N, K, _lib.current_stream())
+    return out
+
+
+def conv3x3_h2(x, w_split, Co, bias=None, scale=None, shift=None, stride=1, reflect=False, act="none"):
+    """conv3x3 on the split-fp16 engine (f32-grade, three fp16 MFMA products): w_split = split_h2(w_ohwi.view(Co, 9 * Ci))."""
+    import ctypes
+    B, H, W, Ci = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Ho, Wo, Co), device=x.device)
+    _lib.call("xp_conv3x3_nhwc_h2", ptr(x), ctypes.c_void_p(w_split.data_ptr()), ptr(y), ptr(bias), ptr(scale), ptr(shift), B, H, W, Ci, Co, stride,
+              int(bool(reflect)), ACT[act], _lib.current_stream())
+    return y
+
+
+def costvolume_mean(a_bhc, b_bhc):
+    """v[n][p] = a[n][p] . mean_q b[n][q]  (RegNet.py:44-52 cost volume + global average pool, without the volume)."""
+    B, hw, C = a_bhc.shape
+    v = torch.empty((B, hw), device=a_bhc.device)
+    _lib.call("xp_costvolume_mean", ptr(a_bhc), ptr(b_bhc), ptr(v), B, hw, C, _lib.current_stream())
+    return v
+
+
 def _rows_ptr(t):
     """Pointer of a 2-D view whose rows are contiguous (column slices of a wider matrix are fine: lda carries the stride)."""
     import ctypes
