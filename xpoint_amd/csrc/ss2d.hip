@@ -32,7 +32,7 @@
 #endif
 
 // L bound of the sequential (one wave per route) form, per image: see ss2d_core_impl
-#define XP_SS2D_SEQ_DEFAULT_MAXL 2048
+#define XP_SS2D_SEQ_DEFAULT_MAXL 8192
 
 namespace {
 
@@ -1043,7 +1043,8 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     // it chunked (bound 512); re-measured in round 4 in the three-stream step it is +1.6 % at 8 pairs per call (1 671-1 673 -> 1 698, three alternations), 0 at
     // 4, -0.9 % at 2 and -4.8 % at ONE pair per call (0.99 -> 1.03 ms per pair).  The bound is now 2 048 for every dt_rank >= 16 shape — the configurations
     // this path is measured on run >= 8 pairs per GPU; the wave-pipelined kernel (ss2d_seq_scan3) then removed the one-pair cost as well (965 -> 1 029 pairs/s,
-    // above the chunked form's 1 022).  xp_ss2d_core_set_mode / XP_SS2D_SEQ force one form.
+    // above the chunked form's 1 022), and the bound went to 8 192: stage 2 of a 1024 x 1024 image (L = 4 096) through the pipelined kernel is +2.4 % on
+    // config C4 at 4 pairs per call, +2 % at 2, +0.8 % at 1.  xp_ss2d_core_set_mode / XP_SS2D_SEQ force one form.
     const int mode = g_ss2d_mode.load();
     static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
     const bool seq2 = seq_scan2_applies(R, H, W, C);
