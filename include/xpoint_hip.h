@@ -89,6 +89,14 @@ int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* wdt, const 
                      const float* Ds, const float* ln_w, const float* ln_b, float* out, float* workspace,
                      size_t workspace_bytes, int batch, int H, int W, int C, int R, int dstate, float eps,
                      void* stream);
+/* The same core with a selectable output format: out_fmt 0 = f32 rows (identical to xp_ss2d_core_fwd), 2 = the P32 image of the (B H W, C) result
+ * (see xp_gemm_nt_h2s: the SS2D out_proj then loads it by DMA).  The P32 form exists where the sequential deep-stage form runs:
+ * xp_ss2d_core_p32_supported(H, W, C, R) != 0 (per-image quantities only); elsewhere out_fmt = 2 is an argument error. */
+int xp_ss2d_core_p32_supported(int H, int W, int C, int R);
+int xp_ss2d_core_fwd_ex(const float* u, const float* xdbl, const float* wdt, const float* dt_bias, const float* A,
+                        const float* Ds, const float* ln_w, const float* ln_b, void* out, int out_fmt, float* workspace,
+                        size_t workspace_bytes, int batch, int H, int W, int C, int R, int dstate, float eps,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers (nn.Linear / nn.Conv2d of VMamba.py:110-128,649,663,1405-1440 and XPoint.py:112-138).
@@ -135,6 +143,21 @@ int xp_gemm_nt_h2(const float* A, const void* Wh2, float* C, const float* bias, 
                   const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, void* stream);
 int xp_conv3x3_nhwc_h2(const float* x, const void* Wh2, float* y, const float* bias, const float* scale, const float* shift,
                        int batch, int Hi, int Wi, int Ci, int Co, int stride, int reflect_pad, int act, void* stream);
+/* The same GEMM on PRE-SPLIT activations (round 5; csrc/gemm_ring.hip, csrc/ring_core.h — the "ring" engine; same reference call sites as xp_gemm_nt_h2:
+ * VMamba.py:649,663 in/out_proj, :110-128 Mlp).  A is the "P32" image of an (M, K) f32 matrix: [m][k / 32][plane 0..1][32] fp16 with
+ * A[m][k] = plane0 + plane1 (the two-way split of csrc/gemm_h2_core.h) — 4 bytes per element, K % 32 == 0, xp_p32_bytes(M, K) bytes.  It is written
+ * by the PRODUCER of the tensor: xp_split_activations_h2 (from f32 rows), xp_layernorm_p32, xp_ss2d_core_fwd_ex(out_fmt = 2), or this GEMM itself
+ * (out_fmt = 2: C is the P32 image of the (M, N) result, N % 32 == 0, ldc == N).  out_fmt 0: C f32 rows (ldc).  Wh2: xp_split_weights_h2's buffer.
+ * Both operands reach the LDS by LDS-DMA and the K loop holds matrix instructions only; same partial products, same summation order and therefore the
+ * same bits as xp_gemm_nt_h2's tile kernel on A = plane0 + plane1.  N % 8 == 0; bias / scale / shift / res (f32, ldres) / act as xp_gemm_nt.
+ * xp_gemm_nt_h2s_applies(N, K): does xp_xpoint_forward route a layer of this shape here (a per-layer predicate: the producers of its input must know). */
+size_t xp_p32_bytes(int64_t M, int K);
+int xp_split_activations_h2(const float* x, void* out_p32, int64_t M, int K, int ldx, void* stream);
+int xp_gemm_nt_h2s_applies(int N, int K);
+int xp_gemm_nt_h2s(const void* A_p32, const void* Wh2, void* C, int out_fmt, const float* bias, const float* scale, const float* shift,
+                   const float* res, int M, int N, int K, int ldc, int ldres, int act, void* stream);
+/* LayerNorm (as xp_layernorm, gelu = 0) writing the P32 image of its (rows, C) result; C % 32 == 0. */
+int xp_layernorm_p32(const float* x, void* y_p32, const float* w, const float* b, int64_t rows, int C, float eps, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * fp16-STORAGE dense kernels of the fast mixed-precision class (csrc/gemm_f16.hip): the reference's `mixed_precision: true` deployment
  * (xpoint/models/XPoint.py:182 autocast) with half tensors in HBM.  A (M, lda) and W (N, K) are fp16, K-contiguous; one exact fp16 product per multiply on

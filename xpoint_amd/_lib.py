@@ -43,6 +43,10 @@ _SIGNATURES = {
     "xp_split_weights_h2": [c_p, c_p, c_i, c_i, c_p],
     "xp_gemm_nt_h2": [c_p] * 7 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc_h2": [c_p] * 6 + [c_i] * 8 + [c_p],
+    "xp_split_activations_h2": [c_p, c_p, c_l, c_i, c_i, c_p],
+    "xp_gemm_nt_h2s": [c_p, c_p, c_p, c_i] + [c_p] * 4 + [c_i] * 6 + [c_p],
+    "xp_layernorm_p32": [c_p] * 4 + [c_l, c_i, c_f, c_p],
+    "xp_ss2d_core_fwd_ex": [c_p] * 9 + [c_i, c_p, c_sz] + [c_i] * 6 + [c_f, c_p],
     "xp_f32_to_f16": [c_p, c_p, c_l, c_p],
     "xp_gemm_nt_f16": [c_p, c_p, c_p, c_i] + [c_p] * 4 + [c_i] * 7 + [c_p],
     "xp_conv3x3_nhwc_f16": [c_p, c_p, c_p, c_i] + [c_p] * 3 + [c_i] * 8 + [c_p],
@@ -109,6 +113,9 @@ _SIZE_QUERIES = {
     "xp_ss2d_core_workspace_bytes": (c_sz, [c_i] * 4),
     "xp_split_weights_x3_bytes": (c_sz, [c_i] * 2),
     "xp_split_weights_h2_bytes": (c_sz, [c_i] * 2),
+    "xp_p32_bytes": (c_sz, [c_l, c_i]),
+    "xp_gemm_nt_h2s_applies": (c_i, [c_i, c_i]),
+    "xp_ss2d_core_p32_supported": (c_i, [c_i] * 4),
     "xp_split_weights_bytes": (c_sz, [c_p]),
     "xp_f16_weights_bytes": (c_sz, [c_p]),
     "xp_mlp_fused_f16_supported": (c_i, [c_i, c_i]),

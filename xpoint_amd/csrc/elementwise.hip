@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Vectorised form for C % 4 == 0: LPR lanes (a power of two) share a row, each lane owns NV float4s, so a wave handles
 // 64/LPR rows per pass with 16-byte accesses (C = 96: two rows per wave, 24 of 32 lanes active, instead of one row on
 // 24 scalar lanes).  Same two-pass mean / variance.
-template <int LPR, int NV, int RPG = 1>
+// P32: y is the two-plane fp16 image [row][c / 32][plane][32] of the result (ring_core.h: the operand format of xp_gemm_nt_h2s) instead of f32 rows.
+template <int LPR, int NV, int RPG = 1, bool P32 = false>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             int64_t M, int C, float eps, int gelu) {
@@ -107,6 +108,15 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                 o.x = (v[r][i].x - mean) * rstd * wv.x + bv.x; o.y = (v[r][i].y - mean) * rstd * wv.y + bv.y;
                 o.z = (v[r][i].z - mean) * rstd * wv.z + bv.z; o.w = (v[r][i].w - mean) * rstd * wv.w + bv.w;
                 if (gelu) { o.x = xp_gelu(o.x); o.y = xp_gelu(o.y); o.z = xp_gelu(o.z); o.w = xp_gelu(o.w); }
+                if (P32) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    const h4 hi = {(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+                    const h4 lo = {(_Float16)(o.x - (float)hi[0]), (_Float16)(o.y - (float)hi[1]), (_Float16)(o.z - (float)hi[2]), (_Float16)(o.w - (float)hi[3])};
+                    const int c = c4 * 4;
+                    unsigned char* op = reinterpret_cast<unsigned char*>(y) + ((row0 + r * RPW) * (C >> 5) + (c >> 5)) * 128 + (c & 31) * 2;
+                    *reinterpret_cast<h4*>(op) = hi;
+                    *reinterpret_cast<h4*>(op + 64) = lo;
+                } else
                 yr[c4] = o;
             }
         }
@@ -505,6 +515,30 @@ static int layernorm_impl(const float* x, float* y, const float* w, const float*
     else if (C4 <= 192) XP_LN_LAUNCH(64, 3);
     else XP_LN_LAUNCH(64, 4);
 #undef XP_LN_LAUNCH
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+extern "C" int xp_layernorm_p32(const float* x, void* y_p32, const float* w, const float* b, int64_t rows, int C, float eps, void* stream) {
+    XP_CHECK_ARG(x && y_p32 && w && b, "xp_layernorm_p32: null pointer");
+    XP_CHECK_ARG(C >= 32 && C <= 1024 && C % 32 == 0, "xp_layernorm_p32: C must be a multiple of 32 in [32, 1024] (got %d)", C);
+    XP_CHECK_ARG((((uintptr_t)x | (uintptr_t)y_p32 | (uintptr_t)w | (uintptr_t)b) & 15) == 0, "xp_layernorm_p32: buffers must be 16-byte aligned");
+    XP_CHECK_ARG(!xp_amp_value(), "xp_layernorm_p32: no mixed-precision form (the P32 image feeds the f32-grade ring GEMM only)");
+    if (rows == 0) return XP_OK;
+    XpProfScope prof("layernorm_p32", (hipStream_t)stream, 8.0 * rows * C, 8.0 * rows * C);
+    hipStream_t s = (hipStream_t)stream;
+    float* y = reinterpret_cast<float*>(y_p32);
+    const int C4 = C / 4;
+    // the lane / row geometry of xp_layernorm for the same C: the statistics and the normalised values are the same bits, only the store differs
+#define XP_LNP_LAUNCH(LPR, NV) hipLaunchKernelGGL((layernorm_vec_kernel<LPR, NV, (NV == 1 ? 4 : 1), true>), dim3(xp_cdiv(rows, 4 * (64 / LPR) * (NV == 1 ? 4 : 1))), dim3(256), 0, s, x, y, w, b, rows, C, eps, 0)
+    if (C4 <= 8) XP_LNP_LAUNCH(8, 1);
+    else if (C4 <= 16) XP_LNP_LAUNCH(16, 1);
+    else if (C4 <= 32) XP_LNP_LAUNCH(32, 1);
+    else if (C4 <= 64) XP_LNP_LAUNCH(64, 1);
+    else if (C4 <= 128) XP_LNP_LAUNCH(64, 2);
+    else if (C4 <= 192) XP_LNP_LAUNCH(64, 3);
+    else XP_LNP_LAUNCH(64, 4);
+#undef XP_LNP_LAUNCH
     XP_LAUNCH_CHECK();
     return XP_OK;
 }

@@ -304,20 +304,31 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
         for (int j = 0; j < c->cfg.depths[s]; ++j) {
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)
-            if (fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
+            const bool fused_block = fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1;
+            // Stages 2 - 3 on the split-fp16 engine: the ring GEMM (csrc/gemm_ring.hip) takes its activation operand as a P32 image written by the producer
+            // (LayerNorm, the SS2D out_norm, fc1's epilogue), so its K loop is DMA + matrix instructions only.  Per-layer predicates (N, K): never the batch.
+            const bool ring_ok = wsplit && h2 && !amp && !fused_block;
+            const bool ring_in = ring_ok && xp_gemm_nt_h2s_applies(C, C);
+            const bool ring_out = ring_in && xp_ss2d_core_p32_supported(sh.H[s], sh.W[s], C, R);
+            const bool ring_mlp = ring_ok && xp_gemm_nt_h2s_applies(H4, C) && xp_gemm_nt_h2s_applies(C, H4);
+            const char* wb = (const char*)wsplit;
+            if (fused_block) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
                 const char* w = (const char*)wsplit;
                 if (h2 && !fused_x3) RUN(xp_ln_proj_h2(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->h2_pack_off(b, true), w + c->h2_off(b + "in_w"), T2, M, C, C, eps, stream));
                 else RUN(xp_ln_proj_x3(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->in_pack_off(b), T2, M, C, C, eps, stream));
+            } else if (ring_in) {
+                RUN(xp_layernorm_p32(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, stream));
+                RUN(xp_gemm_nt_h2s(T1, wb + c->h2_off(b + "in_w"), T2, 0, nullptr, nullptr, nullptr, nullptr, M, C, C, C, 0, 0, stream));
             } else {
                 RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
                 RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
             }
             RUN(xp_dwconv3x3_silu(T2, P(b + "dw_w"), T3, batch, sh.H[s], sh.W[s], C, stream));
             RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
-            RUN(xp_ss2d_core_fwd(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
-                                 T1, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
+            RUN(xp_ss2d_core_fwd_ex(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
+                                    T1, ring_out ? 2 : 0, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
             if (amp) RUN(xp_round_f16(T1, T1, (int64_t)M * C, stream));      // forward_corev2 returns y.to(x.dtype): out_norm's f32 result as a half tensor (VMamba.py:646)
-            if (fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1) {
+            if (fused_block) {
                 // out_proj + first residual + LN + MLP + second residual in one launch; the (M, 4C) hidden activation stays in
                 // registers (csrc/mlp_fused.hip)
                 const char* w = (const char*)wsplit;
@@ -326,8 +337,15 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
                 else RUN(xp_mlp_fused_x3(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), w + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"), M, C, H4, eps, stream));
                 continue;
             }
-            RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
+            if (ring_out) RUN(xp_gemm_nt_h2s(T1, wb + c->h2_off(b + "out_w"), X, 0, nullptr, nullptr, nullptr, X, M, C, C, C, C, 0, stream));
+            else RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
             // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
+            if (ring_mlp) {      // the hidden activation crosses HBM as the P32 image fc2 loads by DMA (same bytes as f32)
+                RUN(xp_layernorm_p32(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, stream));
+                RUN(xp_gemm_nt_h2s(T1, wb + c->h2_off(b + "fc1_w"), HB, 2, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, H4, 0, 1, stream));
+                RUN(xp_gemm_nt_h2s(HB, wb + c->h2_off(b + "fc2_w"), X, 0, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, C, C, 0, stream));
+                continue;
+            }
             RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
             RUN(gemm(T1, b + "fc1_w", HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
             RUN(gemm(HB, b + "fc2_w", X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));

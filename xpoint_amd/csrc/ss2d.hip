@@ -51,6 +51,7 @@ struct SS2DParams {
     float* wsS;          // same; pass 2 overwrites S with the chunk start state
     float* ya;           // (B, H, W, C) row-pair partial
     float* out;          // (B, H, W, C)
+    int out_p32;         // sequential form only: out is the P32 image [row][c / 32][plane][32] of the result (ring_core.h), not f32 rows
     int Bn, H, W, C, T, nc, cpb;
     float eps;
 };
@@ -865,6 +866,21 @@ __global__ __launch_bounds__(256) void ss2d_seq_merge_ln(SS2DParams p, const flo
 #pragma unroll
     for (int q = 0; q < 12; ++q) if (q * 64 + lane < p.C) { const float dd = v[q] - mean; q2 = fmaf(dd, dd, q2); }
     const float rstd = 1.f / sqrtf(xp_wave_sum(q2) / (float)p.C + p.eps);
+    if (std::is_same<OT, float>::value && p.out_p32) {
+        // the two-plane image the ring GEMM (out_proj) loads by DMA: lane pairs own adjacent channels, so a wave stores whole 64-byte plane segments
+        _Float16* prow = reinterpret_cast<_Float16*>(p.out) + row * p.C * 2;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int cc = q * 64 + lane;
+            if (cc < p.C) {
+                const float o = (v[q] - mean) * rstd * p.ln_w[cc] + p.ln_b[cc];
+                const _Float16 hi = (_Float16)o, lo = (_Float16)(o - (float)hi);
+                _Float16* d = prow + (cc >> 5) * 64 + (cc & 31);
+                d[0] = hi; d[32] = lo;
+            }
+        }
+        return;
+    }
     OT* orow = reinterpret_cast<OT*>(p.out) + row * p.C;
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
@@ -995,7 +1011,7 @@ extern "C" size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C) {
 static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, const float* xdbl32, const float* wdt, const float* dt_bias,
                           const float* A, const float* Ds, const float* ln_w, const float* ln_b, void* out,
                           float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
-                          int dstate, float eps, bool half_io, void* stream) {
+                          int dstate, float eps, bool half_io, void* stream, int out_p32 = 0) {
     const char* who = half_io ? "xp_ss2d_core_fwd_f16" : "xp_ss2d_core_fwd";
     XP_CHECK_ARG(u && xdbl && wdt && dt_bias && A && Ds && ln_w && ln_b && out && workspace, "%s: null pointer", who);
     XP_CHECK_ARG(dstate == 1, "%s: only d_state == 1 (the XPoint config) is implemented in the fused core; "
@@ -1006,7 +1022,7 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     XP_CHECK_ARG((int64_t)H * W * C < (1ll << 31), "%s: one image plane (H*W*C) must stay below 2^31 elements", who);
     SS2DParams p;
     p.u = (const float*)u; p.xdbl = (const float*)xdbl; p.wdt = wdt; p.dtb = dt_bias; p.A = A; p.Dp = Ds; p.ln_w = ln_w; p.ln_b = ln_b;
-    p.out = (float*)out; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
+    p.out = (float*)out; p.out_p32 = out_p32; p.Bn = batch; p.H = H; p.W = W; p.C = C; p.eps = eps;
     // threads = cpb * C must be a multiple of 64 and <= 768
     int cpb = 1;
     static const int blk_threads = getenv("XP_SS2D_THREADS") ? atoi(getenv("XP_SS2D_THREADS")) : 192;      // experiments: threads per workgroup of the chunked passes
@@ -1052,6 +1068,7 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     //  sequential form when the caller supplied f32 copies of u and xdbl — xp_ss2d_core_f16_wants_f32_copies says when it will)
     bool seq = (!half_io && xp_amp_value()) ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL)));
     if (half_io && !(seq2 && u32 && xdbl32)) seq = false;
+    XP_CHECK_ARG(!out_p32 || (seq && C <= 768 && C % 64 == 0 && !half_io), "%s: a P32 output exists for the sequential form only (xp_ss2d_core_p32_supported)", who);
     if (seq && C <= 768 && C % 64 == 0) {
         if (half_io) { p.u = u32; p.xdbl = xdbl32; }
         switch (R) {
@@ -1084,6 +1101,23 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
                                 float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
                                 int dstate, float eps, void* stream) {
     return ss2d_core_impl(u, xdbl, nullptr, nullptr, wdt, dt_bias, A, Ds, ln_w, ln_b, out, workspace, workspace_bytes, batch, H, W, C, R, dstate, eps, false, stream);
+}
+
+// out_fmt 0: f32 rows (= xp_ss2d_core_fwd); 2: the P32 image of the result (the operand format of xp_gemm_nt_h2s: out_proj loads it by DMA) — only where the
+// sequential form runs (xp_ss2d_core_p32_supported, a per-image predicate)
+extern "C" int xp_ss2d_core_p32_supported(int H, int W, int C, int R) {
+    const int mode = g_ss2d_mode.load();
+    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
+    if (xp_amp_value() || !(C <= 768 && C % 64 == 0)) return 0;
+    switch (R) { case 2: case 4: case 6: case 8: case 12: case 16: case 24: case 48: break; default: return 0; }
+    return mode >= 0 ? (mode != 0) : (seq_scan2_applies(R, H, W, C) && H * W <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL));
+}
+extern "C" int xp_ss2d_core_fwd_ex(const float* u, const float* xdbl, const float* wdt, const float* dt_bias,
+                                   const float* A, const float* Ds, const float* ln_w, const float* ln_b, void* out, int out_fmt,
+                                   float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
+                                   int dstate, float eps, void* stream) {
+    XP_CHECK_ARG(out_fmt == 0 || out_fmt == 2, "xp_ss2d_core_fwd_ex: out_fmt must be 0 (f32 rows) or 2 (P32 image)");
+    return ss2d_core_impl(u, xdbl, nullptr, nullptr, wdt, dt_bias, A, Ds, ln_w, ln_b, out, workspace, workspace_bytes, batch, H, W, C, R, dstate, eps, false, stream, out_fmt == 2);
 }
 
 // Would xp_ss2d_core_fwd_f16 take the sequential (deep-stage) form for this per-image shape if it is given f32 copies of u and xdbl?  (A per-image
