@@ -191,8 +191,8 @@ def test_ss2d_core_p32_output_matches_f32_bits(gpu_lib, B, H, W, C, R):
 @pytest.mark.parametrize("M,N,K,act,res,c_f32", [(19200, 384, 384, 0, False, 0), (2500, 1536, 384, 1, False, 0), (2400, 384, 1536, 0, True, 0),
                                                  (4800, 768, 768, 0, True, 0), (1000, 3072, 768, 1, False, 0), (777, 384, 448, 0, False, 1)])
 def test_gemm_f16_ring_instance_bits(gpu_lib, M, N, K, act, res, c_f32):
-    """xp_gemm_nt_f16 routes K >= 384, N >= 384 to the ring engine: same fp16 products, same slab / k-step order, same rounding points as the tile kernel
-    (XP_F16_TILE forces the tile kernel: run in a child process, the knob is read once) — here: against the rounding recipe evaluated in float64"""
+    """xp_gemm_nt_f16 on the long-K layers (the ring instance with XP_RING_F16=1, else the round-4 tile kernel: same fp16 products, same slab / k-step
+    order, same rounding points — the next test compares their bits) against the rounding recipe evaluated in float64"""
     L = _lib()
     A = _u(f"fA{M}{N}{K}", (M, K)).half(); Wt = _u(f"fW{M}{N}{K}", (N, K), -0.1, 0.1).half(); bias = _u(f"fb{M}{N}{K}", (N,))
     R = _u(f"fr{M}{N}{K}", (M, N)).half() if res else None
@@ -218,7 +218,7 @@ def test_gemm_f16_ring_instance_bits(gpu_lib, M, N, K, act, res, c_f32):
 
 
 def test_gemm_f16_ring_vs_tile_kernel_bits(gpu_lib):
-    """the ring instance and the round-4 tile kernel produce the same bits (child process with XP_RING=0 computes the tile kernel's CRC)"""
+    """the ring instance (XP_RING_F16=1, read once: child processes) and the round-4 tile kernel produce the same bits"""
     import subprocess, sys
     code = (
         "import ctypes, torch, zlib\n"
@@ -231,7 +231,7 @@ def test_gemm_f16_ring_vs_tile_kernel_bits(gpu_lib):
         "torch.cuda.synchronize(); print('CRC', zlib.crc32(C.cpu().numpy().tobytes()))\n")
     crcs = []
     for ring in ("1", "0"):
-        env = dict(os.environ, XP_RING=ring)
+        env = dict(os.environ, XP_RING_F16=ring)
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert out.returncode == 0, out.stderr[-2000:]
         crcs.append([l for l in out.stdout.splitlines() if l.startswith("CRC")][-1])

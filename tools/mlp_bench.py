@@ -43,6 +43,11 @@ for (M, C, H4) in shapes:
         L.call("xp_layernorm", L.ptr(X), L.ptr(T), L.ptr(lw), L.ptr(lb), M, C, 1e-5, 0, st)
         L.call(f"xp_gemm_nt_{ENG}", L.ptr(T), p1, L.ptr(Hb), L.ptr(b1), None, None, None, M, H4, C, C, H4, 0, 1, st)
         L.call(f"xp_gemm_nt_{ENG}", L.ptr(Hb), p2, L.ptr(X), L.ptr(b2), None, None, L.ptr(X), M, C, H4, H4, C, C, 0, st)
+    if os.environ.get("MLP_CRC") == "1":      # one call on fresh inputs: CRC of the updated rows (schedule A/Bs must not change a bit)
+        import zlib
+        X0 = X.clone(); fused(); torch.cuda.synchronize()
+        print(f"CRC M {M} C {C}: {zlib.crc32(X.cpu().numpy().tobytes()):08x}  finite {bool(torch.isfinite(X).all())}", flush=True)
+        X.copy_(X0)
     tf = timeit(fused); t3 = tf if FUSED_ONLY else timeit(three)
     fl = 4.0 * M * C * H4 + (2.0 * M * C * C if PROJ else 0.0)
     print(f"M {M:7d} C {C:4d} H {H4:5d}: fused {tf*1e3:8.1f} us {fl/tf/1e9:7.1f} TF/s | separate launches {t3*1e3:8.1f} us {fl/t3/1e9:7.1f} TF/s | x{t3/tf:.2f}", flush=True)

@@ -125,9 +125,13 @@ extern "C" int xp_gemm_nt_h2s(const void* A_p32, const void* Wh2, void* C, int o
     return XP_OK;
 }
 
-// one-product fp16 instance for xp_gemm_nt_f16 (gemm_f16.hip): long-K layers of the deep stages
+// one-product fp16 instance for xp_gemm_nt_f16 (gemm_f16.hip): long-K layers of the deep stages.  OFF by default (XP_RING_F16=1 turns it on): alone it
+// is 5 - 14 % faster than the 4-wave tile kernel on these layers (profiles/r5_ring_microbench.txt), but in the three-stream step its 144 KB of LDS and 8 waves
+// per CU leave no room for the other encoders' kernels and the fast class ran 2 454 -> 2 382 pairs/s on one box (profiles/r5_ring_instep_ab.txt); the
+// split class keeps it (+1.0 %: its tile kernels are the slower ones).  Same bits either way.
 bool xp_ring_f16_applies(int M, int N, int K, int lda, int ldc, int ldres, int c_f32, bool has_res) {
-    return ring_enabled() && K % 64 == 0 && K >= 384 && N % 8 == 0 && N >= 384 && lda % 8 == 0 && ldc % (c_f32 ? 4 : 8) == 0 && (!has_res || ldres % 8 == 0) &&
+    static const int on16 = getenv("XP_RING_F16") ? atoi(getenv("XP_RING_F16")) : 0;
+    return on16 && ring_enabled() && K % 64 == 0 && K >= 384 && N % 8 == 0 && N >= 384 && lda % 8 == 0 && ldc % (c_f32 ? 4 : 8) == 0 && (!has_res || ldres % 8 == 0) &&
            (int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * K * 2 < (1ll << 32);
 }
 

@@ -43,6 +43,13 @@
 #define XP_MLP_DBG 0   /* timing experiments only (wrong results): 1 no GELU, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no bf16 split of the hidden values, 16 no MFMA */
 #endif
 
+#if XP_MLP_DBG & 64
+__device__ unsigned long long g_mlp_stamps[8][512];      // debug build only: s_memtime at every ping-pong barrier entry / exit of the waves of workgroup 0
+extern "C" int xp_mlp_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 8 * 512) == hipSuccess ? 0 : -2;
+}
+#endif
+
 namespace {
 
 struct MlpParams {
@@ -171,9 +178,11 @@ __device__ __forceinline__ void mlp_split2(float x, float y, unsigned& p0, unsig
     } else xp_split2(x, y, p0, p1, p2);
 }
 
-template <int C, int NW, int MODE, int NP, bool H2>
+// PP (round 5, split-fp16 instances with 8 waves): the "ping-pong" schedule of the MLP chunk loop — see the loop itself.
+template <int C, int NW, int MODE, int NP, bool H2, bool PP = false>
 __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void mlp_fused_kernel(MlpParams p) {      // h2: two waves per SIMD at every C (two planes resident)
     static_assert(NP == 6 || NP == 3 || NP == 1, "partial products per multiply (gemm_x3_core.h)");
+    static_assert(!PP || (H2 && NW == 8 && MODE != 2), "the ping-pong schedule: split-fp16 MLP instances with two waves per SIMD in ONE workgroup");
     static_assert(!H2 || NP == 3, "the split-fp16 engine always forms its three products");
     constexpr bool PRE = MODE == 1, PROJ_ONLY = MODE == 2;
     using T = MlpTile<C, H2>;
@@ -297,6 +306,20 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
             iv[8 * j + 4] = hi.x; iv[8 * j + 5] = hi.y; iv[8 * j + 6] = hi.z; iv[8 * j + 7] = hi.w;
         }
     };
+    // PP: the same 16 floats by inline-asm LDS reads.  hipcc guards an ordinary ds_read of these arrays with s_waitcnt vmcnt(0) whenever an LDS-DMA is in
+    // flight (it cannot tell the bias region from the image ring: one __shared__ array, and it must be one — cdna_hip_programming.md §5 trap (a)); in the
+    // lockstep loop that wait was placed ahead of the phase's DMA issue, in the ping-pong loop an image is ALWAYS in flight and the wait would put the whole
+    // DMA latency into every phase.  An asm load is invisible to that pass; its own completion is waited for right here.
+    auto lds_read16_asm = [&](const unsigned char* base, int c, float (&v)[16]) {
+        typedef __attribute__((address_space(3))) const unsigned char* lds_cptr;
+        const unsigned addr = (unsigned)(size_t)(lds_cptr)(base + (32 * c + 8 * g) * 4);
+        float4 q0, q1, q2, q3;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w; v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
+    };
     float inv_cur[16];                     // h2: scales of the chunk whose GELU is being evaluated
     // 8 consecutive inverse row scales of a projection's output columns col0 .. col0 + 7 (h2; the x3 planes are unscaled)
     auto load_inv8 = [&](const float* sc, int col0, float (&iv)[8]) {
@@ -320,10 +343,17 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     // The DMA pieces of image n + 2 are issued BETWEEN the MFMA groups of phase n (one piece per k slab / output step), not in one
     // burst at its start: a few per cent faster (363 vs 375 us at C = 192) — an LDS-DMA issued among MFMAs costs less than one issued
     // next to other pieces and fragment reads.
+    int sp_img = -2, sp_slot = 0;                  // PP chunk loop: the image (and its ring slot) whose pieces the current MFMA phase issues; -1: none; -2: not in that loop
     auto spread = [&](int step, int nsteps) {      // called after MFMA group `step` of `nsteps`: the pieces due by then
         if (XP_MLP_DBG & 2) return;
+        if (PP && sp_img != -2) {
+            if (sp_img < 0) return;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(n + 2, slot == 0 ? 2 : slot - 1, i);
+            for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(sp_img, sp_slot, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(n + 2, slot == 0 ? 2 : slot - 1, i);
+        }
     };
     // VALU slices placed between MFMAs.  Slices 0..15: GELU of element r in place; 16..19 / 20..23: bf16 split of pair q of half 0 / 1.
     auto slice = [&](int k, f32x16& h) {
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
             for (int pp = 6 - NP; pp < 6; ++pp) {
                 if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i & 1][0][0]); }
                 else oacc[t] = mlp_mfma<H2>(hfrag(j, PA[pp]), b[i & 1][PB[pp]], oacc[t]);
-                if (i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once
+                if (!PP && i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once (PP: done in the V phase)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (NP >= 4 ? q == pp - (6 - NP) : true) slice(20 + q, cur);
                 }
@@ -456,10 +486,12 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     // phase 0 of the MLP: fc1 of chunk 0
     // (the bias reads come BEFORE the phase's DMA issue: hipcc guards these ds_reads — not the fragment reads — with s_waitcnt vmcnt(0),
     // which after the issue would wait for the image that was just requested; before it, it waits for one requested a phase ago)
-    load_bias(0, h0);
-    __builtin_amdgcn_sched_barrier(0);
-    fc1(slot, h0, h1, std::integral_constant<int, 0>{});
-    end_phase();
+    if constexpr (!PP) {
+        load_bias(0, h0);
+        __builtin_amdgcn_sched_barrier(0);
+        fc1(slot, h0, h1, std::integral_constant<int, 0>{});
+        end_phase();
+    }
     // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
     //          phase B = fc2(c) (image 2 + 2c)
     auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
@@ -472,7 +504,73 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         end_phase();
     };
     int c = 0;
-    if constexpr (H2) {
+    if constexpr (PP) {
+        // Ping-pong schedule of the chunk loop (round 5).  Per chunk a wave runs THREE phases of about equal length — F1 = fc1's matrix instructions (+ their
+        // fragment reads), V = GELU + split on the vector ALU, F2 = fc2's matrix instructions — and the stage-removal timings of the lockstep loop above
+        // (profiles/r5_mlp_h2_stage_removal.txt: no-MFMA build 124 of 274 us, no-GELU-no-split 197) are the SUM of the three: with every wave of the workgroup
+        // between the same two barriers, the two waves of a SIMD want the matrix pipe together and the vector ALU together.  Here waves 4 - 7 (the second wave
+        // of every SIMD) run ONE PHASE BEHIND waves 0 - 3, a barrier after every phase: slot k pairs (F1, F2'), (V, F1'), (F2, V') — the partner's V always
+        // sits under a matrix phase, and only the (F1, F2') slot has both on the pipe, which is then simply full.  Same instructions per wave in the same
+        // order as the loop above: bit-identical results.
+        //   Weight images: image k = W1(k / 2) (k even) / W2(k / 2) (k odd) lives in ring slot (k mod 3); group 0 reads it one slot before group 1, so an
+        //   image occupies its slot for two slots of time and ONE image is in flight: group 0 issues image 2c + 2 at the start of V(c) and 2c + 3 inside F2(c),
+        //   group 1 issues 2c + 2 inside F1(c) and 2c + 3 at the start of V(c) — always into the slot whose last reader (group 1) passed a barrier since —
+        //   and every wave retires its pieces with vmcnt(NI) one barrier before the image's first reader (group 0) starts.
+        const int grp = wave >> 2;
+        const int n0i = n, slot0 = slot;                                   // image index / ring slot of W1(0) on entry (landed; W2(0) issued)
+        auto ring_slot = [&](int k) { return (slot0 + k) % 3; };           // ring slot of MLP image k (k = 0: W1(0))
+        int n_stamp = 0;
+        auto stamp = [&]() {
+#if XP_MLP_DBG & 64
+            if (blockIdx.x == 0 && lane == 0 && n_stamp < 512) g_mlp_stamps[wave][n_stamp] = __builtin_amdgcn_s_memtime();
+            ++n_stamp;
+#endif
+        };
+        auto pp_barrier = [&]() {
+            stamp();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(XP_MLP_DBG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+        };
+        auto pp_wait = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory"); };
+        if (grp == 1) pp_barrier();
+        for (c = 0; c < NC; ++c) {
+            // ---- F1(c)
+            {
+                float bv[16];
+                lds_read16_asm(bias_lds, c, bv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h0[r] = bv[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sp_img = grp == 1 ? n0i + 2 * c + 2 : -1; sp_slot = ring_slot(2 * c + 2);
+            slot = ring_slot(2 * c);
+            fc1(slot, h0, h0, std::integral_constant<int, 0>{});
+            if (grp == 1) pp_wait();                                       // image 2c + 1 has landed (2c + 2 in flight)
+            pp_barrier();
+            // ---- V(c)
+            if (!(XP_MLP_DBG & 2)) issue_image(n0i + 2 * c + 2 + grp, ring_slot(2 * c + 2 + grp));
+            lds_read16_asm(inv1_lds, c, inv_cur);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) slice(k, h0);
+            // pin the phase's results HERE: hipcc otherwise sinks the whole GELU + split past the barrier to its consumer, fc2 (register-only instructions are
+            // not ordered by an asm memory clobber: cdna_hip_programming.md rule 18), and the phase it was meant to fill stays empty (stamps: V 366 cycles, F2 2 229)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hp[j][0][q]), "+v"(hp[j][1][q]));
+            pp_wait();                                                     // group 0: image 2c + 1 landed; group 1: image 2c + 2
+            pp_barrier();
+            // ---- F2(c)
+            sp_img = grp == 0 ? n0i + 2 * c + 3 : -1; sp_slot = ring_slot(2 * c + 3);
+            slot = ring_slot(2 * c + 1);
+            fc2(slot, h0);
+            if (grp == 0) pp_wait();                                       // image 2c + 2 has landed (2c + 3 in flight)
+            if (grp == 0 || c + 1 < NC) pp_barrier();
+        }
+        c = NC;
+    } else if constexpr (H2) {
         // split-fp16 instances: ONE hidden accumulator, chunk after chunk — fc1(c), GELU + split, fc2(c) — over a stream packed in that
         // order.  The x3 schedule below (fc1 of chunk c+1 with the GELU of chunk c between its MFMAs, two accumulator sets) spills 149
         // registers at C = 192 with two planes resident and eight waves (8 here); measured 314 -> 272 us at C = 192, 278 -> 266 us at C = 96.
@@ -486,6 +584,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         }
         c = NC;
     }
+    if constexpr (!H2)
     for (; c + 2 < NC; c += 2) { iter(c, h0, h1); iter(c + 1, h1, h0); }
     auto tail = [&](f32x16& cur) {         // last chunk: nothing left to overlap the GELU with; image 2 NC - 1
         if constexpr (H2) load_inv1(NC - 1, inv_cur);
@@ -523,14 +622,14 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-template <int C, int NW, int MODE, int NP, bool H2 = false>
+template <int C, int NW, int MODE, int NP, bool H2 = false, bool PP = false>
 int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     constexpr bool PRE = MODE == 1;
     using T = MlpTile<C, H2>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4 * (H2 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2, PP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   3 * T::IMGP + 4096 * 4 * (H2 ? 2 : 1));
         attr_set = true;
     }
@@ -542,7 +641,7 @@ int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
     XpProfScope prof(tag.c_str(), s, MODE == 2 ? 2.0 * p.M * C * (double)p.Nout : 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
                      MODE == 2 ? 4.0 * p.M * (C + (double)p.Nout) + 6.0 * C * (double)p.Nout : (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP, H2>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP, H2, PP>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -552,6 +651,15 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     // split-fp16 instances (scales present).  C = 192: one 8-wave workgroup per CU (its three 32 KB image slots leave no room for a
     // second one) puts two waves on every SIMD; the narrower ones run two 4-wave workgroups per CU.
     static const bool nw4 = getenv("XP_MLP_H2_NW4") != nullptr && atoi(getenv("XP_MLP_H2_NW4")) != 0;      // A/B: 0.716 (8 waves) vs 0.747 ms (4 waves) per two launches
+    // round 5: the ping-pong chunk loop (8-wave workgroups, the two waves of a SIMD one phase apart) for the MLP instances at C = 96 and C = 192; XP_MLP_PP=0: the
+    // lockstep loop (A/B).  Bit-identical results (tests/test_gpu_h2.py::test_mlp_fused_h2_pingpong_bits).
+    // OFF by default (XP_MLP_PP = 1: C = 192, 2: also C = 96).  Measured (profiles/r5_mlp_pingpong.txt): bit-identical, C = 192 246 - 258 vs 253 - 267 us alone,
+    // C = 96 293 - 304 vs 261 - 279 us (its 4-wave workgroups run three per CU; the 8-wave ping-pong workgroup runs alone), and the step does not move (1 709 - 1 715
+    // vs 1 702 - 1 712 pairs/s on one box): every phase of a wave is latency-, not throughput-bound (stamps: F1 1 250 cycles for 576 of matrix pipe, V 1 950 for
+    // ~1 000 of vector issue), so pairing phases of two waves hides less than a third wave per SIMD does.
+    static const int pp_mode = getenv("XP_MLP_PP") ? atoi(getenv("XP_MLP_PP")) : 0;
+    const bool pp_on = pp_mode >= (C == 192 ? 1 : 2);
+    constexpr bool PPOK = MODE != 2 && (C == 96 || C == 192);
     if (p.s2 || (MODE == 2 && p.s0)) {
         if (C == 192 && !nw4) {
             // One 256-row workgroup per CU: M = 76 800 rows (16 images of 480 x 640 at stage 1) is 300 workgroups = one full round of the chip + 44 workgroups
@@ -565,6 +673,10 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
                 n_cu = v;
             }
+            auto main_launch = [&](const MlpParams& q) {
+                if constexpr (PPOK) { if (pp_on) return launch_mlp_np<C, 8, MODE, 3, true, true>(q, s); }
+                return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(q, s);
+            };
             const int round_rows = n_cu * 256;
             const int rem = p.M % round_rows;
             if (tail_split && p.M > round_rows && rem > 0 && rem <= round_rows / 2) {
@@ -574,11 +686,12 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
                 b.X = p.X + (int64_t)a.M * C;
                 if (p.T1) b.T1 = p.T1 + (int64_t)a.M * C;
                 if (p.Out) b.Out = p.Out + (int64_t)a.M * p.Nout;
-                const int rc = launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(a, s);
+                const int rc = main_launch(a);
                 return rc != XP_OK ? rc : launch_mlp_np<C, 4, MODE, 3, true>(b, s);
             }
-            return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(p, s);
+            return main_launch(p);
         }
+        if constexpr (PPOK && C == 96) { if (pp_on) return launch_mlp_np<C, 8, MODE, 3, true, true>(p, s); }
         return launch_mlp_np<C, 4, MODE, 3, true>(p, s);
     }
     switch (xp_dense_products_value()) {      // precision class of the dense kernels (xp_set_dense_products)
