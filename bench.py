@@ -413,10 +413,10 @@ def main():
 
                 def step():
                     bufs, ev, hm_host, hm_ev = sstep(pin_o, pin_t, mo, mt)
-                    if pending:
-                        pev, phm = pending[-1]
-                        pev.synchronize(); phm.synchronize()              # results of the step before are on the host
                     pending.append((ev, hm_ev))
+                    if len(pending) >= pipe.depth:                        # the oldest step in flight is on the host; depth - 1 newer ones keep the GPU busy
+                        pev, phm = pending.pop(0)
+                        pev.synchronize(); phm.synchronize()
             else:
                 replay = pipe.capture(opt, thr, mo, mt)
                 step = lambda: replay(opt, thr, mo, mt)
@@ -553,24 +553,56 @@ def main():
     hygiene["match_stats_note"] = (f"nomination lists of the last step's matcher call over {ms['rows']} live rows + columns (inline capacity {ms['inline_capacity']}; longer lists "
                                    "go through the parallel overflow pass): the matcher's time depends on them, its result never does")
     pcie = None
+    pcie_u8 = None
     if not args.no_h2d and args.config == "c2":
+        import collections
         ho, ht = opt.cpu().pin_memory(), thr.cpu().pin_memory()
-        with torch.no_grad():
-            for _ in range(3):                                                 # untimed: the first download_async() calls allocate their pinned host buffers (two sets) —
-                pipe.run(ho, ht, mo, mt)                                       # with the rank's CPU mask narrowed that allocation took ~0.3 s and sat inside this region
-                bufs, ev = pipe.download_async()                               # (PCIe-inclusive 1 455 -> 780 pairs/s for a 0.5 s region; the copies themselves run at
-                ev.synchronize()                                               # 52 GB/s either way: tools/h2d_affinity_probe.py, tools/pcie_affinity_probe.py)
-            sync_all()
-            t1 = time.perf_counter()
-            prev = None
-            for _ in range(args.steps):
-                pipe.run(ho, ht, mo, mt)                                       # pinned host images uploaded straight into the batch buffers
-                bufs, ev = pipe.download_async()                               # counts, keypoints, match lists -> pinned host buffers behind the step
-                if prev is not None:
-                    prev.synchronize()                                         # the step before is on the host while this one runs
-                prev = ev
-            sync_all()
-            pcie = world * B * args.steps / (time.perf_counter() - t1)
+        # the same images as 8-bit gray (what a camera / decoder delivers): a quarter of the upload; gray / 255 happens on the device (xp_u8_to_unit_f32)
+        ho8, ht8 = (opt * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().pin_memory(), (thr * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().pin_memory()
+
+        def stream_region(a, b):
+            """K steps fed from pinned host memory with the result lists downloaded behind every step; the host keeps `pipe.depth` steps in flight
+            (it waits for step i - depth + 1's download before it enqueues step i + 1: the pinned result buffers rotate over depth + 1 sets)"""
+            with torch.no_grad():
+                for _ in range(pipe.depth + 2):                                # untimed: the first download_async() calls allocate their pinned host buffers —
+                    pipe.run(a, b, mo, mt)                                     # with the rank's CPU mask narrowed that allocation took ~0.3 s and sat inside this region
+                    bufs, ev = pipe.download_async()                           # (PCIe-inclusive 1 455 -> 780 pairs/s for a 0.5 s region; the copies themselves run at
+                    ev.synchronize()                                           # 52 GB/s either way: tools/h2d_affinity_probe.py, tools/pcie_affinity_probe.py)
+                sync_all()
+                t1 = time.perf_counter()
+                pend = collections.deque()
+                for _ in range(args.steps):
+                    pipe.run(a, b, mo, mt)                                     # pinned host images uploaded straight into the batch buffers
+                    bufs, ev = pipe.download_async()                           # counts, keypoints, match lists -> pinned host buffers behind the step
+                    pend.append(ev)
+                    if len(pend) >= pipe.depth:
+                        pend.popleft().synchronize()                           # the oldest step in flight is on the host; depth - 1 newer ones keep the GPU busy
+                sync_all()
+                return world * B * args.steps / (time.perf_counter() - t1)
+        pcie = stream_region(ho, ht)
+        pcie_u8 = stream_region(ho8, ht8)
+        if os.environ.get("XP_BENCH_PCIE_PARTS"):      # diagnosis only: which half of the streaming loop costs what (stderr)
+            def region_parts(a, b, dl):
+                with torch.no_grad():
+                    for _ in range(4):
+                        pipe.run(a, b, mo, mt)
+                        if dl:
+                            pipe.download_async()[1].synchronize()
+                    sync_all()
+                    t1 = time.perf_counter()
+                    pend = collections.deque()
+                    for _ in range(args.steps):
+                        pipe.run(a, b, mo, mt)
+                        if dl:
+                            pend.append(pipe.download_async()[1])
+                            if len(pend) >= pipe.depth:
+                                pend.popleft().synchronize()
+                    sync_all()
+                    return world * B * args.steps / (time.perf_counter() - t1)
+            sys.stderr.write("pcie parts: resident, no download %.1f | resident + download %.1f | host f32, no download %.1f | host u8, no download %.1f | host f32 + download %.1f\n" % (
+                region_parts(opt, thr, False), region_parts(opt, thr, True), region_parts(ho, ht, False), region_parts(ho8, ht8, False), region_parts(ho, ht, True)))
+        pipe.run(opt, thr, mo, mt)                                             # leave the buffers holding the headline inputs' results
+        torch.cuda.synchronize()
     res = pipe.fetch()
     per_rank = xdist.gather_floats(region_dt, device=dev) if dist.is_initialized() else [region_dt]
     # region r of the job = its slowest rank; the reported region = the median one
@@ -725,6 +757,7 @@ def main():
                 "pairs_per_s": {k: round(v, 2) for k, v in class_rates.items()}}
         if pcie is not None:
             out["pcie_inclusive_pairs_per_s"] = round(pcie, 2)
+            out["pcie_inclusive_u8_pairs_per_s"] = round(pcie_u8, 2)
         if not args.no_cpu_baseline and world == 1:
             try:
                 if pin.get("applied"):

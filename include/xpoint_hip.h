@@ -301,6 +301,13 @@ int xp_costvolume_mean(const float* a, const float* b, float* v, int batch, int 
  * fixed-point BGR2GRAY), lut256[k] = float32(k / 255.0) supplied by the host (double-precision division as numpy's). */
 int xp_ingest_u8(const uint8_t* src, int H0, int W0, int channels, int top, int left, int h, int w,
                  const float* lut256, float* dst, void* stream);
+/* dst[i] = (float)src[i] / 255 for a batch of 8-bit gray images already cropped (n elements): the device half of an 8-bit upload — the reference loader's
+ * `astype(float32) / 255` (xpoint/datasets/ImagePairDataset.py:254-274), same IEEE division, same bits.  src 4-byte, dst 16-byte aligned. */
+int xp_u8_to_unit_f32(const uint8_t* src, float* dst, int64_t n, void* stream);
+/* Copy `bytes` from device memory to PINNED (device-mapped: hipHostMalloc / torch pin_memory) host memory with a kernel on `stream` instead of a copy
+ * engine: small result lists of a streaming step, so that they never queue in front of the next step's image upload (predict.PairPipeline.download_async).
+ * Valid on the host once an event recorded on `stream` after the call has completed.  16-byte aligned pointers. */
+int xp_copy_to_mapped_host(const void* src_dev, void* dst_host, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Model forward.  Replaces xpoint.models.XPoint.forward_impl (xpoint/models/XPoint.py:283-323) with the

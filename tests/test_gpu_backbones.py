@@ -107,6 +107,41 @@ def test_regnet_head_256(gpu_lib, golden):
         regnet_forward(w, torch.zeros(1, 60, 80, 48, device="cuda"), torch.zeros(1, 60, 80, 48, device="cuda"))
 
 
+def test_regnet_head_large_activations_stay_finite(gpu_lib, golden):
+    """the head's second convolution sees ReLU(BN(c1(x))), which is unbounded.  With BatchNorm scales that push it past fp16's range (65504) the
+    split-fp16 engine would turn the rows into NaN and the following ReLU / max-pool would hide them as zeros; the layer runs on the exact-f32 kernel and the
+    result equals a float64 torch evaluation of RegNet.forward (RegNet.py:32-52) on the same weights."""
+    import torch.nn.functional as F
+    from xpoint_amd.convmodels import regnet_forward, regnet_weights
+    g = golden("g9_regnet.npz")
+    cfg = synth.xpoint_exp1_config(256, 256, hm_head=True)
+    sd = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
+    p = [k for k in sd if k.endswith("layer1.1.weight")][0][:-len("layer1.1.weight")]
+    sd[p + "layer1.1.weight"] = sd[p + "layer1.1.weight"] * 3.0e5            # BN1 gamma: c1's normalised output x 3e5 -> far beyond 65504
+    w = regnet_weights(sd, torch.device("cuda"))
+    e1 = torch.from_numpy(g["enc_optical"]).permute(0, 2, 3, 1).contiguous().cuda()
+    e2 = torch.from_numpy(g["enc_thermal"]).permute(0, 2, 3, 1).contiguous().cuda()
+    hm = regnet_forward(w, e1, e2).cpu().double()
+
+    def bn(x, i):
+        wt, b, m, v = (sd[p + f"layer1.{i}.{n}"].double() for n in ("weight", "bias", "running_mean", "running_var"))
+        return (x - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-5) * wt[None, :, None, None] + b[None, :, None, None]
+
+    def layer1(x):
+        x = F.relu(bn(F.conv2d(x, sd[p + "layer1.0.weight"].double(), padding=1), 1))
+        assert float(x.abs().max()) > 65504.0                                  # the case is what it claims to be
+        x = F.relu(bn(F.conv2d(x, sd[p + "layer1.3.weight"].double(), padding=1), 4))
+        return F.max_pool2d(x, 2)
+    a, b = layer1(torch.from_numpy(g["enc_optical"]).double()), layer1(torch.from_numpy(g["enc_thermal"]).double())
+    B, C, Hh, Wh = a.shape
+    an, bn_ = F.normalize(a, dim=1).view(B, C, -1), F.normalize(b, dim=1).view(B, C, -1)
+    v = torch.bmm(an.transpose(1, 2), bn_).mean(dim=2)                         # cost volume + global average pool over the second image's positions
+    h = F.relu(F.linear(v, sd[p + "fc.1.weight"].double(), sd[p + "fc.1.bias"].double()))
+    ref = F.linear(h, sd[p + "fc.4.weight"].double(), sd[p + "fc.4.bias"].double())
+    assert bool(torch.isfinite(hm).all())
+    assert float((hm - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), float((hm - ref).abs().max())
+
+
 def test_regnet_adaptive_pool_generalisation(gpu_lib, golden):
     """Opt-in generalisation of the RegNet head beyond 256x256 (NOT reference semantics — the reference's head only accepts
     256x256, RegNet.py:38-52): the pooled cost-volume map is adaptive-average-pooled to the 16x16 grid of the FC layer.  (1) At 256x256 it

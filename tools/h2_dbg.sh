@@ -7,7 +7,7 @@ T=/tmp/h2dbg; rm -rf $T; mkdir -p $T
 cp -r $R/xpoint_amd $R/include $R/tools $T/
 cd $T
 for d in ${H2_DBG_LIST:-0 1 2 4 8 16 32 36 6 14 30 62}; do
-  hipcc -x hip -c xpoint_amd/csrc/gemm_h2.hip -o xpoint_amd/csrc/_obj/gemm_h2.hip.o --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I include -I xpoint_amd/csrc -DXP_H2_DBG=$d 2>/dev/null || echo "build failed for $d" >> $OUT
+  hipcc -x hip -c xpoint_amd/csrc/gemm_h2.hip -o xpoint_amd/csrc/_obj/gemm_h2.hip.o --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I include -I xpoint_amd/csrc -DXP_H2_DBG=$d 2>/dev/null || { echo "build failed for $d" >> $OUT; continue; }
   hipcc -shared -fPIC --offload-arch=gfx950 -o xpoint_amd/libxpoint_hip.so xpoint_amd/csrc/_obj/*.o
   echo "== XP_H2_DBG=$d   (1 no split VALU, 2 no global loads, 4 no MFMA, 8 no LDS stores, 16 no barrier, 32 no fragment reads)" >> $OUT
   XP_H2P=0 GB_H2=1 GB_ONLY=${GB_ONLY:-12,15,10} PYTHONPATH=$T python3 tools/gemm_bench.py 2>&1 | grep "^M" >> $OUT

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "xp_maxpool2_nhwc": [c_p] * 2 + [c_i] * 4 + [c_p],
     "xp_costvolume_mean": [c_p] * 3 + [c_i] * 3 + [c_p],
     "xp_ingest_u8": [c_p] + [c_i] * 7 + [c_p] * 3,
+    "xp_u8_to_unit_f32": [c_p, c_p, c_l, c_p],
+    "xp_copy_to_mapped_host": [c_p, c_p, c_sz, c_p],
     "xp_ctx_create": [c_p, ctypes.POINTER(c_p)],
     "xp_ctx_destroy": [c_p],
     "xp_param_info": [c_p, c_i, ctypes.c_char_p, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)],

@@ -174,8 +174,11 @@ def regnet_forward(w, enc1_nhwc, enc2_nhwc, adaptive_pool=False, enc_both=None):
     (H'/2, W'/2) map over the FIRST image's positions, is adaptive-average-pooled to the 16 x 16 grid the FC layer was sized for, so the head
     accepts any image size; at 256x256 the pooling matrix is the identity and the result is the reference's (tests: g9)."""
     def layer1(x):      # conv (no bias) -> BN -> ReLU, twice, then MaxPool2d(2); BOTH images in one batch (2B crops per launch)
+        # c1 on the split-fp16 engine: its input is the encoder output, which the forward's range guard (XP_STATUS_ENC: |x| < 65504) has already vetted.
+        # c2 on the exact-f32 kernel: its input ReLU(BN(c1(x))) is unbounded, the split engine turns |x| >= 65504 into NaN rows and the following
+        # ReLU / max-pool would map those to 0 — a silently wrong hm (ADVICE r4); the exact kernel has no range limit and the layer is 16 K rows x 64.
         x = ops.conv3x3_h2(x, w["c1_h2"], w["c1"].shape[0], None, w["bn1"][0], w["bn1"][1], 1, False, "relu_after_affine")
-        x = ops.conv3x3_h2(x, w["c2_h2"], w["c2"].shape[0], None, w["bn2"][0], w["bn2"][1], 1, False, "relu_after_affine")
+        x = ops.conv3x3(x, w["c2"], None, w["bn2"][0], w["bn2"][1], 1, False, "relu_after_affine")
         return ops.maxpool2(x)
     B0 = enc1_nhwc.shape[0]
     if enc_both is not None:      # the caller's single (2B, H', W', 48) encoder output (models.predict_homography): both images in one batch, no copy

@@ -738,3 +738,52 @@ extern "C" int xp_ingest_u8(const uint8_t* src, int H0, int W0, int channels, in
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
+
+// 8-bit gray batch -> f32 / 255 (the reference loader's `img.astype(float32) / 255`, xpoint/datasets/ImagePairDataset.py:254-274: the same IEEE division, so
+// the same bits as a host conversion): the device half of the streaming path's 8-bit upload (predict.PairPipeline._stage_inputs) — 4 bytes read, 16 written per lane.
+namespace {
+__global__ __launch_bounds__(256) void u8_to_unit_f32_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(src + i);
+        *reinterpret_cast<float4*>(dst + i) = make_float4((float)v.x / 255.f, (float)v.y / 255.f, (float)v.z / 255.f, (float)v.w / 255.f);
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = (float)src[j] / 255.f;
+    }
+}
+}  // namespace
+
+extern "C" int xp_u8_to_unit_f32(const uint8_t* src, float* dst, int64_t n, void* stream) {
+    XP_CHECK_ARG(src && dst && n >= 0, "xp_u8_to_unit_f32: bad args");
+    XP_CHECK_ARG((((uintptr_t)src & 3) | ((uintptr_t)dst & 15)) == 0, "xp_u8_to_unit_f32: src must be 4-byte, dst 16-byte aligned");
+    if (n == 0) return XP_OK;
+    XpProfScope prof("u8_to_unit_f32", (hipStream_t)stream, (double)n, 5.0 * n);
+    hipLaunchKernelGGL(u8_to_unit_f32_kernel, dim3((unsigned)xp_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+
+// Result lists -> pinned (device-mapped) host memory by a KERNEL instead of the runtime's copy engines.  Why: in the streaming loop the device-to-host copies
+// of step i (queued behind its last kernels) and the host-to-device image upload of step i + 2 share a copy-engine queue, and the upload waits behind a copy
+// that itself waits for kernels — the encoder of step i + 2 starts late (bench.py, profiles/r5_streaming_parts.txt: uploads alone -2 %, downloads alone 0 %,
+// both -11 %).  The lists are a few MB: 16-byte stores over the link from a handful of workgroups, ordered like any other kernel of the stream.
+namespace {
+__global__ __launch_bounds__(256) void copy_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, size_t bytes) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0) {
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(src); unsigned char* db = reinterpret_cast<unsigned char*>(dst);
+        for (size_t j = n16 * 16 + threadIdx.x; j < bytes; j += 256) db[j] = sb[j];
+    }
+}
+}  // namespace
+
+extern "C" int xp_copy_to_mapped_host(const void* src_dev, void* dst_host, size_t bytes, void* stream) {
+    XP_CHECK_ARG(src_dev && dst_host, "xp_copy_to_mapped_host: null pointer");
+    XP_CHECK_ARG((((uintptr_t)src_dev | (uintptr_t)dst_host) & 15) == 0, "xp_copy_to_mapped_host: buffers must be 16-byte aligned");
+    if (bytes == 0) return XP_OK;
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (n16 + 255) / 256));
+    hipLaunchKernelGGL(copy_to_host_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_dev, (uint4*)dst_host, n16, bytes);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}

@@ -448,6 +448,10 @@ extern "C" int xp_xpoint_forward_f16(void* ctx, const float* weights, const void
         const bool seq = xp_ss2d_core_f16_wants_f32_copies(sh.H[s], sh.W[s], C, R) != 0;
         float* T3f = seq ? (ws + wp.T3 + ((size_t)M * C / 2 + 63) / 64 * 64) : nullptr;
         float* XDf = seq ? (ws + wp.XD + ((size_t)M * XW / 2 + 63) / 64 * 64) : nullptr;
+        // the f32 copies live in the upper part of the T3 / XD regions, behind this stage's half tensors: that needs 1.5 x the stage's tensor, which the plan
+        // only guarantees for stages smaller than the one that sizes the region (stage 0 in sequential form would overrun into the next region)
+        XP_CHECK_ARG(!seq || (((size_t)M * C / 2 + 63) / 64 * 64 + (size_t)M * C <= wp.HB - wp.T3 && ((size_t)M * XW / 2 + 63) / 64 * 64 + (size_t)M * XW <= wp.SS - wp.XD),
+                     "xp_xpoint_forward_f16: stage %d takes the sequential scan form but its f32 copies do not fit the workspace regions", s);
         for (int j = 0; j < c->cfg.depths[s]; ++j) {
             const std::string b = "s" + std::to_string(s) + ".b" + std::to_string(j) + ".";
             // x = x + SS2D(LN(x))      (VMamba.py:1222-1229, :648-664)

@@ -79,9 +79,10 @@ def selective_scan_fn(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus
         raise RuntimeError("selective_scan_fn: shape mismatch")
     out = torch.empty_like(u)
     last = torch.empty((batch, dim, N), device=u.device, dtype=torch.float32) if return_last_state else None
-    _lib.call("xp_selective_scan_fwd", ptr(u), ptr(delta), ptr(A), ptr(B), ptr(C), ptr(D), ptr(delta_bias), ptr(out),
-              ptr(last), c_i(batch), c_i(dim), c_i(delta.shape[1]), c_i(L), c_i(N), c_i(G), c_i(int(bool(delta_softplus))),
-              _lib.current_stream())
+    with torch.cuda.device(u.device):
+        _lib.call("xp_selective_scan_fwd", ptr(u), ptr(delta), ptr(A), ptr(B), ptr(C), ptr(D), ptr(delta_bias), ptr(out),
+                  ptr(last), c_i(batch), c_i(dim), c_i(delta.shape[1]), c_i(L), c_i(N), c_i(G), c_i(int(bool(delta_softplus))),
+                  _lib.current_stream())
     return (out, last) if return_last_state else out
 
 
@@ -96,7 +97,9 @@ def _csm_dtype(t, who):
 def cross_scan_fn(x, in_channel_first=True, out_channel_first=True, one_by_one=False, scans=0, force_torch=False):
     """Reference `cross_scan_fn` (csm_triton.py:501-507).  x: (B,C,H,W) | (B,H,W,C) | one_by_one: (B,4,C,H,W) | (B,H,W,4,C);
     returns (B,4,C,L) if out_channel_first else (B,L,4,C).  scans 0 cross scan, 1 unidirectional, 2 bidirectional.  `force_torch` is accepted and
-    ignored (there is one implementation).  Inference only: no autograd graph is recorded."""
+    ignored (there is one implementation).  Inference only: no autograd graph is recorded.
+    Two combinations deliberately implement the INTENDED permutation, not the reference's mis-indexed output (oracle/refharness/make_golden.py documents both):
+    one_by_one + channel-last in + scans = 2, and channel-first in / channel-last out with scans = 1."""
     dt = _csm_dtype(x, "cross_scan_fn")
     if scans not in (0, 1, 2):
         raise RuntimeError(f"cross_scan_fn: scans must be 0, 1 or 2 (got {scans})")
@@ -110,8 +113,9 @@ def cross_scan_fn(x, in_channel_first=True, out_channel_first=True, one_by_one=F
         B, C, H, W = x.shape if in_channel_first else (x.shape[0], x.shape[3], x.shape[1], x.shape[2])
     x = x.contiguous()
     y = torch.empty((B, 4, C, H * W) if out_channel_first else (B, H * W, 4, C), device=x.device, dtype=x.dtype)
-    _lib.call("xp_cross_scan", ptr(x), ptr(y), c_i(dt), c_i(B), c_i(C), c_i(H), c_i(W), c_i(int(bool(in_channel_first))),
-              c_i(int(bool(out_channel_first))), c_i(int(bool(one_by_one))), c_i(scans), _lib.current_stream(x))
+    with torch.cuda.device(x.device):       # as the reference (csm_triton.py:231): the launch targets x's device, whichever device is current
+        _lib.call("xp_cross_scan", ptr(x), ptr(y), c_i(dt), c_i(B), c_i(C), c_i(H), c_i(W), c_i(int(bool(in_channel_first))),
+                  c_i(int(bool(out_channel_first))), c_i(int(bool(one_by_one))), c_i(scans), _lib.current_stream(x))
     return y
 
 
@@ -131,6 +135,7 @@ def cross_merge_fn(y, in_channel_first=True, out_channel_first=True, one_by_one=
         out = torch.empty((B, 4, C, H * W) if in_channel_first else (B, H * W, 4, C), device=y.device, dtype=y.dtype)
     else:
         out = torch.empty((B, C, H * W) if in_channel_first else (B, H * W, C), device=y.device, dtype=y.dtype)
-    _lib.call("xp_cross_merge", ptr(y), ptr(out), c_i(dt), c_i(B), c_i(C), c_i(H), c_i(W), c_i(int(bool(in_channel_first))),
-              c_i(int(bool(out_channel_first))), c_i(int(bool(one_by_one))), c_i(scans), _lib.current_stream(y))
+    with torch.cuda.device(y.device):
+        _lib.call("xp_cross_merge", ptr(y), ptr(out), c_i(dt), c_i(B), c_i(C), c_i(H), c_i(W), c_i(int(bool(in_channel_first))),
+                  c_i(int(bool(out_channel_first))), c_i(int(bool(one_by_one))), c_i(scans), _lib.current_stream(y))
     return out

@@ -243,8 +243,18 @@ class PairPipeline:
                                                        ptr(mask_thermal) if masked else None, ptr(self.mask_b[k]) if masked else None, n,
                                                        _lib.current_stream()), "xp_stage_pair_batch")
             return
-        img[:B].copy_(optical, non_blocking=True)           # host (pinned) inputs, other dtypes / layouts: the runtime's copy engines
-        img[B:].copy_(thermal, non_blocking=True)
+        if optical.dtype == torch.uint8 and thermal.dtype == torch.uint8 and optical.numel() == n and thermal.numel() == n:
+            # 8-bit gray images (what a camera / decoder delivers): a quarter of the bytes over PCIe, gray / 255 on the device — the same f32 division the
+            # reference's loader does on the host (xpoint/datasets/ImagePairDataset.py:254-274), so the staged images are the same bits
+            if getattr(self, "_u8_b", None) is None:
+                self._u8_b = [torch.empty((2 * B, H, W), dtype=torch.uint8, device=img.device) for _ in range(self.depth)]
+            u8 = self._u8_b[k]
+            u8[:B].copy_(optical.reshape(B, H, W), non_blocking=True)
+            u8[B:].copy_(thermal.reshape(B, H, W), non_blocking=True)
+            _lib.check(_lib.load().xp_u8_to_unit_f32(ctypes.c_void_p(u8.data_ptr()), ptr(img), 2 * n, _lib.current_stream()), "xp_u8_to_unit_f32")
+        else:
+            img[:B].copy_(optical, non_blocking=True)           # host (pinned) inputs, other dtypes / layouts: the runtime's copy engines
+            img[B:].copy_(thermal, non_blocking=True)
         if masked:
             self.mask_b[k][:B].copy_(mask_optical.reshape(B, H, W))
             self.mask_b[k][B:].copy_(mask_thermal.reshape(B, H, W))
@@ -438,8 +448,9 @@ class PairPipeline:
         """Streaming use: enqueue — right behind the detection / matching kernels of the last run() / replay — the copies of its result
         lists (keypoint counts and coordinates, match counts and index lists, distances; the homography fields when estimated) into
         pinned host buffers, and return (buffers, event).  The buffers are valid after event.synchronize(); the NEXT run() may be enqueued
-        before that, so the device-to-host traffic of step i overlaps step i+1 (two buffer sets alternate: consume a set before the
-        second call after it).  The copies are ordered on the stream that writes the results, ahead of the next step's kernels."""
+        before that, so the device-to-host traffic of step i overlaps the steps behind it (`self.host_sets` = depth + 1 buffer sets rotate: a caller
+        may keep `depth` steps in flight and must consume a set before the host_sets-th call after it).  The copies are ordered on the stream that
+        writes the results, ahead of the next step's kernels."""
         with torch.cuda.device(self.device):
             if not hasattr(self, "_host"):
                 def pin(t):
@@ -451,15 +462,26 @@ class PairPipeline:
                 if self.estimate_homography:
                     src.update(H_est=self.hg["H"], n_inliers=self.hg["n_inliers"], matchesMask=self.hg["mask"])
                 self._host_src = src
-                self._host = [{k: pin(v) for k, v in src.items()} for _ in range(2)]
-                self._host_ev = [torch.cuda.Event() for _ in range(2)]
+                import os
+                self._copy_engine_d2h = os.environ.get("XP_D2H_COPY_ENGINE", "0") == "1"      # A/B: the runtime's copy engines for the result lists
+                self.host_sets = max(2, self.depth + 1)
+                self._host = [{k: pin(v) for k, v in src.items()} for _ in range(self.host_sets)]
+                self._host_ev = [torch.cuda.Event() for _ in range(self.host_sets)]
                 self._host_i = 0
             i = self._host_i
-            self._host_i ^= 1
+            self._host_i = (i + 1) % self.host_sets
             stream = self.post_stream if self.overlap else torch.cuda.current_stream()
             with torch.cuda.stream(stream):
+                # by a kernel, not by the copy engines: a device-to-host copy queued behind this step's kernels would hold up the NEXT steps' image
+                # uploads in the engines' queue (xp_copy_to_mapped_host; bench.py's streaming loop: 1 553 -> see profiles/r5_streaming_parts.txt)
+                lib = _lib.load()
                 for k, v in self._host_src.items():
-                    self._host[i][k].copy_(v, non_blocking=True)
+                    h = self._host[i][k]
+                    if v.is_contiguous() and v.numel() > 0 and v.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0 and not self._copy_engine_d2h:
+                        _lib.check(lib.xp_copy_to_mapped_host(ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(h.data_ptr()), v.numel() * v.element_size(),
+                                                              _lib.current_stream()), "xp_copy_to_mapped_host")
+                    else:
+                        h.copy_(v, non_blocking=True)
                 self._host_ev[i].record()
             return self._host[i], self._host_ev[i]
 

@@ -3,13 +3,16 @@
 Every step takes its B pairs from (pinned) host memory, replays the captured encode + detect + describe + match graphs of an overlapped
 `PairPipeline`, runs the reference's RegNet head (xpoint/models/RegNet.py:7-52) on the 256x256 top-left crop of every pair — the only input size
 that head is defined for (its FC layer is sized for a 32x32 encoder map, RegNet.py:38-52) — from a second captured graph, and
-enqueues the downloads of the result lists and of `hm` into pinned host buffers behind the step's last kernel.  The host consumes step i-1 while
-step i runs (two buffer sets alternate).  `bench.py --config c5` times exactly this object; tests/test_gpu_configs.py checks it against the
+enqueues the downloads of the result lists and of `hm` into pinned host buffers behind the step's last kernel.  The host may keep `pipe.depth`
+steps in flight (depth + 1 pinned buffer sets rotate): it consumes step i - depth + 1 while the newer ones run.  `bench.py --config c5` times exactly this object; tests/test_gpu_configs.py checks it against the
 reference fixtures g15 (lists) and g21 (hm)."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
+from . import _lib
 from .predict import PairPipeline
 
 CROP = 256
@@ -34,8 +37,9 @@ class StreamingRegistrationStep:
             with torch.cuda.graph(self.graph):
                 self.hm = net_hm.predict_homography(self.crop_o, self.crop_t)
             self._hm_engine = net_hm.effective_gemm_mode()
-            self.hm_host = [torch.empty(self.hm.shape, dtype=self.hm.dtype).pin_memory() for _ in range(2)]
-            self.hm_ev = [torch.cuda.Event() for _ in range(2)]
+            self.host_sets = max(2, pipe.depth + 1)         # as PairPipeline.download_async: `depth` steps may be in flight on the host side
+            self.hm_host = [torch.empty(self.hm.shape, dtype=self.hm.dtype).pin_memory() for _ in range(self.host_sets)]
+            self.hm_ev = [torch.cuda.Event() for _ in range(self.host_sets)]
         self._i = 0
 
     def _cut(self, o_img, t_img):
@@ -52,9 +56,14 @@ class StreamingRegistrationStep:
             # the crops are cut outside the graph: their source alternates between the pipeline's input buffers
             self._cut(pipe.images[:self.B], pipe.images[self.B:])
             self.graph.replay()
-            j = self._i & 1
+            j = self._i % self.host_sets
             self._i += 1
-            self.hm_host[j].copy_(self.hm, non_blocking=True)
+            # like the result lists (PairPipeline.download_async): by a kernel, so that no copy-engine transfer of this step queues ahead of the next uploads
+            if self.hm.is_contiguous() and self.hm.data_ptr() % 16 == 0 and not getattr(pipe, "_copy_engine_d2h", False):
+                _lib.check(_lib.load().xp_copy_to_mapped_host(ctypes.c_void_p(self.hm.data_ptr()), ctypes.c_void_p(self.hm_host[j].data_ptr()),
+                                                              self.hm.numel() * self.hm.element_size(), _lib.current_stream()), "xp_copy_to_mapped_host")
+            else:
+                self.hm_host[j].copy_(self.hm, non_blocking=True)
             self.hm_ev[j].record()
             bufs, ev = pipe.download_async()
         return bufs, ev, self.hm_host[j], self.hm_ev[j]
