@@ -575,8 +575,21 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         // order.  The x3 schedule below (fc1 of chunk c+1 with the GELU of chunk c between its MFMAs, two accumulator sets) spills 149
         // registers at C = 192 with two planes resident and eight waves (8 here); measured 314 -> 272 us at C = 192, 278 -> 266 us at C = 96.
         for (; c < NC; ++c) {
-            if (c > 0) { load_bias(c, h0); __builtin_amdgcn_sched_barrier(0); fc1(slot, h0, h0, std::integral_constant<int, 0>{}); end_phase(); }
-            if constexpr (H2) load_inv1(c, inv_cur);
+#ifndef XP_MLP_ASM_LDS
+#define XP_MLP_ASM_LDS 1   /* 0: the bias / scale reads as ordinary ds_reads (hipcc then puts s_waitcnt vmcnt(0) in front of them: the image issued a phase ago is waited for a phase early) */
+#endif
+            if (c > 0) {
+                if (XP_MLP_ASM_LDS) {
+                    float bv[16];
+                    lds_read16_asm(bias_lds, c, bv);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h0[r] = bv[r];
+                } else load_bias(c, h0);
+                __builtin_amdgcn_sched_barrier(0);
+                fc1(slot, h0, h0, std::integral_constant<int, 0>{});
+                end_phase();
+            }
+            if constexpr (H2) { if (XP_MLP_ASM_LDS) lds_read16_asm(inv1_lds, c, inv_cur); else load_inv1(c, inv_cur); }
 #pragma unroll
             for (int k = 0; k < 20; ++k) slice(k, h0);
             fc2(slot, h0);
