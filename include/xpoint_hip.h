@@ -28,6 +28,10 @@ extern "C" {
 int xp_version(void);
 const char* xp_last_error(void);
 int xp_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
+/* The registry of the library's XP_* environment knobs (csrc/xp_knobs.h): tuning / A-B switches only, each read once per process; no knob changes a
+ * precision class.  xp_knob_info returns static strings: the variable, the source that reads it, what it does. */
+int xp_knob_count(void);
+int xp_knob_info(int index, const char** name, const char** where, const char** what);
 
 /* ---------------------------------------------------------------------------------------------
  * Selective-scan forward.  Replaces the pybind op `selective_scan_cuda_oflex.fwd(u, delta, A, B, C,

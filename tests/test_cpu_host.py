@@ -228,3 +228,28 @@ def test_vmamba_needs_four_stages():
     ctx = ctypes.c_void_p()
     assert _lib.load().xp_ctx_create(ctypes.byref(c), ctypes.byref(ctx)) != 0
     assert b"4 stages" in _lib.load().xp_last_error()
+
+
+def test_knob_registry_is_complete():
+    """Every XP_* environment variable the sources read is in the ONE registry (csrc/xp_knobs.h, enumerated by xp_knob_count / xp_knob_info), and every
+    registered knob is read somewhere: no undocumented switch, no stale entry."""
+    import ctypes
+    import glob
+    import re
+    lib = _lib.load()
+    reg = {}
+    for i in range(lib.xp_knob_count()):
+        n, w, d = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_char_p()
+        assert lib.xp_knob_info(i, ctypes.byref(n), ctypes.byref(w), ctypes.byref(d)) == 0
+        reg[n.value.decode()] = (w.value.decode(), d.value.decode())
+    assert len(reg) == lib.xp_knob_count() and all(len(d) > 10 for _, d in reg.values())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for path in glob.glob(os.path.join(root, "xpoint_amd", "csrc", "*")) + glob.glob(os.path.join(root, "xpoint_amd", "*.py")) + [os.path.join(root, "bench.py")]:
+        if os.path.isdir(path) or path.endswith("xp_knobs.h"):
+            continue
+        txt = open(path, errors="ignore").read()
+        used |= set(re.findall(r'getenv\("(XP_[A-Z0-9_]+)"', txt))
+        used |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(XP_[A-Z0-9_]+)"', txt))
+    assert used - set(reg) == set(), f"read but not registered: {sorted(used - set(reg))}"
+    assert set(reg) - used == set(), f"registered but read nowhere: {sorted(set(reg) - used)}"

@@ -42,6 +42,9 @@ GB_X3=1 python3 $R/tools/gemm_bench.py > $OUT/gemm_x3_microbench.txt 2>&1
 python3 $R/tools/scan_bench.py > $OUT/selective_scan_microbench.txt 2>&1
 python3 $R/tools/ss2d_bench.py 0 1 2>&1 | grep -v amdgpu > $OUT/ss2d_core_microbench.txt
 python3 $R/tools/enc_only.py 2>&1 | grep stream > $OUT/encoder_only_streams.txt
+# round 5: the ring dense engine's stand-alone table (tools/ring_bench, built beforehand by tools/ring_dbg.sh build) and the streaming loop's parts
+[ -x $R/tools/ring_bench ] && (cd $R && tools/ring_bench 0 7 1 > $OUT/ring_microbench.txt 2>&1)
+XP_BENCH_PCIE_PARTS=1 python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-other-backend 2>&1 >/dev/null | grep "pcie parts" > $OUT/streaming_parts.txt
 # the headline line again with THIS run's PMC traffic in roofline.traffic (bench.py reads profiles/pmc_traffic.json)
 cp $OUT/bench.json $OUT/bench_before_pmc.json
 cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json

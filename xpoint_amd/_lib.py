@@ -25,6 +25,7 @@ class XPointHipError(RuntimeError):
 c_sz = ctypes.c_size_t
 _SIGNATURES = {
     "xp_device_info": [c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.c_char_p, c_i],
+    "xp_knob_info": [c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)],
     "xp_selective_scan_fwd": [c_p] * 9 + [c_i] * 7 + [c_p],
     "xp_selective_scan_fwd_typed": [c_p] * 9 + [c_i] * 9 + [c_p],
     "xp_cross_scan": [c_p, c_p] + [c_i] * 9 + [c_p],
@@ -109,6 +110,7 @@ _SIGNATURES = {
 }
 # size queries: (restype size_t / int, argtypes)
 _SIZE_QUERIES = {
+    "xp_knob_count": (c_i, []),
     "xp_weights_numel": (c_sz, [c_p]),
     "xp_param_count": (c_i, [c_p]),
     "xp_forward_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "xp_common.h"
+#include "xp_knobs.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -15,6 +16,14 @@ void xp_set_error(const char* fmt, ...) {
 
 extern "C" const char* xp_last_error(void) { return g_err; }
 extern "C" int xp_version(void) { return 100; }  // 0.1.0
+
+// the XP_* environment knob registry (xp_knobs.h)
+extern "C" int xp_knob_count(void) { return kXpKnobCount; }
+extern "C" int xp_knob_info(int index, const char** name, const char** where, const char** what) {
+    if (index < 0 || index >= kXpKnobCount || !name || !where || !what) { xp_set_error("xp_knob_info: bad arguments"); return XP_ERR_ARG; }
+    *name = kXpKnobs[index].name; *where = kXpKnobs[index].where; *what = kXpKnobs[index].what;
+    return XP_OK;
+}
 
 extern "C" int xp_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len) {
     hipDeviceProp_t p;
