@@ -116,7 +116,15 @@ def pmc_kernel_for_tag(tag, names):
         if not m:
             raise KeyError(f"unrecognised fused-kernel tag {tag!r}")
         mode = {"mlp_fused": 0, "proj_mlp_fused": 1, "ln_proj": 2}[m.group(1)]
-        pat = re.compile(rf"mlp_fused_kernel<{m.group(3)}, \d+, {mode}, \d+, {'true' if m.group(2) == 'h2' else 'false'}>$")
+        # (round 5: a trailing PP parameter — the ping-pong schedule, off by default — follows H2)
+        pat = re.compile(rf"mlp_fused_kernel<{m.group(3)}, \d+, {mode}, \d+, {'true' if m.group(2) == 'h2' else 'false'}(, (true|false))?>$")
+    elif tag.startswith("gemm_ring"):
+        # ring dense engine (csrc/ring_core.h): ring_gemm_kernel<GM, GN, TM, TN, PLANES, S>; tag gemm_ring_{h2s|f16}_<BM>x<BN>
+        m = re.match(r"gemm_ring_(h2s|f16)_(\d+)x(\d+)$", tag)
+        if not m:
+            raise KeyError(f"unrecognised ring tag {tag!r}")
+        cfg = {("256", "256"): "2, 2, 2, 4", ("256", "128"): "2, 2, 2, 2", ("128", "128"): "1, 4, 2, 1"}[(m.group(2), m.group(3))]
+        pat = re.compile(rf"ring_gemm_kernel<{cfg}, {2 if m.group(1) == 'h2s' else 1}, \d+>$")
     elif tag.startswith(("gemm_h2p", "gemm_h2w")):
         # ping-pong / wave-specialised schedules of the split-fp16 GEMM: one (non-template) kernel each
         pat = re.compile(rf"{tag.split('_mfma_')[0]}_kernel$")

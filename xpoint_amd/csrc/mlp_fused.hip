@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     if constexpr (PP) {
         // Ping-pong schedule of the chunk loop (round 5).  Per chunk a wave runs THREE phases of about equal length — F1 = fc1's matrix instructions (+ their
         // fragment reads), V = GELU + split on the vector ALU, F2 = fc2's matrix instructions — and the stage-removal timings of the lockstep loop above
-        // (profiles/r5_mlp_h2_stage_removal.txt: no-MFMA build 124 of 274 us, no-GELU-no-split 197) are the SUM of the three: with every wave of the workgroup
+        // (profiles/r5_mlp_pingpong.txt: no-MFMA build 124 of 274 us, no-GELU-no-split 197) are the SUM of the three: with every wave of the workgroup
         // between the same two barriers, the two waves of a SIMD want the matrix pipe together and the vector ALU together.  Here waves 4 - 7 (the second wave
         // of every SIMD) run ONE PHASE BEHIND waves 0 - 3, a barrier after every phase: slot k pairs (F1, F2'), (V, F1'), (F2, V') — the partner's V always
         // sits under a matrix phase, and only the (F1, F2') slot has both on the pipe, which is then simply full.  Same instructions per wave in the same
