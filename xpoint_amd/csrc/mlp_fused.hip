@@ -39,6 +39,9 @@
 #include "gemm_x3_core.h"
 #include "gemm_h2_core.h"
 
+#ifndef XP_MLP_FRAG_DEPTH
+#define XP_MLP_FRAG_DEPTH 2   /* LDS fragment look-ahead of the split-fp16 instances, in k slabs (1 = round 4) */
+#endif
 #ifndef XP_MLP_DBG
 #define XP_MLP_DBG 0   /* timing experiments only (wrong results): 1 no GELU, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no bf16 split of the hidden values, 16 no MFMA */
 #endif
@@ -367,21 +370,26 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     auto fc1 = [&](int slot, f32x16& nxt, f32x16& cur, auto nsl_tag) {
         constexpr int NSL = decltype(nsl_tag)::value;
         const unsigned char* img = lds + slot * T::IMGP + frag;
-        frag_bits a[2][3];
+        // fragment ring FD + 1 deep: the reads of slab s + FD are requested before the MFMAs of slab s (round 5: FD = 2 for the split-fp16 instances — with
+        // one slab of look-ahead the ds_read latency exceeded the 96 cycles of a slab's three MFMAs and every slab stalled: stamps in profiles/r5_mlp_pingpong.txt; C = 96: 262.7 - 268.7 -> 258.8 us, same bits)
+        constexpr int FD = (H2 && C <= 128 && XP_MLP_FRAG_DEPTH > 1 && KS > 2) ? 2 : 1;      // (C = 192 is at the register limit: 8 -> 18 spills, no gain)
+        frag_bits a[FD + 1][3];
 #pragma unroll
-        for (int pl = 0; pl < NPLD; ++pl) a[0][pl] = *reinterpret_cast<const frag_bits*>(img + pl * 32);
+        for (int d = 0; d < FD; ++d)
+#pragma unroll
+            for (int pl = 0; pl < NPLD; ++pl) a[d][pl] = *reinterpret_cast<const frag_bits*>(img + d * 32 * ROWB + pl * 32);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if (s + 1 < KS) {      // fragments of slab s+1 are requested before the MFMAs of slab s
+            if (s + FD < KS) {
 #pragma unroll
-                for (int pl = 0; pl < NPLD; ++pl) a[(s + 1) & 1][pl] = *reinterpret_cast<const frag_bits*>(img + (s + 1) * 32 * ROWB + pl * 32);
+                for (int pl = 0; pl < NPLD; ++pl) a[(s + FD) % (FD + 1)][pl] = *reinterpret_cast<const frag_bits*>(img + (s + FD) * 32 * ROWB + pl * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 6 - NP; pp < 6; ++pp) {
                 const int m = s * NP + pp - (6 - NP);
-                if (XP_MLP_DBG & 16) { if (pp == 5) nxt[0] += __uint_as_float(a[s & 1][0][0]) * __uint_as_float(xp[s][0][0]); }
-                else nxt = mlp_mfma<H2>(a[s & 1][PA[pp]], xp[s][PB[pp]], nxt);
+                if (XP_MLP_DBG & 16) { if (pp == 5) nxt[0] += __uint_as_float(a[s % (FD + 1)][0][0]) * __uint_as_float(xp[s][0][0]); }
+                else nxt = mlp_mfma<H2>(a[s % (FD + 1)][PA[pp]], xp[s][PB[pp]], nxt);
 #pragma unroll
                 for (int k = (m * NSL + NP * KS - 1) / (NP * KS); k < ((m + 1) * NSL + NP * KS - 1) / (NP * KS); ++k) slice(k, cur);
                 __builtin_amdgcn_sched_barrier(0);
@@ -393,22 +401,25 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     // (slices 20..23 of `cur`) between those MFMAs, then hidden slab 1
     auto fc2 = [&](int slot, f32x16& cur) {
         const unsigned char* img = lds + slot * T::IMGP + frag;
-        frag_bits b[2][3];
+        constexpr int FD = (H2 && C <= 128 && XP_MLP_FRAG_DEPTH > 1 && 2 * NT > 2) ? 2 : 1;       // fragment look-ahead, as in fc1
+        frag_bits b[FD + 1][3];
+        auto b_addr = [&](int i) { return img + ((i / NT) * C + (i % NT) * 32) * ROWB; };
 #pragma unroll
-        for (int pl = 0; pl < NPLD; ++pl) b[0][pl] = *reinterpret_cast<const frag_bits*>(img + pl * 32);
+        for (int d = 0; d < FD; ++d)
+#pragma unroll
+            for (int pl = 0; pl < NPLD; ++pl) b[d][pl] = *reinterpret_cast<const frag_bits*>(b_addr(d) + pl * 32);
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {          // step i = (hidden slab j = i / NT, output tile t = i % NT)
             const int j = i / NT, t = i % NT;
-            if (i + 1 < 2 * NT) {
-                const int j1 = (i + 1) / NT, t1 = (i + 1) % NT;
+            if (i + FD < 2 * NT) {
 #pragma unroll
-                for (int pl = 0; pl < NPLD; ++pl) b[(i + 1) & 1][pl] = *reinterpret_cast<const frag_bits*>(img + (j1 * C + t1 * 32) * ROWB + pl * 32);
+                for (int pl = 0; pl < NPLD; ++pl) b[(i + FD) % (FD + 1)][pl] = *reinterpret_cast<const frag_bits*>(b_addr(i + FD) + pl * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 6 - NP; pp < 6; ++pp) {
-                if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i & 1][0][0]); }
-                else oacc[t] = mlp_mfma<H2>(hfrag(j, PA[pp]), b[i & 1][PB[pp]], oacc[t]);
+                if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i % (FD + 1)][0][0]); }
+                else oacc[t] = mlp_mfma<H2>(hfrag(j, PA[pp]), b[i % (FD + 1)][PB[pp]], oacc[t]);
                 if (!PP && i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once (PP: done in the V phase)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (NP >= 4 ? q == pp - (6 - NP) : true) slice(20 + q, cur);
