@@ -611,6 +611,54 @@ def test_download_async_equals_fetch(gpu_lib, overlap):
             assert g["match_q"][i, :nm].tolist() == ref[i]["match_q"].tolist() and g["match_t"][i, :nm].tolist() == ref[i]["match_t"].tolist()
 
 
+def test_streaming_depth_u8_upload_and_kernel_downloads(gpu_lib):
+    """Round 5 streaming path: (1) xp_u8_to_unit_f32 = the loader's `astype(float32) / 255` bit for bit; (2) xp_copy_to_mapped_host copies any byte count into
+    pinned host memory; (3) a PairPipeline fed 8-bit pinned images, with `depth` steps kept in flight by the host and the result lists downloaded by the
+    kernel copy (depth + 1 pinned buffer sets), returns exactly what synchronous runs on the float images return."""
+    import collections
+    import ctypes
+    from xpoint_amd import _lib as L
+    from xpoint_amd.predict import PairPipeline
+    lib = L.load()
+    u8 = torch.randint(0, 256, (3, 1, 37, 53), dtype=torch.uint8)
+    dev8 = u8.cuda(); out = torch.empty(u8.shape, dtype=torch.float32, device="cuda")
+    L.check(lib.xp_u8_to_unit_f32(ctypes.c_void_p(dev8.data_ptr()), L.ptr(out), u8.numel(), L.current_stream()), "xp_u8_to_unit_f32")
+    assert torch.equal(out.cpu(), torch.from_numpy(u8.numpy().astype(np.float32) / 255.0))
+    for nbytes in (16, 4096, 100003):
+        src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda"); dst = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        L.check(lib.xp_copy_to_mapped_host(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), nbytes, L.current_stream()), "xp_copy_to_mapped_host")
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src.cpu())
+    H, W, B = 96, 128, 2
+    net = _net(synth.xpoint_exp1_config(H, W))
+    seq = [_data(s, B, H, W) for s in (3, 8, 1, 5, 2, 9)]
+    q8 = lambda img: (img * 255.0).round().clamp(0, 255).to(torch.uint8)
+    with torch.no_grad():
+        ref_pipe = PairPipeline(net, B, H, W, cap=2048)
+        refs = [ref_pipe.run(q8(d["optical"]["image"]).float() / 255.0, q8(d["thermal"]["image"]).float() / 255.0, d["optical"]["valid_mask"],
+                             d["thermal"]["valid_mask"]).fetch() for d in seq]
+        pipe = PairPipeline(net, B, H, W, cap=2048, overlap=True, alternate_encoders=3)
+        assert pipe.depth == 3
+        got, pend = [], collections.deque()
+        for d in seq:
+            o, t = q8(d["optical"]["image"]).cpu().pin_memory(), q8(d["thermal"]["image"]).cpu().pin_memory()
+            pipe.run(o, t, d["optical"]["valid_mask"], d["thermal"]["valid_mask"])
+            pend.append(pipe.download_async())
+            assert pipe.host_sets == pipe.depth + 1
+            if len(pend) >= pipe.depth:                      # the host consumes step i - depth + 1 only now: depth steps were in flight
+                bufs, ev = pend.popleft(); ev.synchronize(); got.append({k: v.clone() for k, v in bufs.items()})
+        while pend:
+            bufs, ev = pend.popleft(); ev.synchronize(); got.append({k: v.clone() for k, v in bufs.items()})
+        torch.cuda.synchronize()
+        pipe.verify()
+    assert len(got) == len(refs)
+    for g, ref in zip(got, refs):
+        for i in range(B):
+            no, nt, nm = int(g["counts"][i]), int(g["counts"][B + i]), int(g["match_count"][i])
+            assert torch.equal(g["kp"][i, :no].long(), ref[i]["kp_optical"]) and torch.equal(g["kp"][B + i, :nt].long(), ref[i]["kp_thermal"])
+            assert g["match_q"][i, :nm].tolist() == ref[i]["match_q"].tolist() and g["match_t"][i, :nm].tolist() == ref[i]["match_t"].tolist()
+
+
 def test_fp16_range_overflow_falls_back_to_x3(gpu_lib):
     """The default dense engine splits f32 operands into two fp16 values: activations beyond 65504 overflow, and the heads' ReLU would turn a NaN
     encoder map into finite, wrong scores.  Every forward reports it through a device status word (xp_xpoint_forward_ex); the host then re-runs
