@@ -57,6 +57,7 @@ static const XpKnob kXpKnobs[] = {
     {"XP_LIB_PATH", "_lib.py", "load another build of libxpoint_hip.so"},
     {"XP_EXTRA_HIPCC_FLAGS", "build.py", "extra hipcc flags of `python -m xpoint_amd.build`"},
     {"XP_D2H_COPY_ENGINE", "predict.py", "1: result lists to the host through the runtime's copy engines instead of xp_copy_to_mapped_host (A/B)"},
+    {"XP_C5_HEAD_STREAM", "streaming.py", "caller: the RegNet head of the streaming step on the caller's stream (round-4 placement) instead of the detection / matching stream (A/B)"},
     {"XP_RANK_CPUS", "affinity.py", "pin every rank to this cpulist instead of its GPU's NUMA CPUs"},
     {"XP_CPU_THREADS", "bench.py", "threads of the CPU baseline"},
     {"XP_BENCH_DEPTH", "bench.py", "steps in flight of the alternating-encoder schedule (default 3)"},

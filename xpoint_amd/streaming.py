@@ -9,6 +9,7 @@ reference fixtures g15 (lists) and g21 (hm)."""
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -41,6 +42,7 @@ class StreamingRegistrationStep:
             self.hm_host = [torch.empty(self.hm.shape, dtype=self.hm.dtype).pin_memory() for _ in range(self.host_sets)]
             self.hm_ev = [torch.cuda.Event() for _ in range(self.host_sets)]
         self._i = 0
+        self._head_on_caller = os.environ.get("XP_C5_HEAD_STREAM", "post") == "caller"     # A/B knob: the round-4 placement
 
     def _cut(self, o_img, t_img):
         self.crop_o.copy_(o_img[:, :, :CROP, :CROP]); self.crop_t.copy_(t_img[:, :, :CROP, :CROP])
@@ -53,18 +55,26 @@ class StreamingRegistrationStep:
         pipe = self.pipe
         with torch.cuda.device(pipe.device), torch.no_grad():
             self.replay(optical, thermal, mask_optical, mask_thermal)
-            # the crops are cut outside the graph: their source alternates between the pipeline's input buffers
-            self._cut(pipe.images[:self.B], pipe.images[self.B:])
-            self.graph.replay()
-            j = self._i % self.host_sets
-            self._i += 1
-            # like the result lists (PairPipeline.download_async): by a kernel, so that no copy-engine transfer of this step queues ahead of the next uploads
-            if self.hm.is_contiguous() and self.hm.data_ptr() % 16 == 0 and not getattr(pipe, "_copy_engine_d2h", False):
-                _lib.check(_lib.load().xp_copy_to_mapped_host(ctypes.c_void_p(self.hm.data_ptr()), ctypes.c_void_p(self.hm_host[j].data_ptr()),
-                                                              self.hm.numel() * self.hm.element_size(), _lib.current_stream()), "xp_copy_to_mapped_host")
-            else:
-                self.hm_host[j].copy_(self.hm, non_blocking=True)
-            self.hm_ev[j].record()
+            # The head runs on the pipeline's detection / matching stream, behind this step's matching: the runtime maps streams onto
+            # GPU_MAX_HW_QUEUES (4) hardware queues, and a fifth busy stream shares a queue with one of the other four (measured: head on the caller's
+            # stream 1 241 pairs/s, with 6 queues 1 402).  The crops are cut outside the graph: their source alternates between the pipeline's
+            # input buffers, which the step `depth` calls later overwrites only after post_done[k] — re-recorded below, behind the head.
+            head_stream = pipe.post_stream if (pipe.overlap and not self._head_on_caller) else torch.cuda.current_stream()
+            head_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(head_stream):
+                self._cut(pipe.images[:self.B], pipe.images[self.B:])
+                self.graph.replay()
+                j = self._i % self.host_sets
+                self._i += 1
+                # like the result lists (PairPipeline.download_async): by a kernel, so that no copy-engine transfer of this step queues ahead of the next uploads
+                if self.hm.is_contiguous() and self.hm.data_ptr() % 16 == 0 and not getattr(pipe, "_copy_engine_d2h", False):
+                    _lib.check(_lib.load().xp_copy_to_mapped_host(ctypes.c_void_p(self.hm.data_ptr()), ctypes.c_void_p(self.hm_host[j].data_ptr()),
+                                                                  self.hm.numel() * self.hm.element_size(), _lib.current_stream()), "xp_copy_to_mapped_host")
+                else:
+                    self.hm_host[j].copy_(self.hm, non_blocking=True)
+                self.hm_ev[j].record()
+                if pipe.overlap and not self._head_on_caller:
+                    pipe.post_done[pipe._last[0]].record()
             bufs, ev = pipe.download_async()
         return bufs, ev, self.hm_host[j], self.hm_ev[j]
 
