@@ -26,6 +26,33 @@ __global__ void k(float* out, int iters) {
                 asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
                              "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (MODE == 5) {   // ONE dependent chain: 8 v_fma_f32, each on the previous result
+                asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                             "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                             : "+v"(a0) : "v"(m), "v"(c));
+            } else if (MODE == 6) {   // TWO interleaved dependent chains
+                asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                             "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                             : "+v"(a0), "+v"(a1) : "v"(m), "v"(c));
+            } else if (MODE == 7) {   // ONE dependent chain of v_pk_fma_f32
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
+                             : "+v"(p0) : "v"(pm), "v"(pc));
+            } else if (MODE == 8) {   // dependent chain exp -> fma -> exp -> fma
+                asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n v_exp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"
+                             "v_exp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n v_exp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2\n"
+                             : "+v"(a0) : "v"(m), "v"(c));
+            } else if (MODE == 9) {   // one MFMA 32x32x16 f16 + one dependent chain of 6 v_fma_f32 (a GELU slice per MFMA gap)
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                typedef float f16v __attribute__((ext_vector_type(16)));
+                static __device__ f16v acc;
+                h8 x = {1, 1, 1, 1, 1, 1, 1, 1};
+                f16v z = {};
+                z[0] = a1;
+                z = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, z, 0, 0, 0);
+                asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                             "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                             : "+v"(a0) : "v"(m), "v"(c));
+                a1 = z[0] * 1e-30f;
             } else if (MODE == 4) {   // 4 exp + 4 pk_fma interleaved
                 asm volatile("v_exp_f32 %0, %0\n v_pk_fma_f32 %4, %4, %8, %9\n v_exp_f32 %1, %1\n v_pk_fma_f32 %5, %5, %8, %9\n"
                              "v_exp_f32 %2, %2\n v_pk_fma_f32 %6, %6, %8, %9\n v_exp_f32 %3, %3\n v_pk_fma_f32 %7, %7, %8, %9\n"
@@ -39,7 +66,7 @@ template <int MODE>
 void run(const char* name, int instr_per_iter, int lanes_elems) {
     float* out; hipMalloc(&out, 256 * 1024 * 4 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int wps = 1; wps <= 8; wps *= 2) {
+    for (int wps = 1; wps <= 8; wps = wps < 4 ? wps + 1 : wps * 2) {
         const int threads = 256, blocks = 256 * wps;     // 4 waves per block = 1 per SIMD
         const int iters = 4096;
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, 16);
@@ -57,5 +84,10 @@ int main() {
     run<2>("v_pk_mul_f32", 4, 2);
     run<3>("v_exp_f32", 8, 1);
     run<4>("v_exp_f32+v_pk_fma_f32 pairs", 8, 1);
+    run<5>("v_fma_f32, 1 dependent chain", 8, 1);
+    run<6>("v_fma_f32, 2 chains", 8, 1);
+    run<7>("v_pk_fma_f32, 1 dependent chain", 4, 2);
+    run<8>("exp->fma dependent chain", 8, 1);
+    run<9>("mfma + 6 dependent v_fma (per 7)", 7, 1);
     return 0;
 }
