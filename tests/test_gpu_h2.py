@@ -159,6 +159,43 @@ def test_mlp_fused_h2(gpu_lib, M, C, H4, proj):
     assert float((Xg - X3).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+def test_mlp_fused_h2_schedules_are_bit_identical(gpu_lib):
+    """The experimental schedules of the split-fp16 fused tail — ping-pong chunk loop (XP_MLP_PP) and the warp-specialised instances (XP_MLP_WS = 1: 8 matrix
+    + 4 vector waves, 2: 4 + 4) — keep every row's arithmetic and its order: same bits as the default lockstep kernel, ragged last workgroup included.
+    (The knobs are read once per process: child processes.)"""
+    import os, subprocess, sys
+    code = (
+        "import ctypes, torch, zlib\n"
+        "from xpoint_amd import _lib as L, synth\n"
+        "vp = lambda t: ctypes.c_void_p(t.data_ptr())\n"
+        "st = L.current_stream()\n"
+        "def split(W):\n"
+        "    N, K = W.shape\n"
+        "    o = torch.empty(L.load().xp_split_weights_h2_bytes(N, K), dtype=torch.uint8, device='cuda')\n"
+        "    L.call('xp_split_weights_h2', L.ptr(W), vp(o), N, K, st); return o\n"
+        "u = lambda tag, shape, lo, hi: torch.from_numpy(synth.uniform(tag, shape, lo, hi)).cuda()\n"
+        "for (M, C, H4, proj) in [(1000, 96, 384, 1), (4480, 96, 384, 0), (300, 96, 96, 1), (2400, 192, 768, 1)]:\n"
+        "    X = u(f'sx{M}{C}', (M, C), -2.0, 2.0); lw = u(f'slw{C}', (C,), 0.5, 1.5); lb = u(f'slb{C}', (C,), -0.5, 0.5)\n"
+        "    W1 = u(f'sw1{C}{H4}', (H4, C), -0.2, 0.2); b1 = u(f'sb1{H4}', (H4,), -0.5, 0.5); W2 = u(f'sw2{C}{H4}', (C, H4), -0.1, 0.1); b2 = u(f'sb2{C}', (C,), -0.5, 0.5)\n"
+        "    T1 = u(f'st{M}{C}', (M, C), -1.0, 1.0); W0 = u(f'sw0{C}', (C, C), -0.2, 0.2)\n"
+        "    W1x, W2x, W0x = split(W1), split(W2), split(W0)\n"
+        "    pack = torch.empty(L.load().xp_mlp_fused_h2_pack_bytes(C, H4, proj), dtype=torch.uint8, device='cuda')\n"
+        "    L.call('xp_mlp_fused_h2_pack', vp(W1x), vp(W2x), vp(W0x) if proj else None, vp(pack), C, H4, st)\n"
+        "    L.call('xp_mlp_fused_h2', L.ptr(X), L.ptr(T1) if proj else None, L.ptr(lw), L.ptr(lb), vp(pack), vp(W1x), vp(W2x), vp(W0x) if proj else None,\n"
+        "           L.ptr(b1), L.ptr(b2), M, C, H4, 1e-5, st)\n"
+        "    torch.cuda.synchronize(); assert bool(torch.isfinite(X).all())\n"
+        "    print('CRC', M, C, H4, proj, zlib.crc32(X.cpu().numpy().tobytes()))\n")
+    outs = {}
+    for name, env in (("default", {}), ("pingpong", {"XP_MLP_PP": "2"}), ("ws 8+4", {"XP_MLP_WS": "1"}), ("ws 4+4", {"XP_MLP_WS": "2"})):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, (name, out.stderr[-2000:])
+        outs[name] = [l for l in out.stdout.splitlines() if l.startswith("CRC")]
+        assert len(outs[name]) == 4, (name, out.stdout[-2000:])
+    for name in outs:
+        assert outs[name] == outs["default"], (name, outs[name], outs["default"])
+
+
 @pytest.mark.parametrize("M,C,N", [(300, 96, 96), (1000, 32, 64), (517, 64, 64), (4480, 96, 96), (77, 192, 192), (129, 128, 128), (260, 96, 32)])
 def test_ln_proj_h2(gpu_lib, M, C, N):
     """LayerNorm + bias-free projection in one launch (VMamba.py:1229 norm + :649 in_proj) on the split-fp16 engine."""

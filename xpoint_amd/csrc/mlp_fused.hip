@@ -646,6 +646,418 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
+
+// =============================================================================================================================================
+// Warp-specialised instance of the split-fp16 fused tail (round 5, XP_MLP_WS).  The counters of the kernel above (profiles/r5_mlp_pmc.txt) show the
+// matrix pipe busy 0.34 and the vector ALU 0.32 of the time with every wave doing BOTH kinds of work one after the other (fc1, then GELU + split, then fc2:
+// a wave's phases add up, and 2 - 3 waves per SIMD overlap them only by chance), and every 128 rows re-stream all weight images from L2.
+// Here a workgroup is NM MATRIX waves (NM / 4 per SIMD, 32 rows each: the same rows, fragments and instruction order per row as above — bit-identical
+// results) + 4 VECTOR waves (one per SIMD, serving the matrix waves of its SIMD).  Per phase q (one workgroup barrier each) a matrix wave runs fc1 of
+// chunk q and fc2 of chunk q - 2 back to back (36 MFMAs and their fragment reads, plus its share of the LDS-DMA of the two weight images of phase
+// q + 1 between them), the vector wave evaluates GELU + split of chunk q - 1.  The hidden tile travels through LDS lane to lane (the accumulator layout of
+// fc1 IS the A-operand layout of fc2, see `slice` above): H (16 f32 per lane) matrix -> vector, P (2 slabs x 2 planes x 4 registers) vector -> matrix
+// IN PLACE (the vector lane overwrites what it read; the matrix lane re-uses the buffer two phases later, after it has read P): 2 x 4 KB per matrix wave.
+// Weight images: ring of 4 slots, phase g reads slots 2g, 2g + 1 (mod 4); every matrix wave waits for its own pieces (vmcnt(0)) before the phase barrier.
+// =============================================================================================================================================
+typedef float ws_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ws_lds_write16_asm(unsigned addr, const float (&v)[16]) {
+    const ws_f4 q0 = {v[0], v[1], v[2], v[3]}, q1 = {v[4], v[5], v[6], v[7]};
+    const ws_f4 q2 = {v[8], v[9], v[10], v[11]}, q3 = {v[12], v[13], v[14], v[15]};
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\tds_write_b128 %0, %3 offset:2048\n\tds_write_b128 %0, %4 offset:3072"
+                 :: "v"(addr), "v"(q0), "v"(q1), "v"(q2), "v"(q3) : "memory");
+}
+// 4 x 16 bytes at addr + {0, 1, 2, 3} x STRIDE, complete on return
+template <int O1, int O2, int O3>
+__device__ __forceinline__ void ws_lds_read16_asm(unsigned addr, float (&v)[16]) {
+    float4 q0, q1, q2, q3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr), "n"(O1), "n"(O2), "n"(O3) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w; v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
+}
+
+#ifndef XP_WS_DBG
+#define XP_WS_DBG 0   /* timing experiments only (wrong results): 1 no GELU / split arithmetic, 2 no LDS-DMA after the first two phases, 4 no MFMA, 8 no H / P exchange, 64 stamps */
+#endif
+#if XP_WS_DBG & 64
+__device__ unsigned long long g_ws_stamps[2][4096];      // debug build only: s_memtime stamps of matrix wave 0 / vector wave 0 of workgroup 0
+extern "C" int xp_mlp_ws_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_stamps), sizeof(unsigned long long) * 2 * 4096) == hipSuccess ? 0 : -2;
+}
+#endif
+template <int C, int MODE, int NM>
+__global__ __launch_bounds__((NM + 4) * 64, 1) void mlp_ws_kernel(MlpParams p) {
+    constexpr bool PRE = MODE == 1;
+    using T = MlpTile<C, true>;
+    constexpr int ROWB = T::ROWB, KS = T::KS, NT = T::NT;
+    constexpr int NSLOT = 4;
+    constexpr int NPIECE = T::NI * 4;          // 1 KiB pieces per image
+    static_assert(NPIECE % NM == 0, "image pieces must divide among the matrix waves");
+    constexpr int NIM = NPIECE / NM;           // DMA pieces per matrix wave and image
+    constexpr int NPRE = PRE ? NT : 0;
+    constexpr int NTHREADS = (NM + 4) * 64;
+    extern __shared__ __align__(16) unsigned char lds[];       // [4 image slots][b1 / scale][1 / scale][exchange: buf 2 x NM waves x 4 KB]
+    unsigned char* const bias_lds = lds + NSLOT * T::IMGP;
+    unsigned char* const inv1_lds = bias_lds + (size_t)p.H4 * 4;
+    unsigned char* const xch = inv1_lds + (size_t)p.H4 * 4;
+    typedef __attribute__((address_space(3))) const unsigned char* lds_cptr;
+    const int lane = threadIdx.x & 63, fr = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NC = p.H4 / 32, NIMG = 2 * NC + NPRE;
+    auto xbuf = [&](int mwave, int c) { return xch + ((c & 1) * NM + mwave) * 4096 + lane * 16; };      // H(c), then P(c), of matrix wave `mwave`
+    int n_stamp = 0;
+    auto stamp = [&]() {
+#if XP_WS_DBG & 64
+        __builtin_amdgcn_sched_barrier(0);
+        if (blockIdx.x == 0 && (wave == 0 || wave == NM) && lane == 0 && n_stamp < 4096) g_ws_stamps[wave == NM][n_stamp] = __builtin_amdgcn_s_memtime();
+        ++n_stamp;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+
+    // b1 / row scale and 1 / row scale of fc1 -> LDS (as the kernel above)
+    for (int i = threadIdx.x; i < p.H4 / 4; i += NTHREADS) {
+        float4 bv = reinterpret_cast<const float4*>(p.b1)[i];
+        const float4 iv = reinterpret_cast<const float4*>(p.s1)[i];
+        reinterpret_cast<float4*>(inv1_lds)[i] = iv;
+        bv = make_float4(bv.x / iv.x, bv.y / iv.y, bv.z / iv.z, bv.w / iv.w);
+        reinterpret_cast<float4*>(bias_lds)[i] = bv;
+    }
+
+    if (wave >= NM) {
+        // ======================================================= vector wave: no VMEM in its loop, ordinary LDS accesses =======================================================
+        const int v = wave - NM;                               // serves the matrix waves v, v + 4, ... (its SIMD's)
+        auto phase_end = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        phase_end();
+        for (int gp = 0; gp < NPRE; ++gp) phase_end();
+        const int NQ = NC + 2;
+        for (int q = 0; q < NQ; ++q) {
+            stamp();                                           // V stamps per phase: 0 start, 1 H and scales read, 2 GELU + split done, 3 P written (before the barrier)
+            if (q >= 1 && q <= NC) {
+                const int c = q - 1;
+                float inv_cur[16];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 lo = *reinterpret_cast<const float4*>(inv1_lds + (32 * c + 16 * j + 8 * g) * 4);
+                    const float4 hi = *reinterpret_cast<const float4*>(inv1_lds + (32 * c + 16 * j + 8 * g + 4) * 4);
+                    inv_cur[8 * j + 0] = lo.x; inv_cur[8 * j + 1] = lo.y; inv_cur[8 * j + 2] = lo.z; inv_cur[8 * j + 3] = lo.w;
+                    inv_cur[8 * j + 4] = hi.x; inv_cur[8 * j + 5] = hi.y; inv_cur[8 * j + 6] = hi.z; inv_cur[8 * j + 7] = hi.w;
+                }
+                float h[NM / 4][16];
+#pragma unroll
+                for (int u = 0; u < NM / 4; ++u) {
+                    const unsigned char* hb = xbuf(v + 4 * u, c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 t = (XP_WS_DBG & 8) ? make_float4(lane, i, u, c) : *reinterpret_cast<const float4*>(hb + i * 1024);
+                        h[u][4 * i] = t.x; h[u][4 * i + 1] = t.y; h[u][4 * i + 2] = t.z; h[u][4 * i + 3] = t.w;
+                    }
+                }
+                stamp();
+#pragma unroll
+                for (int u = 0; u < NM / 4; ++u) {
+                    float pv[16];
+                    if (!(XP_WS_DBG & 1)) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) h[u][k] = mlp_gelu(h[u][k] * inv_cur[k]);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                unsigned p0, p1, p2;
+                                mlp_split2<true>(h[u][8 * j + 2 * qq], h[u][8 * j + 2 * qq + 1], p0, p1, p2);
+                                pv[(2 * j + 0) * 4 + qq] = __uint_as_float(p0); pv[(2 * j + 1) * 4 + qq] = __uint_as_float(p1);
+                            }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) pv[k] = h[u][k] + inv_cur[k];
+                    }
+                    if (u == NM / 4 - 1) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(pv[k]));
+                        stamp();
+                    }
+                    unsigned char* pb = xbuf(v + 4 * u, c);
+                    if (!(XP_WS_DBG & 8) || pv[0] == 123.456f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(pb + i * 1024) = make_float4(pv[4 * i], pv[4 * i + 1], pv[4 * i + 2], pv[4 * i + 3]);
+                    }
+                }
+#if XP_WS_DBG & 64
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                stamp();
+            } else { stamp(); stamp(); stamp(); }
+            if (q + 1 < NQ) phase_end();
+        }
+        return;
+    }
+
+    // ======================================================= matrix wave =======================================================
+    const int m0 = blockIdx.x * (NM * 32) + wave * 32;
+    const int mrow = (m0 + fr < p.M) ? m0 + fr : p.M - 1;      // rows past M are computed on a copy of the last row, never stored
+    // this wave's pieces (wave, wave + NM, ...) of image n -> ring slot
+    auto issue_piece = [&](int n, int slot, int i) {
+        n = n < NIMG ? n : NIMG - 1;
+        const unsigned char* base = p.Wpack + (size_t)n * T::IMGP + (wave + i * NM) * 1024;      // uniform: kept in scalar registers (no 64-bit vector pointer to spill)
+        asm volatile("" : "+s"(base));
+        const unsigned char* src = base + lane * 16;
+        unsigned char* dst = lds + slot * T::IMGP + (wave + i * NM) * 1024;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+    };
+    // the images phase gp reads: PRE phase t: W0 tile t; MLP phase q: W1(q) (q < NC) into the even slot, W2(q - 2) (q >= 2) into the odd one.
+    // Issued by the phase before, in two halves (after fc1 / inside fc2): piece `part` of NIM for each image
+    auto issue_for_phase = [&](int gp, int i) {
+        if ((XP_WS_DBG & 2) && gp >= 2) return;
+        if (gp < NPRE) { issue_piece(gp, (2 * gp) & 3, i); return; }
+        const int q = gp - NPRE;
+        if (q < NC) issue_piece(NPRE + 2 * q, (2 * gp) & 3, i);
+        if (q >= 2 && q - 2 < NC) issue_piece(NPRE + 2 * (q - 2) + 1, (2 * gp + 1) & 3, i);
+    };
+#pragma unroll
+    for (int i = 0; i < NIM; ++i) issue_for_phase(0, i);
+    float4 xv[KS][2];
+    {
+        const float* xr = p.X + (int64_t)mrow * C + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xv[s][0] = *reinterpret_cast<const float4*>(xr + 16 * s);
+            xv[s][1] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
+        }
+    }
+    frag_bits xp[KS][3];
+    auto layer_norm_split = [&]() {
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            sum += ((xv[s][0].x + xv[s][0].y) + (xv[s][0].z + xv[s][0].w)) + ((xv[s][1].x + xv[s][1].y) + (xv[s][1].z + xv[s][1].w));
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum / (float)C;
+        float q2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float dx = xv[s][e].x - mean, dy = xv[s][e].y - mean, dz = xv[s][e].z - mean, dw = xv[s][e].w - mean;
+                q2 = fmaf(dx, dx, q2); q2 = fmaf(dy, dy, q2); q2 = fmaf(dz, dz, q2); q2 = fmaf(dw, dw, q2);
+            }
+        q2 += __shfl_xor(q2, 32, 64);
+        const float rstd = 1.f / sqrtf(q2 / (float)C + p.eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g), w1 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g), c1 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g + 4);
+            float4 lo, hi;
+            lo.x = (xv[s][0].x - mean) * rstd * w0.x + c0.x; lo.y = (xv[s][0].y - mean) * rstd * w0.y + c0.y;
+            lo.z = (xv[s][0].z - mean) * rstd * w0.z + c0.z; lo.w = (xv[s][0].w - mean) * rstd * w0.w + c0.w;
+            hi.x = (xv[s][1].x - mean) * rstd * w1.x + c1.x; hi.y = (xv[s][1].y - mean) * rstd * w1.y + c1.y;
+            hi.z = (xv[s][1].z - mean) * rstd * w1.z + c1.z; hi.w = (xv[s][1].w - mean) * rstd * w1.w + c1.w;
+            mlp_split8<true>(lo, hi, xp[s]);
+        }
+    };
+    if (PRE) {
+        const float* tr = p.T1 + (int64_t)mrow * C + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 lo = *reinterpret_cast<const float4*>(tr + 16 * s), hi = *reinterpret_cast<const float4*>(tr + 16 * s + 4);
+            mlp_split8<true>(lo, hi, xp[s]);
+        }
+    } else {
+        layer_norm_split();
+    }
+    auto phase_end = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    phase_end();                                               // images of phase 0 landed, bias / scale tables written
+
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // the three products of the split-fp16 engine, smallest first: a1 b0, a0 b1, a0 b0
+    const int frag = fr * ROWB + 16 * g;
+    constexpr int FD = (KS > 2 && NM <= 4) ? 2 : 1;            // (8 matrix waves: 168 registers per wave, one slab of look-ahead — the SIMD's other matrix wave covers the latency)
+    // fc1-type phase: acc += W(image in `slot`) x xp over the KS k slabs, fragment ring FD + 1 deep (same order per accumulator as the kernel above);
+    // DMA pieces [i0, i1) of the next phase's images go out after slab KS / 2
+    auto fc1 = [&](int slot, f32x16& acc, int gp_next, int i0, int i1) {
+        const unsigned char* img = lds + slot * T::IMGP + frag;
+        frag_bits a[FD + 1][2];
+#pragma unroll
+        for (int d = 0; d < FD; ++d)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[d][pl] = *reinterpret_cast<const frag_bits*>(img + d * 32 * ROWB + pl * 32);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + FD < KS) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[(s + FD) % (FD + 1)][pl] = *reinterpret_cast<const frag_bits*>(img + (s + FD) * 32 * ROWB + pl * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                if (XP_WS_DBG & 4) { if (pp == 2) acc[0] += __uint_as_float(a[s % (FD + 1)][0][0]) * __uint_as_float(xp[s][0][0]); }
+                else acc = mlp_mfma<true>(a[s % (FD + 1)][PA[pp]], xp[s][PB[pp]], acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == KS / 2 && gp_next >= 0) {
+                for (int i = i0; i < i1; ++i) issue_for_phase(gp_next, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    unsigned hp[2][2][4];
+    auto hfrag = [&](int j, int pl) { return frag_bits{hp[j][pl][0], hp[j][pl][1], hp[j][pl][2], hp[j][pl][3]}; };
+    auto fc2 = [&](int slot, int gp_next, int i0, int i1) {
+        const unsigned char* img = lds + slot * T::IMGP + frag;
+        constexpr int FD2 = (2 * NT > 2 && NM <= 4) ? 2 : 1;
+        frag_bits b[FD2 + 1][2];
+        auto b_addr = [&](int i) { return img + ((i / NT) * C + (i % NT) * 32) * ROWB; };
+#pragma unroll
+        for (int d = 0; d < FD2; ++d)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) b[d][pl] = *reinterpret_cast<const frag_bits*>(b_addr(d) + pl * 32);
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int j = i / NT, t = i % NT;
+            if (i + FD2 < 2 * NT) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) b[(i + FD2) % (FD2 + 1)][pl] = *reinterpret_cast<const frag_bits*>(b_addr(i + FD2) + pl * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                if (XP_WS_DBG & 4) { if (pp == 2) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i % (FD2 + 1)][0][0]); }
+                else oacc[t] = mlp_mfma<true>(hfrag(j, PA[pp]), b[i % (FD2 + 1)][PB[pp]], oacc[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0 && gp_next >= 0) {
+                for (int k = i0; k < i1; ++k) issue_for_phase(gp_next, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    f32x16 h;
+    if (PRE) {
+        // x <- x + T1 W0^T, one fc1-type phase per 32 output channels (see the kernel above for the register layout)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = 0.f;
+            fc1((2 * t) & 3, h, t + 1, 0, NIM);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float* sc = p.s0 + 16 * (2 * t + jj) + 8 * g;
+                const float4 ilo = *reinterpret_cast<const float4*>(sc), ihi = *reinterpret_cast<const float4*>(sc + 4);
+                const float iv[8] = {ilo.x, ilo.y, ilo.z, ilo.w, ihi.x, ihi.y, ihi.z, ihi.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[8 * jj + e] *= iv[e];
+                float4& lo = xv[2 * t + jj][0]; float4& hi = xv[2 * t + jj][1];
+                lo.x = lo.x + h[8 * jj + 0]; lo.y = lo.y + h[8 * jj + 1]; lo.z = lo.z + h[8 * jj + 2]; lo.w = lo.w + h[8 * jj + 3];
+                hi.x = hi.x + h[8 * jj + 4]; hi.y = hi.y + h[8 * jj + 5]; hi.z = hi.z + h[8 * jj + 6]; hi.w = hi.w + h[8 * jj + 7];
+            }
+            phase_end();
+        }
+        if (m0 + fr < p.M) {
+            float* xw = p.X + (int64_t)(m0 + fr) * C + 8 * g;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                *reinterpret_cast<float4*>(xw + 16 * s) = xv[s][0];
+                *reinterpret_cast<float4*>(xw + 16 * s + 4) = xv[s][1];
+            }
+        }
+        layer_norm_split();
+    }
+    const int NQ = NC + 2;
+    for (int q = 0; q < NQ; ++q) {
+        const int gp = NPRE + q;
+        const int gp_next = q + 1 < NQ ? gp + 1 : -1;
+        stamp();                                               // M stamps per phase: 0 start, 1 fc1 done, 2 fc2 done, 3 H written + own DMA landed (before the barrier)
+        if (q >= 2) {                                          // P(q - 2): the A operand of fc2, written by the vector wave one phase ago (asm: no compiler vmcnt(0) ahead of it)
+            float pv[16];
+            if (!(XP_WS_DBG & 8)) ws_lds_read16_asm<1024, 2048, 3072>((unsigned)(size_t)(lds_cptr)xbuf(wave, q - 2), pv);
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) pv[k] = (float)(lane + k + q);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hp[j][pl][e] = __float_as_uint(pv[(2 * j + pl) * 4 + e]);
+        }
+        if (q < NC) {
+            float bv[16];
+            ws_lds_read16_asm<16, 64, 80>((unsigned)(size_t)(lds_cptr)(bias_lds + (32 * q + 8 * g) * 4), bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = bv[r];
+            fc1((2 * gp) & 3, h, q >= 2 ? gp_next : gp_next, 0, q >= 2 ? (NIM + 1) / 2 : NIM);
+        }
+        stamp();
+        if (q >= 2) fc2((2 * gp + 1) & 3, gp_next, q < NC ? (NIM + 1) / 2 : 0, NIM);
+        stamp();
+        if (q < NC && !(XP_WS_DBG & 8)) {
+            float hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = h[r];
+            ws_lds_write16_asm((unsigned)(size_t)(lds_cptr)xbuf(wave, q), hv);
+        }
+#if XP_WS_DBG & 64
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        stamp();
+        if (q + 1 < NQ) phase_end();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: x[m][n] = x[m][n] + (acc * 1/scale + b2[n]); lane = column n, registers = rows (r&3) + 8(r>>2) + 4g ----
+    float* xb = p.X + (int64_t)m0 * C;
+    auto epilogue = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 32 + fr;
+            const float bi = p.b2[col];
+            const float ws = p.s2[col];
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float* rp = xb + ((INTERIOR || m0 + rl < p.M) ? rl : 0) * C + col;
+                rv[r] = PRE ? __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *rp;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float v = oacc[t][r] * ws + bi;
+                if (INTERIOR || m0 + rl < p.M) xb[rl * C + col] = rv[r] + v;
+            }
+        }
+    };
+    if (m0 + 32 <= p.M) epilogue(std::true_type{}); else if (m0 < p.M) epilogue(std::false_type{});
+}
+
+template <int C, int MODE, int NM>
+int launch_mlp_ws(const MlpParams& p, hipStream_t s) {
+    using T = MlpTile<C, true>;
+    const size_t lds_bytes = 4 * (size_t)T::IMGP + (size_t)p.H4 * 8 + (size_t)NM * 8192;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ws_kernel<C, MODE, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
+    std::string tag = std::string(MODE == 1 ? "proj_mlp_fused" : "mlp_fused") + "_h2_c" + std::to_string(C);
+    if (by_shape) tag += "_M" + std::to_string(p.M);
+    XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4 + (MODE == 1 ? 2.0 * p.M * C * (double)C : 0.0), (MODE == 1 ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
+    hipLaunchKernelGGL((mlp_ws_kernel<C, MODE, NM>), dim3(xp_cdiv(p.M, NM * 32)), dim3((NM + 4) * 64), lds_bytes, s, p);
+    XP_LAUNCH_CHECK();
+    return XP_OK;
+}
+// LDS of the warp-specialised instance: 4 image slots + two H4-float tables + 8 KB exchange per matrix wave must fit 160 KB
+template <int C, int NM>
+bool mlp_ws_fits(int H4) { return 4 * (size_t)MlpTile<C, true>::IMGP + (size_t)H4 * 8 + (size_t)NM * 8192 <= 160 * 1024; }
+
 template <int C, int NW, int MODE, int NP, bool H2 = false, bool PP = false>
 int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     constexpr bool PRE = MODE == 1;
@@ -676,7 +1088,7 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     // second one) puts two waves on every SIMD; the narrower ones run two 4-wave workgroups per CU.
     static const bool nw4 = getenv("XP_MLP_H2_NW4") != nullptr && atoi(getenv("XP_MLP_H2_NW4")) != 0;      // A/B: 0.716 (8 waves) vs 0.747 ms (4 waves) per two launches
     // round 5: the ping-pong chunk loop (8-wave workgroups, the two waves of a SIMD one phase apart) for the MLP instances at C = 96 and C = 192; XP_MLP_PP=0: the
-    // lockstep loop (A/B).  Bit-identical results (tests/test_gpu_h2.py::test_mlp_fused_h2_pingpong_bits).
+    // lockstep loop (A/B).  Bit-identical results (tests/test_gpu_h2.py::test_mlp_fused_h2_schedules_are_bit_identical).
     // OFF by default (XP_MLP_PP = 1: C = 192, 2: also C = 96).  Measured (profiles/r5_mlp_pingpong.txt): bit-identical, C = 192 246 - 258 vs 253 - 267 us alone,
     // C = 96 293 - 304 vs 261 - 279 us (its 4-wave workgroups run three per CU; the 8-wave ping-pong workgroup runs alone), and the step does not move (1 709 - 1 715
     // vs 1 702 - 1 712 pairs/s on one box): every phase of a wave is latency-, not throughput-bound (stamps: F1 1 250 cycles for 576 of matrix pipe, V 1 950 for
@@ -685,6 +1097,11 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     const bool pp_on = pp_mode >= (C == 192 ? 1 : 2);
     constexpr bool PPOK = MODE != 2 && (C == 96 || C == 192);
     if (p.s2 || (MODE == 2 && p.s0)) {
+        if constexpr (MODE != 2 && C == 96) {
+            static const int ws_mode = getenv("XP_MLP_WS") ? atoi(getenv("XP_MLP_WS")) : 0;      // warp-specialised instance (see mlp_ws_kernel): 1 = 8 + 4 waves, 2 = 4 + 4
+            if (ws_mode == 1 && mlp_ws_fits<C, 8>(p.H4)) return launch_mlp_ws<C, MODE, 8>(p, s);
+            if (ws_mode == 2 && mlp_ws_fits<C, 4>(p.H4)) return launch_mlp_ws<C, MODE, 4>(p, s);
+        }
         if (C == 192 && !nw4) {
             // One 256-row workgroup per CU: M = 76 800 rows (16 images of 480 x 640 at stage 1) is 300 workgroups = one full round of the chip + 44 workgroups
             // that take as long again.  When the last round would be less than half full, its rows run as 128-row (4-wave) workgroups in a second launch —

@@ -30,6 +30,7 @@ static const XpKnob kXpKnobs[] = {
     {"XP_NO_LN_PROJ_F16", "model.cpp", "fp16 class: LayerNorm and in_proj as two launches"},
     {"XP_NO_FUSED_MLP_F16", "model.cpp", "fp16 class: 1 two-GEMM MLP everywhere, 2 fused MLP behind a separate LayerNorm"},
     {"XP_MLP_PP", "mlp_fused.hip", "ping-pong chunk loop of the split-fp16 fused tail: 0 (default) off, 1 C = 192, 2 also C = 96 (profiles/r5_mlp_pingpong.txt)"},
+    {"XP_MLP_WS", "mlp_fused.hip", "warp-specialised instance of the split-fp16 fused tail at C = 96 (experiment, bit-identical, slower: profiles/r5_mlp_warp_specialised.txt): 1 = 8 matrix + 4 vector waves, 2 = 4 + 4"},
     {"XP_MLP_TAIL", "mlp_fused.hip", "0: no separate 4-wave launch for a last round less than half full (C = 192)"},
     {"XP_MLP_NW8", "mlp_fused.hip", "1: 8-wave workgroups in the x3 fused tail (C <= 96)"},
     {"XP_MLP_H2_NW4", "mlp_fused.hip", "1: 4-wave workgroups in the h2 fused tail at C = 192"},
