@@ -219,7 +219,7 @@ def test_bench_pmc_lookup_covers_the_committed_counter_files():
     spec.loader.exec_module(bench)          # bench.py imports no torch at module level (the launcher parent must stay GPU-free)
     for fn in ("pmc_traffic.json", "pmc_mfma.json"):
         names = list(json.load(open(os.path.join(root, "profiles", fn)))["kernels"])
-        for tag in ("gemm_h2p_mfma_128x128", "gemm_h2_mfma_128x128", "gemm_h2_mfma_64x128", "proj_mlp_fused_h2_c192", "proj_mlp_fused_h2_c96",
+        for tag in ("gemm_ring_h2s_256x256", "gemm_ring_h2s_256x128", "gemm_ring_h2s_128x128", "gemm_h2_mfma_128x128", "gemm_h2_mfma_64x128", "proj_mlp_fused_h2_c192", "proj_mlp_fused_h2_c96",
                     "conv3x3_h2r_mfma_128x96", "conv3x3_h2r_mfma_128x128"):
             assert bench.pmc_kernel_for_tag(tag, names) in names, (fn, tag)
     # the fast mixed-precision class has its own counter files (bench.py --precision-class amp16f reads pmc_*_amp16f.json)
