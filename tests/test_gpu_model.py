@@ -738,6 +738,32 @@ def test_fp16_range_overflow_falls_back_to_x3(gpu_lib):
             got = pipe_a.fetch()
         assert net.effective_gemm_mode() == "x3" and int(pipe_a.status_word().item()) == 0
         assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"]) and got[0]["match_q"].tolist() == ref[0]["match_q"].tolist()
+        # a trip judged against the engine its forwards were ENQUEUED with: B's step ran on h2 and tripped; before B looks, A's trip has already
+        # switched the shared model to x3 — B must still repair (re-run on x3, no second warning), not raise "non-finite on x3"; eager and captured
+        net = _net(cfg, sd)
+        pipe_a = PairPipeline(net, B, H, W, cap=4096)
+        pipe_b = PairPipeline(net, B, H, W, cap=4096)
+        pipe_b.run(*args)
+        pipe_a.run(*args)
+        torch.cuda.synchronize()
+        assert int(pipe_a.status_word().item()) != 0 and int(pipe_b.status_word().item()) != 0
+        with pytest.warns(RuntimeWarning, match="re-running on gemm_mode 'x3'"):
+            pipe_a.fetch()
+        assert net.effective_gemm_mode() == "x3" and int(pipe_b.status_word().item()) != 0
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)      # the model is on x3 already: B repairs silently
+            got = pipe_b.fetch()
+        assert pipe_b.repaired and int(pipe_b.status_word().item()) == 0
+        assert torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"]) and got[0]["match_q"].tolist() == ref[0]["match_q"].tolist()
+        pipe_b.run(*args)
+        got = pipe_b.fetch()                                    # later steps: x3 from the start, nothing to repair
+        assert not pipe_b.repaired and torch.equal(got[0]["kp_optical"], ref[0]["kp_optical"])
+        # (captured pipelines: every replay is recorded with the engine its graphs were captured on)
+        step = pipe_b.capture(*args)
+        assert pipe_b._graph_engine == "x3"
+        step(*args)
+        assert pipe_b._engine_enqueued == "x3" and not pipe_b._h2_pending
         # genuinely non-finite weights: no engine can help -> raise, on every engine
         sd_nan = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
         sd_nan["encoder.layers.1.blocks.0.mlp.fc1.bias"][3] = float("nan")

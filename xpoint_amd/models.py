@@ -351,19 +351,24 @@ class XPoint(torch.nn.Module):
     _STATUS_BITS = ((1, "encoder output non-finite or beyond the dense engine's operand range"), (2, "non-finite heat-map logit"),
                     (4, "non-finite descriptor element"))
 
-    def handle_status(self, st: int, where: str) -> bool:
+    def handle_status(self, st: int, where: str, engine: str = None) -> bool:
         """Host policy for a non-zero status: on the split-fp16 engine switch this weight set to "x3" (warning) and return True = the
-        caller re-runs; on any other engine the outputs are genuinely non-finite: raise."""
+        caller re-runs; on any other engine the outputs are genuinely non-finite: raise.
+        engine: the engine the reporting forwards were ENQUEUED with (stream-ordered callers: a pipeline's steps in flight or its captured graphs) —
+        default: the model's engine now.  A trip of forwards enqueued on "h2" is recoverable also when another caller has switched the model to
+        "x3" in the meantime: no second switch, no second warning, the caller re-runs."""
         if st == 0:
             return False
         what = "; ".join(t for b, t in self._STATUS_BITS if st & b)
-        if self.effective_gemm_mode() == "h2":
-            import warnings
-            warnings.warn(f"xpoint_amd.XPoint ({where}): {what} on the split-fp16 dense engine (operands must stay below 65504); "
-                          "re-running on gemm_mode 'x3' (split-bf16, no range limit) and keeping it for this weight set", RuntimeWarning, stacklevel=3)
-            self._h2_off = True
+        eng = engine if engine is not None else self.effective_gemm_mode()
+        if eng == "h2":
+            if self.gemm_mode == "h2" and not self._h2_off:
+                import warnings
+                warnings.warn(f"xpoint_amd.XPoint ({where}): {what} on the split-fp16 dense engine (operands must stay below 65504); "
+                              "re-running on gemm_mode 'x3' (split-bf16, no range limit) and keeping it for this weight set", RuntimeWarning, stacklevel=3)
+                self._h2_off = True
             return True
-        raise RuntimeError(f"xpoint_amd.XPoint ({where}): {what} on gemm_mode {self.effective_gemm_mode()!r} — the weights or the input produce "
+        raise RuntimeError(f"xpoint_amd.XPoint ({where}): {what} on gemm_mode {eng!r} — the weights or the input produce "
                            "non-finite activations")
 
     def forward_raw(self, images: torch.Tensor, want_prob=True, want_desc=True, want_logits=False, out=None, workspace=None,

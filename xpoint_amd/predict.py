@@ -264,6 +264,7 @@ class PairPipeline:
             self._stage_inputs(k, optical, thermal, None, None)
         ws = self.alt_ws[k] if getattr(self, "alternate", False) else None
         # check=False: stream-ordered, no host synchronisation here; the forward's status word is read in verify() / fetch() / download_async()
+        self._note_engine()
         self.raw_b[k] = self.net.forward_raw(self.images_b[k], want_prob=True, want_desc=True, out=self.raw_b[k], workspace=ws, is_optical=self._flags(),
                                              check=False, **self._status_kw())
 
@@ -341,6 +342,7 @@ class PairPipeline:
                 def replay(optical, thermal, mask_optical=None, mask_thermal=None):
                     self._stage_inputs(0, optical, thermal, mask_optical, mask_thermal)
                     self._last = (0, mask_optical is not None)
+                    self._note_engine(self._graph_engine)
                     self._graphs.replay()
                     return self
                 return replay
@@ -354,6 +356,7 @@ class PairPipeline:
                     cur.wait_event(self.post_done[k])
                     self._stage_inputs(k, optical, thermal, mask_optical, mask_thermal)
                     enc_g, pg = self._graphs[k]
+                    self._note_engine(self._graph_engine)
                     for h, stream in enumerate(self._streams_of(k)):
                         stream.wait_stream(cur)
                         with torch.cuda.stream(stream):
@@ -374,12 +377,15 @@ class PairPipeline:
     def _capture_graphs(self):
         """(Re)capture the step's graphs with the dense engine in force now; buffers exist (warm-up done), device synchronised."""
         masked = self._capture_masked
+        self._graph_engine = self.net.effective_gemm_mode() if hasattr(self.net, "effective_gemm_mode") else None      # what every replay enqueues (_note_engine)
+        pend = getattr(self, "_h2_pending", False)
         if not self.overlap:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._encode(0, None, None)
                 self._post(0, masked, None)
             self._graphs = g
+            self._h2_pending = pend                             # (capturing enqueues nothing)
             return
         S = max(self.split_encoder, 1)
         graphs = []
@@ -403,6 +409,7 @@ class PairPipeline:
                 self._post(k, masked, None)
             graphs.append((enc_g, pg))
         self._graphs = graphs
+        self._h2_pending = pend                                 # (capturing enqueues nothing)
         torch.cuda.synchronize()
 
     def status_word(self):
@@ -419,6 +426,15 @@ class PairPipeline:
             self._status_ok = hasattr(self.net, "status_word") and "status" in inspect.signature(self.net.forward_raw).parameters
         return {"status": self.status_word()} if self._status_ok else {}
 
+    def _note_engine(self, engine=None):
+        """Record the dense engine of the forwards this pipeline enqueues (eager: the model's engine now; graph replay: the engine the graphs were
+        captured on): a status trip is judged against THAT engine, not against whatever the shared model has been switched to since (_settle_engine)."""
+        if engine is None:
+            engine = self.net.effective_gemm_mode() if hasattr(self.net, "effective_gemm_mode") else None
+        if engine == "h2":
+            self._h2_pending = True
+        self._engine_enqueued = engine
+
     def _settle_engine(self):
         """After a device-wide synchronisation: read and clear the forward status word.  Non-zero on the split-fp16 engine = an operand left
         the fp16 range: the model switches to "x3" for this weight set (warning), captured graphs are re-captured on it, and the latest call
@@ -429,9 +445,14 @@ class PairPipeline:
         word = self.status_word()
         st = int(word.item())
         if st == 0:
+            self._h2_pending = False                           # (device-wide synchronisation done: nothing enqueued on h2 is still in flight)
             return False
         word.zero_()
-        self.net.handle_status(st, "PairPipeline")          # raises unless the h2 -> x3 switch applies
+        # judged against the engine the pending forwards were enqueued with (some step in flight on "h2" -> recoverable, even when another user of
+        # the same model has already switched it to "x3"); raises unless the h2 -> x3 switch applies
+        pending = "h2" if getattr(self, "_h2_pending", False) else getattr(self, "_engine_enqueued", None)
+        self._h2_pending = False
+        self.net.handle_status(st, "PairPipeline", pending)
         if self._graphs is not None:
             self._capture_graphs()
         if self._last is not None:
@@ -441,6 +462,7 @@ class PairPipeline:
             torch.cuda.synchronize()
             st = int(word.item())
             word.zero_()
+            self._h2_pending = False
             self.net.handle_status(st, "PairPipeline, second run")
         return True
 
