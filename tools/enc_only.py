@@ -8,7 +8,7 @@ H, W, n = 480, 640, 16
 cfg = synth.xpoint_exp1_config(H, W)
 net = models.XPoint(cfg); net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True); net.to("cuda").eval()
 img = torch.rand(n, 1, H, W, device="cuda")
-for S in (1, 2, 3):
+for S in (1, 2, 3, 4):
     streams = [torch.cuda.Stream() for _ in range(S)]
     ws = [torch.empty(net.workspace_bytes(n, H, W), dtype=torch.uint8, device="cuda") for _ in range(S)]
     outs = [None] * S
