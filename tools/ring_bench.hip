@@ -106,6 +106,9 @@ std::vector<Variant> variants() {
         VARIANT("128x256 w32x128 S3", 2, 2, 1, 4, PL, 3),
         VARIANT("256x256 w64x128 S2", 2, 2, 2, 4, PL, 2),
         VARIANT("128x64 w32x32 S4", 2, 2, 1, 1, PL, 4),
+        VARIANT("128x128 w64x32 S2 (2 WG/CU)", 1, 4, 2, 1, PL, 2),
+        VARIANT("128x128 w32x64 S2 (2 WG/CU)", 2, 2, 1, 2, PL, 2),
+        VARIANT("128x64 w32x32 S2 (3 WG/CU)", 2, 2, 1, 1, PL, 2),
     };
 }
 
