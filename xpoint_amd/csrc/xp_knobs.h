@@ -49,6 +49,7 @@ static const XpKnob kXpKnobs[] = {
     {"XP_LN_COVER", "elementwise.hip", "1: LayerNorm lane mapping that covers 96 / 192 / 384-channel rows exactly (different sum order: moves near-ties)"},
     {"XP_NMS_SCHED", "postproc.hip", "NMS local-iteration schedule"},
     {"XP_NMS_SWEEP", "postproc.hip", "NMS sweep count"},
+    {"XP_NMS_BANDS", "postproc.hip", "n > 1: at least n row bands (workgroups) per image in the NMS finisher instead of one (latency of the step, not its throughput)"},
     {"XP_NMS_WIDE_ROUNDS", "postproc.hip", "wide suppression rounds ahead of the NMS finisher"},
     // ---- profiling
     {"XP_PROF_SHAPES", "*.hip", "1: per-shape tags in the HIP-event breakdown (xp_prof_*)"},
