@@ -453,6 +453,24 @@ int xp_find_homography(const float* src, const float* dst, const int* counts, in
                        size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Perspective warp — the reference's registration output:
+ *     cv2.warpPerspective(im_optical, H_est, im_optical.shape[:2][::-1], borderMode=cv2.BORDER_CONSTANT)
+ * (predict_align_image_pair.py:308, demo.py:225-249): INTER_LINEAR, border value 0, M (batch, 9) f64 ON THE DEVICE = the forward
+ * map src -> dst (what xp_find_homography writes), inverted on the device by the closed 3 x 3 form unless inverse_map != 0
+ * (cv2.WARP_INVERSE_MAP).  Arithmetic = OpenCV's documented fixed-point scheme (source coordinates rounded to 1/32 pixel in double,
+ * u8: 15-bit integer weights; f32: the same 1/32 fractions as float weights) — OpenCV is absent here: parity unpinned, the oracle
+ * (oracle/csrc/oracle_kernels.c: xo_warp_perspective_u8 / _f32) states the same scheme and the GPU tests demand equality with it.
+ *   src (batch, Hs, Ws, channels), dst (batch, Hd, Wd, dst_channels), channel-interleaved; dst_channels == channels, or a
+ *   1-channel source replicated into dst_channels (the reference warps cv2.cvtColor(gray, COLOR_GRAY2RGB)).
+ *   dtype XP_WARP_U8: u8 -> u8;  XP_WARP_F32: f32 -> f32;  XP_WARP_F32_AS_U8: f32 source in [0, 1] quantised on load as
+ *   (np.clip(img, 0, 1) * 255.0).astype(np.uint8) (predict_align_image_pair.py:271) -> u8.  Hs, Ws < 32768. */
+#define XP_WARP_U8 0
+#define XP_WARP_F32 1
+#define XP_WARP_F32_AS_U8 2
+int xp_warp_perspective(const void* src, void* dst, const double* M, int batch, int Hs, int Ws, int Hd, int Wd, int channels,
+                        int dst_channels, int dtype, int inverse_map, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; replaces the
  * reference's wall-clock brackets, benchmark_evaluation.py:12-37).  Off by default.  xp_prof_filter(tag)
  * restricts recording to one kernel tag (NULL/"" = all).  xp_prof_count / xp_prof_get synchronise on the

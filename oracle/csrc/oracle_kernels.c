@@ -196,3 +196,100 @@ int64_t xo_threshold_pairs(const float* d1, int64_t n1, const float* d2, int64_t
     }
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Perspective warp.  Reference call: predict_align_image_pair.py:308 (and demo.py:225-249)
+ *     cv2.warpPerspective(im_optical, H_est, (W, H), borderMode=cv2.BORDER_CONSTANT)
+ * PARITY UNPINNED: OpenCV (opencv-python==4.10.0.82, requirements.txt:2) is absent from /root/reference and from the
+ * image; this restates the published algorithm of its imgproc module (imgwarp.cpp: warpPerspective ->
+ * WarpPerspectiveInvoker -> remap, INTER_LINEAR, INTER_BITS = 5, INTER_REMAP_COEF_BITS = 15):
+ *   - M (forward map, src -> dst) is inverted by the closed 3x3 form of cv::invert (det and cofactors in double,
+ *     multiplied by 1/det; a singular M gives the zero matrix) unless inverse_map;
+ *   - destination pixels are walked in blocks bw0 = min(1024 / min(16, H), W) wide; per row of a block
+ *         X0 = M0*x + M1*y + M2 (x = first column of the block), likewise Y0, W0;   per column x1 of the block
+ *         W = W0 + M6*x1;  W = W ? 32/W : 0;  fX = max(INT_MIN, min(INT_MAX, (X0 + M0*x1)*W));  X = cvRound(fX)  (lrint)
+ *         sx = saturate_cast<short>(X >> 5), alpha = (Y & 31)*32 + (X & 31)
+ *   - remapBilinear, BORDER_CONSTANT, borderValue 0: the 2x2 taps at (sx, sy); taps outside the image read 0.
+ *         u8 : integer weights itab = saturate_cast<short>(w * 32768) — for the bilinear table exact integers
+ *              (32-ay | ay)*(32-ax | ax)*32 that sum to 32768 — and FixedPtCast: (sum + 16384) >> 15
+ *         f32: float weights (1-fy)*(1-fx), (1-fy)*fx, fy*(1-fx), fy*fx; S0*w0 + S1*w1 + S2*w2 + S3*w3 left to right
+ * src (Hs, Ws, C) interleaved, dst (Hd, Wd, C).  Compiled with -ffp-contract=off: every product and sum rounds separately.
+ * ---------------------------------------------------------------------------------------- */
+static void xo_warp_matrix(const double* S, int inverse_map, double* t) {
+    if (inverse_map) { for (int k = 0; k < 9; ++k) t[k] = S[k]; return; }
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (d != 0.0) {
+        d = 1.0 / d;
+        t[0] = (S[4] * S[8] - S[5] * S[7]) * d; t[1] = (S[2] * S[7] - S[1] * S[8]) * d; t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+        t[3] = (S[5] * S[6] - S[3] * S[8]) * d; t[4] = (S[0] * S[8] - S[2] * S[6]) * d; t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+        t[6] = (S[3] * S[7] - S[4] * S[6]) * d; t[7] = (S[1] * S[6] - S[0] * S[7]) * d; t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    } else {
+        for (int k = 0; k < 9; ++k) t[k] = 0.0;
+    }
+}
+
+static void xo_warp_coords(const double* m, int x, int y, int bw, int* sx, int* sy, int* ax, int* ay) {
+    const int xb = x / bw * bw, x1 = x - xb;
+    const double X0 = m[0] * xb + m[1] * y + m[2], Y0 = m[3] * xb + m[4] * y + m[5], W0 = m[6] * xb + m[7] * y + m[8];
+    double W = W0 + m[6] * x1;
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    double fX = (X0 + m[0] * x1) * W, fY = (Y0 + m[3] * x1) * W;
+    fX = fX < 2147483647.0 ? fX : 2147483647.0; fX = fX > -2147483648.0 ? fX : -2147483648.0;      /* NaN -> INT_MIN by these comparisons ... */
+    fY = fY < 2147483647.0 ? fY : 2147483647.0; fY = fY > -2147483648.0 ? fY : -2147483648.0;
+    if (fX != fX) fX = 0.0;                                                                           /* ... so map it to 0 (the device's conversion of NaN) explicitly */
+    if (fY != fY) fY = 0.0;
+    const int X = (int)lrint(fX), Y = (int)lrint(fY);
+    int a = X >> 5, b = Y >> 5;
+    *sx = a < -32768 ? -32768 : (a > 32767 ? 32767 : a);
+    *sy = b < -32768 ? -32768 : (b > 32767 ? 32767 : b);
+    *ax = X & 31; *ay = Y & 31;
+}
+
+static int xo_warp_bw(int Hd, int Wd) { const int bh = Hd < 16 ? Hd : 16; const int bw = 1024 / bh; return bw < Wd ? bw : Wd; }
+
+void xo_warp_perspective_u8(const uint8_t* src, uint8_t* dst, const double* M, int64_t Hs, int64_t Ws, int64_t Hd, int64_t Wd, int64_t C,
+                            int inverse_map) {
+    double m[9];
+    xo_warp_matrix(M, inverse_map, m);
+    const int bw = xo_warp_bw((int)Hd, (int)Wd);
+#pragma omp parallel for schedule(static)
+    for (int64_t y = 0; y < Hd; ++y)
+        for (int64_t x = 0; x < Wd; ++x) {
+            int sx, sy, ax, ay;
+            xo_warp_coords(m, (int)x, (int)y, bw, &sx, &sy, &ax, &ay);
+            const int w[4] = {(32 - ay) * (32 - ax) * 32, (32 - ay) * ax * 32, ay * (32 - ax) * 32, ay * ax * 32};
+            for (int64_t c = 0; c < C; ++c) {
+                int sum = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t px = sx + (k & 1), py = sy + (k >> 1);
+                    const int v = (px >= 0 && px < Ws && py >= 0 && py < Hs) ? src[(py * Ws + px) * C + c] : 0;
+                    sum += v * w[k];
+                }
+                const int o = (sum + 16384) >> 15;
+                dst[(y * Wd + x) * C + c] = (uint8_t)(o > 255 ? 255 : o);
+            }
+        }
+}
+
+void xo_warp_perspective_f32(const float* src, float* dst, const double* M, int64_t Hs, int64_t Ws, int64_t Hd, int64_t Wd, int64_t C,
+                             int inverse_map) {
+    double m[9];
+    xo_warp_matrix(M, inverse_map, m);
+    const int bw = xo_warp_bw((int)Hd, (int)Wd);
+#pragma omp parallel for schedule(static)
+    for (int64_t y = 0; y < Hd; ++y)
+        for (int64_t x = 0; x < Wd; ++x) {
+            int sx, sy, ax, ay;
+            xo_warp_coords(m, (int)x, (int)y, bw, &sx, &sy, &ax, &ay);
+            const float fx = (float)ax * 0.03125f, fy = (float)ay * 0.03125f;
+            const float w[4] = {(1.f - fy) * (1.f - fx), (1.f - fy) * fx, fy * (1.f - fx), fy * fx};
+            for (int64_t c = 0; c < C; ++c) {
+                float t[4];
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t px = sx + (k & 1), py = sy + (k >> 1);
+                    t[k] = (px >= 0 && px < Ws && py >= 0 && py < Hs) ? src[(py * Ws + px) * C + c] : 0.f;
+                }
+                dst[(y * Wd + x) * C + c] = ((t[0] * w[0] + t[1] * w[1]) + t[2] * w[2]) + t[3] * w[3];
+            }
+        }
+}

@@ -610,3 +610,30 @@ def gray_to_float(gray_u8):
     """numpy's `gray / 255.0` of the reference (float64 division) as the float32 the network receives."""
     import numpy as np
     return (np.asarray(gray_u8).astype(np.float64) / 255.0).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Perspective warp (predict_align_image_pair.py:308 cv2.warpPerspective(im, H_est, (W, H), borderMode=BORDER_CONSTANT)).
+# PARITY UNPINNED: OpenCV is absent; oracle/csrc/oracle_kernels.c restates its documented INTER_LINEAR fixed-point scheme.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def warp_perspective(img, M, dsize=None, inverse_map=False):
+    """img: (H, W) or (H, W, C) numpy uint8 / float32; M (3, 3) forward map src -> dst (x, y); dsize = (width, height) as in cv2."""
+    import numpy as np
+    img = np.ascontiguousarray(img)
+    squeeze = img.ndim == 2
+    a = img[..., None] if squeeze else img
+    Hs, Ws, C = a.shape
+    Wd, Hd = (Ws, Hs) if dsize is None else (int(dsize[0]), int(dsize[1]))
+    Mc = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(9))
+    out = np.zeros((Hd, Wd, C), dtype=a.dtype)
+    a = np.ascontiguousarray(a)
+    fn = {np.dtype(np.uint8): lib().xo_warp_perspective_u8, np.dtype(np.float32): lib().xo_warp_perspective_f32}[a.dtype]
+    fn(_p(a), _p(out), _p(Mc), ctypes.c_int64(Hs), ctypes.c_int64(Ws), ctypes.c_int64(Hd), ctypes.c_int64(Wd), ctypes.c_int64(C),
+       ctypes.c_int(1 if inverse_map else 0))
+    return out[..., 0] if squeeze else out
+
+
+def to_u8_image(img01):
+    """predict_align_image_pair.py:271: (np.clip(img, 0.0, 1.0) * 255.0).astype(np.uint8) on a float32 image."""
+    import numpy as np
+    return (np.clip(np.asarray(img01, dtype=np.float32), 0.0, 1.0) * 255.0).astype(np.uint8)

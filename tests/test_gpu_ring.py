@@ -190,9 +190,9 @@ def test_ss2d_core_p32_output_matches_f32_bits(gpu_lib, B, H, W, C, R):
 
 @pytest.mark.parametrize("M,N,K,act,res,c_f32", [(19200, 384, 384, 0, False, 0), (2500, 1536, 384, 1, False, 0), (2400, 384, 1536, 0, True, 0),
                                                  (4800, 768, 768, 0, True, 0), (1000, 3072, 768, 1, False, 0), (777, 384, 448, 0, False, 1)])
-def test_gemm_f16_ring_instance_bits(gpu_lib, M, N, K, act, res, c_f32):
-    """xp_gemm_nt_f16 on the long-K layers (the ring instance with XP_RING_F16=1, else the round-4 tile kernel: same fp16 products, same slab / k-step
-    order, same rounding points — the next test compares their bits) against the rounding recipe evaluated in float64"""
+def test_gemm_f16_long_k_layers_bits(gpu_lib, M, N, K, act, res, c_f32):
+    """xp_gemm_nt_f16 on the long-K layers of the deep stages against the rounding recipe evaluated in float64 (round 6: the one-product ring
+    instance that could take these layers — bit-identical, slower in the step — was removed from the product; tools/ring_bench.hip still builds it)"""
     L = _lib()
     A = _u(f"fA{M}{N}{K}", (M, K)).half(); Wt = _u(f"fW{M}{N}{K}", (N, K), -0.1, 0.1).half(); bias = _u(f"fb{M}{N}{K}", (N,))
     R = _u(f"fr{M}{N}{K}", (M, N)).half() if res else None
@@ -215,24 +215,3 @@ def test_gemm_f16_ring_instance_bits(gpu_lib, M, N, K, act, res, c_f32):
     bad = (got - ref).abs() > tol
     assert int(bad.sum()) == 0, (int(bad.sum()), float((got - ref).abs().max()))
     assert float((got != ref).float().mean()) <= 0.02          # and almost everywhere the same bits
-
-
-def test_gemm_f16_ring_vs_tile_kernel_bits(gpu_lib):
-    """the ring instance (XP_RING_F16=1, read once: child processes) and the round-4 tile kernel produce the same bits"""
-    import subprocess, sys
-    code = (
-        "import ctypes, torch, zlib\n"
-        "from xpoint_amd import _lib as L, synth\n"
-        "M, N, K = 2500, 1536, 384\n"
-        "A = torch.from_numpy(synth.uniform('tA', (M, K), -1.0, 1.0)).half().cuda(); W = torch.from_numpy(synth.uniform('tW', (N, K), -0.1, 0.1)).half().cuda()\n"
-        "b = torch.from_numpy(synth.uniform('tb', (N,), -1.0, 1.0)).cuda(); C = torch.empty((M, N), device='cuda', dtype=torch.float16)\n"
-        "vp = lambda t: ctypes.c_void_p(t.data_ptr())\n"
-        "L.call('xp_gemm_nt_f16', vp(A), vp(W), vp(C), 0, L.ptr(b), None, None, None, M, N, K, K, N, N, 1, L.current_stream())\n"
-        "torch.cuda.synchronize(); print('CRC', zlib.crc32(C.cpu().numpy().tobytes()))\n")
-    crcs = []
-    for ring in ("1", "0"):
-        env = dict(os.environ, XP_RING_F16=ring)
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert out.returncode == 0, out.stderr[-2000:]
-        crcs.append([l for l in out.stdout.splitlines() if l.startswith("CRC")][-1])
-    assert crcs[0] == crcs[1], crcs

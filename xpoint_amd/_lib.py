@@ -101,6 +101,7 @@ _SIGNATURES = {
     "xp_points_min_dist": [c_p, c_i, c_p, c_i, c_p, c_p],
     "xp_gather_match_points": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "xp_find_homography": [c_p, c_p, c_p, c_i, c_i, c_f, c_i, ctypes.c_uint, c_p, c_p, c_p, c_p, c_sz, c_p],
+    "xp_warp_perspective": [c_p, c_p, c_p] + [c_i] * 9 + [c_p],
     "xp_prof_enable": [c_i],
     "xp_prof_filter": [ctypes.c_char_p],
     "xp_prof_reset": [],

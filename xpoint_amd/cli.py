@@ -63,7 +63,8 @@ def main(argv=None):
     ap.add_argument('-v', '--version', default='latest', help='Model version (name of the param file), none for no weights')
     ap.add_argument('-i', '--index', default=0, type=int, help='Index of the first sample')
     ap.add_argument('-n', '--count', default=1, type=int, help='Number of consecutive samples')
-    ap.add_argument('-e', dest='evaluation', action='store_true', help='align: also estimate the homography of every pair')
+    ap.add_argument('-e', dest='evaluation', action='store_true', help='align: also estimate the homography of every pair and warp the optical image with it')
+    ap.add_argument('--save-warped', default=None, metavar='DIR', help='align -e: write the warped optical image of every sample to DIR/<name>_warped.png')
     ap.add_argument('-s', '--seed', default=0, type=int, help='Seed of the random generators')
     ap.add_argument('-o', '--output', default=None, help='write keypoints / matches of the samples to this .npz')
     ap.add_argument('--device', default='cuda:0')
@@ -103,6 +104,13 @@ def main(argv=None):
                 out[f"{idx}/matches"] = np.array([(m.queryIdx, m.trainIdx) for m in r['matches']], dtype=np.int64).reshape(-1, 2)
             if 'H_est' in r:
                 out[f"{idx}/H_est"] = np.asarray(r['H_est'])
+            if 'warped_optical' in r:
+                out[f"{idx}/warped_optical"] = r['warped_optical'].cpu().numpy()
+                if args.save_warped:
+                    import os
+                    from PIL import Image
+                    os.makedirs(args.save_warped, exist_ok=True)
+                    Image.fromarray(out[f"{idx}/warped_optical"]).save(os.path.join(args.save_warped, f"{name}_warped.png"))
     print(f"{args.flow}: {sum(1 for k in out if k.endswith('/kp_optical'))} sample(s), {t_total * 1e3:.1f} ms")
     if args.output:
         np.savez(args.output, **out)

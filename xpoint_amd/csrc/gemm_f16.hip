@@ -24,11 +24,6 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f16acc __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* f16_lds_ptr_t;
 
-// ring_core.h instance for the long-K layers of the deep stages (gemm_ring.hip)
-bool xp_ring_f16_applies(int M, int N, int K, int lda, int ldc, int ldres, int c_f32, bool has_res);
-int xp_ring_f16_launch(const void* A, const void* W, void* C, int c_f32, const float* bias, const float* scale, const float* shift, const void* res,
-                       int M, int N, int K, int lda, int ldc, int ldres, int act, hipStream_t s);
-
 namespace {
 
 // Slab depth BK (halves): 64 (128-byte LDS rows, 8 slots, rows permuted by (r >> 1) & 7) for the K loops that keep the matrix pipe busy; 32 (64-byte rows, 4 slots,
@@ -291,10 +286,6 @@ void f16_launch(const F16Params& p, hipStream_t s) {
 int f16_dispatch(const F16Params& p, hipStream_t s) {
     static const int force = getenv("XP_F16_TILE") ? atoi(getenv("XP_F16_TILE")) : -1;      // tuning experiments only
     const int N = p.N;
-    // K >= 384 and N >= 384 (in / out_proj, fc1, fc2 of stages 2 - 3): the ping-pong ring engine — same slab order and accumulation order as the tiles below,
-    // so the same bits (tests/test_gpu_ring.py), 5 - 14 % less time alone (profiles/r5_ring_microbench.txt)
-    if (!p.Ci && force < 0 && xp_ring_f16_applies(p.M, p.N, p.K, p.lda, p.ldc, p.ldres, p.c_f32, p.res != nullptr))
-        return xp_ring_f16_launch(p.A, p.W, p.C, p.c_f32, p.bias, p.scale, p.shift, p.res, p.M, p.N, p.K, p.lda, p.ldc, p.ldres, p.act, s);
     // Tile by LAYER (N, K) only — every tile walks K in the same slab order, so the choice never changes a result bit, and it never depends on the batch.
     // Measured on the deep-stage layers (tools/gemm_bench.py, GB_F16=1, XP_F16_TILE=3/4/5): 128 x 192 wins where it covers N in fewer column tiles at short K
     // (N 192, K 768: 54.1 -> 49.8 us; N 1536, K 384 + GELU: 64.3 -> 57.4), 256 x 128 where K is long and N narrow (N 384, K 1536: 40.5 -> 35.7: the L2-read-bound

@@ -124,26 +124,3 @@ extern "C" int xp_gemm_nt_h2s(const void* A_p32, const void* Wh2, void* C, int o
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
-
-// one-product fp16 instance for xp_gemm_nt_f16 (gemm_f16.hip): long-K layers of the deep stages.  OFF by default (XP_RING_F16=1 turns it on): alone it
-// is 5 - 14 % faster than the 4-wave tile kernel on these layers (profiles/r5_ring_microbench.txt), but in the three-stream step its 144 KB of LDS and 8 waves
-// per CU leave no room for the other encoders' kernels and the fast class ran 2 454 -> 2 382 pairs/s on one box (profiles/r5_ring_instep_ab.txt); the
-// split class keeps it (+1.0 %: its tile kernels are the slower ones).  Same bits either way.
-bool xp_ring_f16_applies(int M, int N, int K, int lda, int ldc, int ldres, int c_f32, bool has_res) {
-    static const int on16 = getenv("XP_RING_F16") ? atoi(getenv("XP_RING_F16")) : 0;
-    return on16 && ring_enabled() && K % 64 == 0 && K >= 384 && N % 8 == 0 && N >= 384 && lda % 8 == 0 && ldc % (c_f32 ? 4 : 8) == 0 && (!has_res || ldres % 8 == 0) &&
-           (int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * K * 2 < (1ll << 32);
-}
-
-int xp_ring_f16_launch(const void* A, const void* W, void* C, int c_f32, const float* bias, const float* scale, const float* shift, const void* res,
-                       int M, int N, int K, int lda, int ldc, int ldres, int act, hipStream_t s) {
-    RingParams p{};
-    p.A = (const char*)A; p.W = (const char*)W;
-    p.a_row = (int64_t)lda * 2; p.a_slab = 128; p.w_row = (int64_t)K * 2; p.w_slab = 128;
-    p.M = M; p.N = N; p.T = K / 64;
-    p.C = C; p.ldc = ldc; p.out_fmt = c_f32 ? RG_F32 : RG_F16;
-    p.wscale = nullptr; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.ldres = ldres; p.res_fmt = RG_F16; p.act = act; p.r16 = 1;
-    ring_dispatch<1>(p, s, "gemm_ring_f16", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (res ? 2 : 1)) + (c_f32 ? 2.0 * M * N : 0.0));
-    XP_LAUNCH_CHECK();
-    return XP_OK;
-}

@@ -42,15 +42,17 @@
 #ifndef XP_MLP_FRAG_DEPTH
 #define XP_MLP_FRAG_DEPTH 2   /* LDS fragment look-ahead of the split-fp16 instances, in k slabs (1 = round 4) */
 #endif
+#ifndef XP_MLP_H2_PIPE
+#define XP_MLP_H2_PIPE 0   /* experiment: split-fp16 instances on the software-pipelined chunk loop (fc1 of chunk c + 1 between the GELU slices of chunk c) */
+#endif
+#ifndef XP_MLP_AGPR
+#define XP_MLP_AGPR 0      /* experiment: accumulators in AccVGPRs (an "a" asm operand makes hipcc select the AGPR form of every MFMA) */
+#endif
+#ifndef XP_MLP_WPE
+#define XP_MLP_WPE 2       /* waves per SIMD the split-fp16 instances are compiled for */
+#endif
 #ifndef XP_MLP_DBG
 #define XP_MLP_DBG 0   /* timing experiments only (wrong results): 1 no GELU, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no bf16 split of the hidden values, 16 no MFMA */
-#endif
-
-#if XP_MLP_DBG & 64
-__device__ unsigned long long g_mlp_stamps[8][512];      // debug build only: s_memtime at every ping-pong barrier entry / exit of the waves of workgroup 0
-extern "C" int xp_mlp_debug_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 8 * 512) == hipSuccess ? 0 : -2;
-}
 #endif
 
 namespace {
@@ -122,12 +124,12 @@ __global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __res
     if (u < T::UNITS && k < KD) {
         // x3 (fc1 of chunk c+1 runs ahead of fc2 of chunk c): image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1);
         // n = 2NC-1 -> W2(NC-1).   h2 (one hidden accumulator, chunk after chunk): even n -> W1(n/2), odd n -> W2(n/2).
-        const bool is_w1 = H2 ? !(n & 1) : ((n == 0) || ((n & 1) && n < 2 * NC - 1));
+        const bool is_w1 = (H2 && !XP_MLP_H2_PIPE) ? !(n & 1) : ((n == 0) || ((n & 1) && n < 2 * NC - 1));
         if (is_w1) {
-            const int c = H2 ? n >> 1 : (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
+            const int c = (H2 && !XP_MLP_H2_PIPE) ? n >> 1 : (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
             v = mlp_src_unit<H2>(W1, H4, h, s, k);
         } else {
-            const int c = H2 ? n >> 1 : ((n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1), j = row / C, nn = row - j * C;
+            const int c = (H2 && !XP_MLP_H2_PIPE) ? n >> 1 : ((n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1), j = row / C, nn = row - j * C;
             v = mlp_src_unit<H2>(W2, C, nn, 2 * c + j, k);
         }
     }
@@ -181,11 +183,9 @@ __device__ __forceinline__ void mlp_split2(float x, float y, unsigned& p0, unsig
     } else xp_split2(x, y, p0, p1, p2);
 }
 
-// PP (round 5, split-fp16 instances with 8 waves): the "ping-pong" schedule of the MLP chunk loop — see the loop itself.
-template <int C, int NW, int MODE, int NP, bool H2, bool PP = false>
-__global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void mlp_fused_kernel(MlpParams p) {      // h2: two waves per SIMD at every C (two planes resident)
+template <int C, int NW, int MODE, int NP, bool H2>
+__global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)) void mlp_fused_kernel(MlpParams p) {      // h2: two waves per SIMD at every C (two planes resident)
     static_assert(NP == 6 || NP == 3 || NP == 1, "partial products per multiply (gemm_x3_core.h)");
-    static_assert(!PP || (H2 && NW == 8 && MODE != 2), "the ping-pong schedule: split-fp16 MLP instances with two waves per SIMD in ONE workgroup");
     static_assert(!H2 || NP == 3, "the split-fp16 engine always forms its three products");
     constexpr bool PRE = MODE == 1, PROJ_ONLY = MODE == 2;
     using T = MlpTile<C, H2>;
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     constexpr int KS = T::KS, NT = T::NT;
     constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
     static_assert(T::NI * 4 % NW == 0, "image pieces must divide among the waves");
+    if constexpr (H2 && XP_MLP_AGPR) { float dummy_a = 0.f; asm volatile("" :: "a"(dummy_a)); }
     extern __shared__ __align__(16) unsigned char lds[];       // [3 image slots][b1 (H4 floats)][h2: 1 / row scale of fc1 (H4 floats)] — ONE array (LDS-DMA waits)
     unsigned char* const bias_lds = lds + 3 * T::IMGP;
     unsigned char* const inv1_lds = bias_lds + (size_t)p.H4 * 4;
@@ -309,10 +310,9 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
             iv[8 * j + 4] = hi.x; iv[8 * j + 5] = hi.y; iv[8 * j + 6] = hi.z; iv[8 * j + 7] = hi.w;
         }
     };
-    // PP: the same 16 floats by inline-asm LDS reads.  hipcc guards an ordinary ds_read of these arrays with s_waitcnt vmcnt(0) whenever an LDS-DMA is in
-    // flight (it cannot tell the bias region from the image ring: one __shared__ array, and it must be one — cdna_hip_programming.md §5 trap (a)); in the
-    // lockstep loop that wait was placed ahead of the phase's DMA issue, in the ping-pong loop an image is ALWAYS in flight and the wait would put the whole
-    // DMA latency into every phase.  An asm load is invisible to that pass; its own completion is waited for right here.
+    // The same 16 floats by inline-asm LDS reads.  hipcc guards an ordinary ds_read of these arrays with s_waitcnt vmcnt(0) whenever an LDS-DMA is in
+    // flight (it cannot tell the bias region from the image ring: one __shared__ array, and it must be one — cdna_hip_programming.md §5 trap (a)): the image
+    // issued a phase ago would be waited for a phase early.  An asm load is invisible to that pass; its own completion is waited for right here.
     auto lds_read16_asm = [&](const unsigned char* base, int c, float (&v)[16]) {
         typedef __attribute__((address_space(3))) const unsigned char* lds_cptr;
         const unsigned addr = (unsigned)(size_t)(lds_cptr)(base + (32 * c + 8 * g) * 4);
@@ -346,24 +346,25 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     // The DMA pieces of image n + 2 are issued BETWEEN the MFMA groups of phase n (one piece per k slab / output step), not in one
     // burst at its start: a few per cent faster (363 vs 375 us at C = 192) — an LDS-DMA issued among MFMAs costs less than one issued
     // next to other pieces and fragment reads.
-    int sp_img = -2, sp_slot = 0;                  // PP chunk loop: the image (and its ring slot) whose pieces the current MFMA phase issues; -1: none; -2: not in that loop
     auto spread = [&](int step, int nsteps) {      // called after MFMA group `step` of `nsteps`: the pieces due by then
         if (XP_MLP_DBG & 2) return;
-        if (PP && sp_img != -2) {
-            if (sp_img < 0) return;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(sp_img, sp_slot, i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(n + 2, slot == 0 ? 2 : slot - 1, i);
-        }
+        for (int i = 0; i < NI; ++i) if (i * nsteps / NI == step) issue_piece(n + 2, slot == 0 ? 2 : slot - 1, i);
     };
     // VALU slices placed between MFMAs.  Slices 0..15: GELU of element r in place; 16..19 / 20..23: bf16 split of pair q of half 0 / 1.
     auto slice = [&](int k, f32x16& h) {
-        if (k < 16) { h[k] = mlp_gelu(H2 ? h[k] * inv_cur[k] : h[k]); return; }
+        // (pipelined schedule: a slice's result is pinned where the slice stands — hipcc otherwise SINKS this register-only code past the sched_barriers to its
+        // consumer, the fc2 phase, and nothing runs between the matrix instructions: round 6, the ISA of the first XP_MLP_H2_PIPE build)
+        if (k < 16) {
+            float v = mlp_gelu(H2 ? h[k] * inv_cur[k] : h[k]);
+            if (H2 && XP_MLP_H2_PIPE) asm volatile("" : "+v"(v));
+            h[k] = v;
+            return;
+        }
         const int j = (k - 16) >> 2, q = (k - 16) & 3;
         if (XP_MLP_DBG & 8) { hp[j][0][q] = __float_as_uint(h[8 * j + 2 * q]); hp[j][1][q] = __float_as_uint(h[8 * j + 2 * q + 1]); hp[j][2][q] = hp[j][0][q]; }
         else mlp_split2<H2>(h[8 * j + 2 * q], h[8 * j + 2 * q + 1], hp[j][0][q], hp[j][1][q], hp[j][2][q]);
+        if (H2 && XP_MLP_H2_PIPE) asm volatile("" : "+v"(hp[j][0][q]), "+v"(hp[j][1][q]));
     };
     // fc1 of one chunk from the W1 image in `slot` into nxt (preloaded with the bias); between the MFMAs, slices [0, NSL) of the
     // previous chunk's accumulators `cur` (NSL = 0: none)
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
             for (int pp = 6 - NP; pp < 6; ++pp) {
                 if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i % (FD + 1)][0][0]); }
                 else oacc[t] = mlp_mfma<H2>(hfrag(j, PA[pp]), b[i % (FD + 1)][PB[pp]], oacc[t]);
-                if (!PP && i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once (PP: done in the V phase)
+                if (i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (NP >= 4 ? q == pp - (6 - NP) : true) slice(20 + q, cur);
                 }
@@ -497,17 +498,20 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     // phase 0 of the MLP: fc1 of chunk 0
     // (the bias reads come BEFORE the phase's DMA issue: hipcc guards these ds_reads — not the fragment reads — with s_waitcnt vmcnt(0),
     // which after the issue would wait for the image that was just requested; before it, it waits for one requested a phase ago)
-    if constexpr (!PP) {
-        load_bias(0, h0);
-        __builtin_amdgcn_sched_barrier(0);
-        fc1(slot, h0, h1, std::integral_constant<int, 0>{});
-        end_phase();
-    }
+    load_bias(0, h0);
+    __builtin_amdgcn_sched_barrier(0);
+    fc1(slot, h0, h1, std::integral_constant<int, 0>{});
+    end_phase();
     // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
     //          phase B = fc2(c) (image 2 + 2c)
     auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
-        if constexpr (H2) load_inv1(c, inv_cur);
-        load_bias(c + 1, nxt);
+        if constexpr (H2) {
+            float bv[16];
+            lds_read16_asm(inv1_lds, c, inv_cur);
+            lds_read16_asm(bias_lds, c + 1, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nxt[r] = bv[r];
+        } else load_bias(c + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         fc1(slot, nxt, cur, std::integral_constant<int, 20>{});
         end_phase();
@@ -515,73 +519,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         end_phase();
     };
     int c = 0;
-    if constexpr (PP) {
-        // Ping-pong schedule of the chunk loop (round 5).  Per chunk a wave runs THREE phases of about equal length — F1 = fc1's matrix instructions (+ their
-        // fragment reads), V = GELU + split on the vector ALU, F2 = fc2's matrix instructions — and the stage-removal timings of the lockstep loop above
-        // (profiles/r5_mlp_pingpong.txt: no-MFMA build 124 of 274 us, no-GELU-no-split 197) are the SUM of the three: with every wave of the workgroup
-        // between the same two barriers, the two waves of a SIMD want the matrix pipe together and the vector ALU together.  Here waves 4 - 7 (the second wave
-        // of every SIMD) run ONE PHASE BEHIND waves 0 - 3, a barrier after every phase: slot k pairs (F1, F2'), (V, F1'), (F2, V') — the partner's V always
-        // sits under a matrix phase, and only the (F1, F2') slot has both on the pipe, which is then simply full.  Same instructions per wave in the same
-        // order as the loop above: bit-identical results.
-        //   Weight images: image k = W1(k / 2) (k even) / W2(k / 2) (k odd) lives in ring slot (k mod 3); group 0 reads it one slot before group 1, so an
-        //   image occupies its slot for two slots of time and ONE image is in flight: group 0 issues image 2c + 2 at the start of V(c) and 2c + 3 inside F2(c),
-        //   group 1 issues 2c + 2 inside F1(c) and 2c + 3 at the start of V(c) — always into the slot whose last reader (group 1) passed a barrier since —
-        //   and every wave retires its pieces with vmcnt(NI) one barrier before the image's first reader (group 0) starts.
-        const int grp = wave >> 2;
-        const int n0i = n, slot0 = slot;                                   // image index / ring slot of W1(0) on entry (landed; W2(0) issued)
-        auto ring_slot = [&](int k) { return (slot0 + k) % 3; };           // ring slot of MLP image k (k = 0: W1(0))
-        int n_stamp = 0;
-        auto stamp = [&]() {
-#if XP_MLP_DBG & 64
-            if (blockIdx.x == 0 && lane == 0 && n_stamp < 512) g_mlp_stamps[wave][n_stamp] = __builtin_amdgcn_s_memtime();
-            ++n_stamp;
-#endif
-        };
-        auto pp_barrier = [&]() {
-            stamp();
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(XP_MLP_DBG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-        };
-        auto pp_wait = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory"); };
-        if (grp == 1) pp_barrier();
-        for (c = 0; c < NC; ++c) {
-            // ---- F1(c)
-            {
-                float bv[16];
-                lds_read16_asm(bias_lds, c, bv);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h0[r] = bv[r];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            sp_img = grp == 1 ? n0i + 2 * c + 2 : -1; sp_slot = ring_slot(2 * c + 2);
-            slot = ring_slot(2 * c);
-            fc1(slot, h0, h0, std::integral_constant<int, 0>{});
-            if (grp == 1) pp_wait();                                       // image 2c + 1 has landed (2c + 2 in flight)
-            pp_barrier();
-            // ---- V(c)
-            if (!(XP_MLP_DBG & 2)) issue_image(n0i + 2 * c + 2 + grp, ring_slot(2 * c + 2 + grp));
-            lds_read16_asm(inv1_lds, c, inv_cur);
-#pragma unroll
-            for (int k = 0; k < 24; ++k) slice(k, h0);
-            // pin the phase's results HERE: hipcc otherwise sinks the whole GELU + split past the barrier to its consumer, fc2 (register-only instructions are
-            // not ordered by an asm memory clobber: cdna_hip_programming.md rule 18), and the phase it was meant to fill stays empty (stamps: V 366 cycles, F2 2 229)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hp[j][0][q]), "+v"(hp[j][1][q]));
-            pp_wait();                                                     // group 0: image 2c + 1 landed; group 1: image 2c + 2
-            pp_barrier();
-            // ---- F2(c)
-            sp_img = grp == 0 ? n0i + 2 * c + 3 : -1; sp_slot = ring_slot(2 * c + 3);
-            slot = ring_slot(2 * c + 1);
-            fc2(slot, h0);
-            if (grp == 0) pp_wait();                                       // image 2c + 2 has landed (2c + 3 in flight)
-            if (grp == 0 || c + 1 < NC) pp_barrier();
-        }
-        c = NC;
-    } else if constexpr (H2) {
+    if constexpr (H2 && !XP_MLP_H2_PIPE) {
         // split-fp16 instances: ONE hidden accumulator, chunk after chunk — fc1(c), GELU + split, fc2(c) — over a stream packed in that
         // order.  The x3 schedule below (fc1 of chunk c+1 with the GELU of chunk c between its MFMAs, two accumulator sets) spills 149
         // registers at C = 192 with two planes resident and eight waves (8 here); measured 314 -> 272 us at C = 192, 278 -> 266 us at C = 96.
@@ -608,10 +546,10 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
         }
         c = NC;
     }
-    if constexpr (!H2)
+    if constexpr (!H2 || XP_MLP_H2_PIPE)
     for (; c + 2 < NC; c += 2) { iter(c, h0, h1); iter(c + 1, h1, h0); }
     auto tail = [&](f32x16& cur) {         // last chunk: nothing left to overlap the GELU with; image 2 NC - 1
-        if constexpr (H2) load_inv1(NC - 1, inv_cur);
+        if constexpr (H2) lds_read16_asm(inv1_lds, NC - 1, inv_cur);
 #pragma unroll
         for (int k = 0; k < 20; ++k) slice(k, cur);
         fc2(slot, cur);
@@ -646,426 +584,14 @@ __global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void ml
     if (m0 + 32 <= p.M) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
-
-// =============================================================================================================================================
-// Warp-specialised instance of the split-fp16 fused tail (round 5, XP_MLP_WS).  The counters of the kernel above (profiles/r5_mlp_pmc.txt) show the
-// matrix pipe busy 0.34 and the vector ALU 0.32 of the time with every wave doing BOTH kinds of work one after the other (fc1, then GELU + split, then fc2:
-// a wave's phases add up, and 2 - 3 waves per SIMD overlap them only by chance), and every 128 rows re-stream all weight images from L2.
-// Here a workgroup is NM MATRIX waves (NM / 4 per SIMD, 32 rows each: the same rows, fragments and instruction order per row as above — bit-identical
-// results) + 4 VECTOR waves (one per SIMD, serving the matrix waves of its SIMD).  Per phase q (one workgroup barrier each) a matrix wave runs fc1 of
-// chunk q and fc2 of chunk q - 2 back to back (36 MFMAs and their fragment reads, plus its share of the LDS-DMA of the two weight images of phase
-// q + 1 between them), the vector wave evaluates GELU + split of chunk q - 1.  The hidden tile travels through LDS lane to lane (the accumulator layout of
-// fc1 IS the A-operand layout of fc2, see `slice` above): H (16 f32 per lane) matrix -> vector, P (2 slabs x 2 planes x 4 registers) vector -> matrix
-// IN PLACE (the vector lane overwrites what it read; the matrix lane re-uses the buffer two phases later, after it has read P): 2 x 4 KB per matrix wave.
-// Weight images: ring of 4 slots, phase g reads slots 2g, 2g + 1 (mod 4); every matrix wave waits for its own pieces (vmcnt(0)) before the phase barrier.
-// =============================================================================================================================================
-typedef float ws_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void ws_lds_write16_asm(unsigned addr, const float (&v)[16]) {
-    const ws_f4 q0 = {v[0], v[1], v[2], v[3]}, q1 = {v[4], v[5], v[6], v[7]};
-    const ws_f4 q2 = {v[8], v[9], v[10], v[11]}, q3 = {v[12], v[13], v[14], v[15]};
-    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\tds_write_b128 %0, %3 offset:2048\n\tds_write_b128 %0, %4 offset:3072"
-                 :: "v"(addr), "v"(q0), "v"(q1), "v"(q2), "v"(q3) : "memory");
-}
-// 4 x 16 bytes at addr + {0, 1, 2, 3} x STRIDE, complete on return
-template <int O1, int O2, int O3>
-__device__ __forceinline__ void ws_lds_read16_asm(unsigned addr, float (&v)[16]) {
-    float4 q0, q1, q2, q3;
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr), "n"(O1), "n"(O2), "n"(O3) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
-    v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w; v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
-}
-
-#ifndef XP_WS_DBG
-#define XP_WS_DBG 0   /* timing experiments only (wrong results): 1 no GELU / split arithmetic, 2 no LDS-DMA after the first two phases, 4 no MFMA, 8 no H / P exchange, 64 stamps */
-#endif
-#if XP_WS_DBG & 64
-__device__ unsigned long long g_ws_stamps[2][4096];      // debug build only: s_memtime stamps of matrix wave 0 / vector wave 0 of workgroup 0
-extern "C" int xp_mlp_ws_debug_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_stamps), sizeof(unsigned long long) * 2 * 4096) == hipSuccess ? 0 : -2;
-}
-#endif
-template <int C, int MODE, int NM>
-__global__ __launch_bounds__((NM + 4) * 64, 1) void mlp_ws_kernel(MlpParams p) {
-    constexpr bool PRE = MODE == 1;
-    using T = MlpTile<C, true>;
-    constexpr int ROWB = T::ROWB, KS = T::KS, NT = T::NT;
-    constexpr int NSLOT = 4;
-    constexpr int NPIECE = T::NI * 4;          // 1 KiB pieces per image
-    static_assert(NPIECE % NM == 0, "image pieces must divide among the matrix waves");
-    constexpr int NIM = NPIECE / NM;           // DMA pieces per matrix wave and image
-    constexpr int NPRE = PRE ? NT : 0;
-    constexpr int NTHREADS = (NM + 4) * 64;
-    extern __shared__ __align__(16) unsigned char lds[];       // [4 image slots][b1 / scale][1 / scale][exchange: buf 2 x NM waves x 4 KB]
-    unsigned char* const bias_lds = lds + NSLOT * T::IMGP;
-    unsigned char* const inv1_lds = bias_lds + (size_t)p.H4 * 4;
-    unsigned char* const xch = inv1_lds + (size_t)p.H4 * 4;
-    typedef __attribute__((address_space(3))) const unsigned char* lds_cptr;
-    const int lane = threadIdx.x & 63, fr = lane & 31, g = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NC = p.H4 / 32, NIMG = 2 * NC + NPRE;
-    auto xbuf = [&](int mwave, int c) { return xch + ((c & 1) * NM + mwave) * 4096 + lane * 16; };      // H(c), then P(c), of matrix wave `mwave`
-    int n_stamp = 0;
-    auto stamp = [&]() {
-#if XP_WS_DBG & 64
-        __builtin_amdgcn_sched_barrier(0);
-        if (blockIdx.x == 0 && (wave == 0 || wave == NM) && lane == 0 && n_stamp < 4096) g_ws_stamps[wave == NM][n_stamp] = __builtin_amdgcn_s_memtime();
-        ++n_stamp;
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    };
-
-    // b1 / row scale and 1 / row scale of fc1 -> LDS (as the kernel above)
-    for (int i = threadIdx.x; i < p.H4 / 4; i += NTHREADS) {
-        float4 bv = reinterpret_cast<const float4*>(p.b1)[i];
-        const float4 iv = reinterpret_cast<const float4*>(p.s1)[i];
-        reinterpret_cast<float4*>(inv1_lds)[i] = iv;
-        bv = make_float4(bv.x / iv.x, bv.y / iv.y, bv.z / iv.z, bv.w / iv.w);
-        reinterpret_cast<float4*>(bias_lds)[i] = bv;
-    }
-
-    if (wave >= NM) {
-        // ======================================================= vector wave: no VMEM in its loop, ordinary LDS accesses =======================================================
-        const int v = wave - NM;                               // serves the matrix waves v, v + 4, ... (its SIMD's)
-        auto phase_end = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-        phase_end();
-        for (int gp = 0; gp < NPRE; ++gp) phase_end();
-        const int NQ = NC + 2;
-        for (int q = 0; q < NQ; ++q) {
-            stamp();                                           // V stamps per phase: 0 start, 1 H and scales read, 2 GELU + split done, 3 P written (before the barrier)
-            if (q >= 1 && q <= NC) {
-                const int c = q - 1;
-                float inv_cur[16];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float4 lo = *reinterpret_cast<const float4*>(inv1_lds + (32 * c + 16 * j + 8 * g) * 4);
-                    const float4 hi = *reinterpret_cast<const float4*>(inv1_lds + (32 * c + 16 * j + 8 * g + 4) * 4);
-                    inv_cur[8 * j + 0] = lo.x; inv_cur[8 * j + 1] = lo.y; inv_cur[8 * j + 2] = lo.z; inv_cur[8 * j + 3] = lo.w;
-                    inv_cur[8 * j + 4] = hi.x; inv_cur[8 * j + 5] = hi.y; inv_cur[8 * j + 6] = hi.z; inv_cur[8 * j + 7] = hi.w;
-                }
-                float h[NM / 4][16];
-#pragma unroll
-                for (int u = 0; u < NM / 4; ++u) {
-                    const unsigned char* hb = xbuf(v + 4 * u, c);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4 t = (XP_WS_DBG & 8) ? make_float4(lane, i, u, c) : *reinterpret_cast<const float4*>(hb + i * 1024);
-                        h[u][4 * i] = t.x; h[u][4 * i + 1] = t.y; h[u][4 * i + 2] = t.z; h[u][4 * i + 3] = t.w;
-                    }
-                }
-                stamp();
-#pragma unroll
-                for (int u = 0; u < NM / 4; ++u) {
-                    float pv[16];
-                    if (!(XP_WS_DBG & 1)) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) h[u][k] = mlp_gelu(h[u][k] * inv_cur[k]);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) {
-                                unsigned p0, p1, p2;
-                                mlp_split2<true>(h[u][8 * j + 2 * qq], h[u][8 * j + 2 * qq + 1], p0, p1, p2);
-                                pv[(2 * j + 0) * 4 + qq] = __uint_as_float(p0); pv[(2 * j + 1) * 4 + qq] = __uint_as_float(p1);
-                            }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) pv[k] = h[u][k] + inv_cur[k];
-                    }
-                    if (u == NM / 4 - 1) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(pv[k]));
-                        stamp();
-                    }
-                    unsigned char* pb = xbuf(v + 4 * u, c);
-                    if (!(XP_WS_DBG & 8) || pv[0] == 123.456f) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(pb + i * 1024) = make_float4(pv[4 * i], pv[4 * i + 1], pv[4 * i + 2], pv[4 * i + 3]);
-                    }
-                }
-#if XP_WS_DBG & 64
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                stamp();
-            } else { stamp(); stamp(); stamp(); }
-            if (q + 1 < NQ) phase_end();
-        }
-        return;
-    }
-
-    // ======================================================= matrix wave =======================================================
-    const int m0 = blockIdx.x * (NM * 32) + wave * 32;
-    const int mrow = (m0 + fr < p.M) ? m0 + fr : p.M - 1;      // rows past M are computed on a copy of the last row, never stored
-    // this wave's pieces (wave, wave + NM, ...) of image n -> ring slot
-    auto issue_piece = [&](int n, int slot, int i) {
-        n = n < NIMG ? n : NIMG - 1;
-        const unsigned char* base = p.Wpack + (size_t)n * T::IMGP + (wave + i * NM) * 1024;      // uniform: kept in scalar registers (no 64-bit vector pointer to spill)
-        asm volatile("" : "+s"(base));
-        const unsigned char* src = base + lane * 16;
-        unsigned char* dst = lds + slot * T::IMGP + (wave + i * NM) * 1024;
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
-    };
-    // the images phase gp reads: PRE phase t: W0 tile t; MLP phase q: W1(q) (q < NC) into the even slot, W2(q - 2) (q >= 2) into the odd one.
-    // Issued by the phase before, in two halves (after fc1 / inside fc2): piece `part` of NIM for each image
-    auto issue_for_phase = [&](int gp, int i) {
-        if ((XP_WS_DBG & 2) && gp >= 2) return;
-        if (gp < NPRE) { issue_piece(gp, (2 * gp) & 3, i); return; }
-        const int q = gp - NPRE;
-        if (q < NC) issue_piece(NPRE + 2 * q, (2 * gp) & 3, i);
-        if (q >= 2 && q - 2 < NC) issue_piece(NPRE + 2 * (q - 2) + 1, (2 * gp + 1) & 3, i);
-    };
-#pragma unroll
-    for (int i = 0; i < NIM; ++i) issue_for_phase(0, i);
-    float4 xv[KS][2];
-    {
-        const float* xr = p.X + (int64_t)mrow * C + 8 * g;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            xv[s][0] = *reinterpret_cast<const float4*>(xr + 16 * s);
-            xv[s][1] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
-        }
-    }
-    frag_bits xp[KS][3];
-    auto layer_norm_split = [&]() {
-        float sum = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            sum += ((xv[s][0].x + xv[s][0].y) + (xv[s][0].z + xv[s][0].w)) + ((xv[s][1].x + xv[s][1].y) + (xv[s][1].z + xv[s][1].w));
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum / (float)C;
-        float q2 = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float dx = xv[s][e].x - mean, dy = xv[s][e].y - mean, dz = xv[s][e].z - mean, dw = xv[s][e].w - mean;
-                q2 = fmaf(dx, dx, q2); q2 = fmaf(dy, dy, q2); q2 = fmaf(dz, dz, q2); q2 = fmaf(dw, dw, q2);
-            }
-        q2 += __shfl_xor(q2, 32, 64);
-        const float rstd = 1.f / sqrtf(q2 / (float)C + p.eps);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g), w1 = *reinterpret_cast<const float4*>(p.ln_w + 16 * s + 8 * g + 4);
-            const float4 c0 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g), c1 = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * g + 4);
-            float4 lo, hi;
-            lo.x = (xv[s][0].x - mean) * rstd * w0.x + c0.x; lo.y = (xv[s][0].y - mean) * rstd * w0.y + c0.y;
-            lo.z = (xv[s][0].z - mean) * rstd * w0.z + c0.z; lo.w = (xv[s][0].w - mean) * rstd * w0.w + c0.w;
-            hi.x = (xv[s][1].x - mean) * rstd * w1.x + c1.x; hi.y = (xv[s][1].y - mean) * rstd * w1.y + c1.y;
-            hi.z = (xv[s][1].z - mean) * rstd * w1.z + c1.z; hi.w = (xv[s][1].w - mean) * rstd * w1.w + c1.w;
-            mlp_split8<true>(lo, hi, xp[s]);
-        }
-    };
-    if (PRE) {
-        const float* tr = p.T1 + (int64_t)mrow * C + 8 * g;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float4 lo = *reinterpret_cast<const float4*>(tr + 16 * s), hi = *reinterpret_cast<const float4*>(tr + 16 * s + 4);
-            mlp_split8<true>(lo, hi, xp[s]);
-        }
-    } else {
-        layer_norm_split();
-    }
-    auto phase_end = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    phase_end();                                               // images of phase 0 landed, bias / scale tables written
-
-    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};        // the three products of the split-fp16 engine, smallest first: a1 b0, a0 b1, a0 b0
-    const int frag = fr * ROWB + 16 * g;
-    constexpr int FD = (KS > 2 && NM <= 4) ? 2 : 1;            // (8 matrix waves: 168 registers per wave, one slab of look-ahead — the SIMD's other matrix wave covers the latency)
-    // fc1-type phase: acc += W(image in `slot`) x xp over the KS k slabs, fragment ring FD + 1 deep (same order per accumulator as the kernel above);
-    // DMA pieces [i0, i1) of the next phase's images go out after slab KS / 2
-    auto fc1 = [&](int slot, f32x16& acc, int gp_next, int i0, int i1) {
-        const unsigned char* img = lds + slot * T::IMGP + frag;
-        frag_bits a[FD + 1][2];
-#pragma unroll
-        for (int d = 0; d < FD; ++d)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) a[d][pl] = *reinterpret_cast<const frag_bits*>(img + d * 32 * ROWB + pl * 32);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (s + FD < KS) {
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[(s + FD) % (FD + 1)][pl] = *reinterpret_cast<const frag_bits*>(img + (s + FD) * 32 * ROWB + pl * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {
-                if (XP_WS_DBG & 4) { if (pp == 2) acc[0] += __uint_as_float(a[s % (FD + 1)][0][0]) * __uint_as_float(xp[s][0][0]); }
-                else acc = mlp_mfma<true>(a[s % (FD + 1)][PA[pp]], xp[s][PB[pp]], acc);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == KS / 2 && gp_next >= 0) {
-                for (int i = i0; i < i1; ++i) issue_for_phase(gp_next, i);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    f32x16 oacc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    unsigned hp[2][2][4];
-    auto hfrag = [&](int j, int pl) { return frag_bits{hp[j][pl][0], hp[j][pl][1], hp[j][pl][2], hp[j][pl][3]}; };
-    auto fc2 = [&](int slot, int gp_next, int i0, int i1) {
-        const unsigned char* img = lds + slot * T::IMGP + frag;
-        constexpr int FD2 = (2 * NT > 2 && NM <= 4) ? 2 : 1;
-        frag_bits b[FD2 + 1][2];
-        auto b_addr = [&](int i) { return img + ((i / NT) * C + (i % NT) * 32) * ROWB; };
-#pragma unroll
-        for (int d = 0; d < FD2; ++d)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) b[d][pl] = *reinterpret_cast<const frag_bits*>(b_addr(d) + pl * 32);
-#pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const int j = i / NT, t = i % NT;
-            if (i + FD2 < 2 * NT) {
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) b[(i + FD2) % (FD2 + 1)][pl] = *reinterpret_cast<const frag_bits*>(b_addr(i + FD2) + pl * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {
-                if (XP_WS_DBG & 4) { if (pp == 2) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i % (FD2 + 1)][0][0]); }
-                else oacc[t] = mlp_mfma<true>(hfrag(j, PA[pp]), b[i % (FD2 + 1)][PB[pp]], oacc[t]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (i == 0 && gp_next >= 0) {
-                for (int k = i0; k < i1; ++k) issue_for_phase(gp_next, k);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    f32x16 h;
-    if (PRE) {
-        // x <- x + T1 W0^T, one fc1-type phase per 32 output channels (see the kernel above for the register layout)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[r] = 0.f;
-            fc1((2 * t) & 3, h, t + 1, 0, NIM);
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const float* sc = p.s0 + 16 * (2 * t + jj) + 8 * g;
-                const float4 ilo = *reinterpret_cast<const float4*>(sc), ihi = *reinterpret_cast<const float4*>(sc + 4);
-                const float iv[8] = {ilo.x, ilo.y, ilo.z, ilo.w, ihi.x, ihi.y, ihi.z, ihi.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) h[8 * jj + e] *= iv[e];
-                float4& lo = xv[2 * t + jj][0]; float4& hi = xv[2 * t + jj][1];
-                lo.x = lo.x + h[8 * jj + 0]; lo.y = lo.y + h[8 * jj + 1]; lo.z = lo.z + h[8 * jj + 2]; lo.w = lo.w + h[8 * jj + 3];
-                hi.x = hi.x + h[8 * jj + 4]; hi.y = hi.y + h[8 * jj + 5]; hi.z = hi.z + h[8 * jj + 6]; hi.w = hi.w + h[8 * jj + 7];
-            }
-            phase_end();
-        }
-        if (m0 + fr < p.M) {
-            float* xw = p.X + (int64_t)(m0 + fr) * C + 8 * g;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                *reinterpret_cast<float4*>(xw + 16 * s) = xv[s][0];
-                *reinterpret_cast<float4*>(xw + 16 * s + 4) = xv[s][1];
-            }
-        }
-        layer_norm_split();
-    }
-    const int NQ = NC + 2;
-    for (int q = 0; q < NQ; ++q) {
-        const int gp = NPRE + q;
-        const int gp_next = q + 1 < NQ ? gp + 1 : -1;
-        stamp();                                               // M stamps per phase: 0 start, 1 fc1 done, 2 fc2 done, 3 H written + own DMA landed (before the barrier)
-        if (q >= 2) {                                          // P(q - 2): the A operand of fc2, written by the vector wave one phase ago (asm: no compiler vmcnt(0) ahead of it)
-            float pv[16];
-            if (!(XP_WS_DBG & 8)) ws_lds_read16_asm<1024, 2048, 3072>((unsigned)(size_t)(lds_cptr)xbuf(wave, q - 2), pv);
-            else {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) pv[k] = (float)(lane + k + q);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hp[j][pl][e] = __float_as_uint(pv[(2 * j + pl) * 4 + e]);
-        }
-        if (q < NC) {
-            float bv[16];
-            ws_lds_read16_asm<16, 64, 80>((unsigned)(size_t)(lds_cptr)(bias_lds + (32 * q + 8 * g) * 4), bv);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[r] = bv[r];
-            fc1((2 * gp) & 3, h, q >= 2 ? gp_next : gp_next, 0, q >= 2 ? (NIM + 1) / 2 : NIM);
-        }
-        stamp();
-        if (q >= 2) fc2((2 * gp + 1) & 3, gp_next, q < NC ? (NIM + 1) / 2 : 0, NIM);
-        stamp();
-        if (q < NC && !(XP_WS_DBG & 8)) {
-            float hv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hv[r] = h[r];
-            ws_lds_write16_asm((unsigned)(size_t)(lds_cptr)xbuf(wave, q), hv);
-        }
-#if XP_WS_DBG & 64
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-        stamp();
-        if (q + 1 < NQ) phase_end();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- epilogue: x[m][n] = x[m][n] + (acc * 1/scale + b2[n]); lane = column n, registers = rows (r&3) + 8(r>>2) + 4g ----
-    float* xb = p.X + (int64_t)m0 * C;
-    auto epilogue = [&](auto interior_tag) {
-        constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = t * 32 + fr;
-            const float bi = p.b2[col];
-            const float ws = p.s2[col];
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float* rp = xb + ((INTERIOR || m0 + rl < p.M) ? rl : 0) * C + col;
-                rv[r] = PRE ? __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *rp;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float v = oacc[t][r] * ws + bi;
-                if (INTERIOR || m0 + rl < p.M) xb[rl * C + col] = rv[r] + v;
-            }
-        }
-    };
-    if (m0 + 32 <= p.M) epilogue(std::true_type{}); else if (m0 < p.M) epilogue(std::false_type{});
-}
-
-template <int C, int MODE, int NM>
-int launch_mlp_ws(const MlpParams& p, hipStream_t s) {
-    using T = MlpTile<C, true>;
-    const size_t lds_bytes = 4 * (size_t)T::IMGP + (size_t)p.H4 * 8 + (size_t)NM * 8192;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ws_kernel<C, MODE, NM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
-    std::string tag = std::string(MODE == 1 ? "proj_mlp_fused" : "mlp_fused") + "_h2_c" + std::to_string(C);
-    if (by_shape) tag += "_M" + std::to_string(p.M);
-    XpProfScope prof(tag.c_str(), s, 4.0 * p.M * C * (double)p.H4 + (MODE == 1 ? 2.0 * p.M * C * (double)C : 0.0), (MODE == 1 ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_ws_kernel<C, MODE, NM>), dim3(xp_cdiv(p.M, NM * 32)), dim3((NM + 4) * 64), lds_bytes, s, p);
-    XP_LAUNCH_CHECK();
-    return XP_OK;
-}
-// LDS of the warp-specialised instance: 4 image slots + two H4-float tables + 8 KB exchange per matrix wave must fit 160 KB
-template <int C, int NM>
-bool mlp_ws_fits(int H4) { return 4 * (size_t)MlpTile<C, true>::IMGP + (size_t)H4 * 8 + (size_t)NM * 8192 <= 160 * 1024; }
-
-template <int C, int NW, int MODE, int NP, bool H2 = false, bool PP = false>
+template <int C, int NW, int MODE, int NP, bool H2 = false>
 int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     constexpr bool PRE = MODE == 1;
     using T = MlpTile<C, H2>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4 * (H2 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2, PP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   3 * T::IMGP + 4096 * 4 * (H2 ? 2 : 1));
         attr_set = true;
     }
@@ -1077,7 +603,7 @@ int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     // flops = algorithmic 2*M*C*H4 per GEMM (f32-equivalent); bytes: x read twice (LN input, residual) and written once
     XpProfScope prof(tag.c_str(), s, MODE == 2 ? 2.0 * p.M * C * (double)p.Nout : 4.0 * p.M * C * (double)p.H4 + (PRE ? 2.0 * p.M * C * (double)C : 0.0),
                      MODE == 2 ? 4.0 * p.M * (C + (double)p.Nout) + 6.0 * C * (double)p.Nout : (PRE ? 20.0 : 12.0) * p.M * C + 12.0 * C * (double)p.H4);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP, H2, PP>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, MODE, NP, H2>), dim3(xp_cdiv(p.M, NW * 32)), dim3(NW * 64), lds_bytes, s, p);
     XP_LAUNCH_CHECK();
     return XP_OK;
 }
@@ -1087,21 +613,7 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
     // split-fp16 instances (scales present).  C = 192: one 8-wave workgroup per CU (its three 32 KB image slots leave no room for a
     // second one) puts two waves on every SIMD; the narrower ones run two 4-wave workgroups per CU.
     static const bool nw4 = getenv("XP_MLP_H2_NW4") != nullptr && atoi(getenv("XP_MLP_H2_NW4")) != 0;      // A/B: 0.716 (8 waves) vs 0.747 ms (4 waves) per two launches
-    // round 5: the ping-pong chunk loop (8-wave workgroups, the two waves of a SIMD one phase apart) for the MLP instances at C = 96 and C = 192; XP_MLP_PP=0: the
-    // lockstep loop (A/B).  Bit-identical results (tests/test_gpu_h2.py::test_mlp_fused_h2_schedules_are_bit_identical).
-    // OFF by default (XP_MLP_PP = 1: C = 192, 2: also C = 96).  Measured (profiles/r5_mlp_pingpong.txt): bit-identical, C = 192 246 - 258 vs 253 - 267 us alone,
-    // C = 96 293 - 304 vs 261 - 279 us (its 4-wave workgroups run three per CU; the 8-wave ping-pong workgroup runs alone), and the step does not move (1 709 - 1 715
-    // vs 1 702 - 1 712 pairs/s on one box): every phase of a wave is latency-, not throughput-bound (stamps: F1 1 250 cycles for 576 of matrix pipe, V 1 950 for
-    // ~1 000 of vector issue), so pairing phases of two waves hides less than a third wave per SIMD does.
-    static const int pp_mode = getenv("XP_MLP_PP") ? atoi(getenv("XP_MLP_PP")) : 0;
-    const bool pp_on = pp_mode >= (C == 192 ? 1 : 2);
-    constexpr bool PPOK = MODE != 2 && (C == 96 || C == 192);
     if (p.s2 || (MODE == 2 && p.s0)) {
-        if constexpr (MODE != 2 && C == 96) {
-            static const int ws_mode = getenv("XP_MLP_WS") ? atoi(getenv("XP_MLP_WS")) : 0;      // warp-specialised instance (see mlp_ws_kernel): 1 = 8 + 4 waves, 2 = 4 + 4
-            if (ws_mode == 1 && mlp_ws_fits<C, 8>(p.H4)) return launch_mlp_ws<C, MODE, 8>(p, s);
-            if (ws_mode == 2 && mlp_ws_fits<C, 4>(p.H4)) return launch_mlp_ws<C, MODE, 4>(p, s);
-        }
         if (C == 192 && !nw4) {
             // One 256-row workgroup per CU: M = 76 800 rows (16 images of 480 x 640 at stage 1) is 300 workgroups = one full round of the chip + 44 workgroups
             // that take as long again.  When the last round would be less than half full, its rows run as 128-row (4-wave) workgroups in a second launch —
@@ -1115,7 +627,6 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
                 n_cu = v;
             }
             auto main_launch = [&](const MlpParams& q) {
-                if constexpr (PPOK) { if (pp_on) return launch_mlp_np<C, 8, MODE, 3, true, true>(q, s); }
                 return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(q, s);
             };
             const int round_rows = n_cu * 256;
@@ -1132,7 +643,6 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
             }
             return main_launch(p);
         }
-        if constexpr (PPOK && C == 96) { if (pp_on) return launch_mlp_np<C, 8, MODE, 3, true, true>(p, s); }
         return launch_mlp_np<C, 4, MODE, 3, true>(p, s);
     }
     switch (xp_dense_products_value()) {      // precision class of the dense kernels (xp_set_dense_products)

@@ -425,13 +425,12 @@ __global__ __launch_bounds__(256) void nms_round_kernel(const float* __restrict_
 // bands a workgroup sees the rows of its neighbours (reach R above and below) as they were when the launch started and cannot decide a candidate that
 // waits on one of them: such launches are repeated (ping-pong masks) until a launch leaves nothing undecided — rare chains across a band border.
 struct NmsFinishPlan { int wpr, rows, rw, bands, brows; size_t mask_bytes, list_off; int list_cap; };
-__host__ __device__ inline NmsFinishPlan nms_finish_plan(int H, int W, int R, size_t lds_budget, int min_bands = 1) {
+__host__ __device__ inline NmsFinishPlan nms_finish_plan(int H, int W, int R, size_t lds_budget) {
     NmsFinishPlan p;
     p.wpr = (W + 31) / 32; p.rw = p.wpr + 2;
     const size_t per_row = (size_t)p.rw * 4 * 2;                         // both masks
     const size_t want = lds_budget * 5 / 8;                               // keep 3/8 of the budget for the (position, score) list
-    int bands = min_bands > 1 ? min_bands : 1;                            // (XP_NMS_BANDS: more workgroups per image than LDS requires, see nms_min_bands)
-    if (bands > 1 && (H + bands - 1) / bands < 4 * (R > 0 ? R : 1)) bands = 1;      // bands thinner than a few reaches decide nothing
+    int bands = 1;                                                        // as few as the LDS allows (more per image was measured: no gain, profiles/r5_nms_bands.txt)
     while (bands < 64 && (size_t)((H + bands - 1) / bands + 2 * R) * per_row > want) ++bands;
     p.bands = bands; p.brows = (H + bands - 1) / bands;
     p.rows = p.brows + 2 * R;
@@ -448,12 +447,12 @@ __global__ __launch_bounds__(NMS_FIN_THREADS) void nms_finish_kernel(const float
                                                                        const unsigned* __restrict__ und32, const unsigned* __restrict__ kept32,
                                                                        unsigned* __restrict__ und_out, unsigned* __restrict__ kept_out,
                                                                        int* __restrict__ glist, int H, int W, NmsTable tab, int* __restrict__ counters,
-                                                                       int sweep, int* __restrict__ info, int min_bands) {
+                                                                       int sweep, int* __restrict__ info) {
     extern __shared__ __align__(16) unsigned char fin_lds[];
     __shared__ int s_n;
     const int R = RT > 0 ? RT : tab.reach;
     constexpr int NW = RT > 0 ? 2 * RT + 1 : 2 * NMS_MAXR + 1;
-    const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS, min_bands);
+    const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS);
     unsigned* mU = reinterpret_cast<unsigned*>(fin_lds);                          // undecided (bits cleared as decisions fall)
     unsigned* mK = reinterpret_cast<unsigned*>(fin_lds + pl.mask_bytes);          // kept
     if (sweep > 0 && counters[sweep - 1] == 0) return;                            // banded form: an earlier launch already left nothing undecided
@@ -915,17 +914,10 @@ size_t nms_ws_tail_offset(int batch, int H, int W, int cap) {
 }
 // the two-launch form applies when an image's padded masks, rank prefix and a minimal score table fit one workgroup's LDS, a thread owns at
 // most NMS_FIN_MAXW mask words and the mask words fit the state bytes
-// XP_NMS_BANDS = n: split every image into at least n row bands for the finisher (n workgroups per image instead of one; chains across a band border
-// take another launch, launches past convergence exit at once).  Default 1: the finisher's latency is hidden behind the encoders of the next steps and its
-// 16 CUs cost the step nothing; the knob spreads it over the chip where the step's LATENCY matters.
-int nms_min_bands() {
-    static const int v = getenv("XP_NMS_BANDS") ? atoi(getenv("XP_NMS_BANDS")) : 1;
-    return v > 1 ? (v > 32 ? 32 : v) : 1;
-}
 bool nms_two_launch_applies(int H, int W, int R) {
     static const bool force_sweeps = getenv("XP_NMS_SWEEP") != nullptr && atoi(getenv("XP_NMS_SWEEP")) != 0;     // A/B: the round-1/2 sweep form
     if (force_sweeps || W < 32) return false;
-    const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS, nms_min_bands());
+    const NmsFinishPlan pl = nms_finish_plan(H, W, R, NMS_FIN_LDS);
     return pl.wpr <= 64 && H < 65536 && W < 65536 && pl.list_cap >= 2048 && pl.bands <= 32;
 }
 }  // namespace
@@ -964,13 +956,12 @@ static int box_nms_two_launch(const float* prob, float* out, void* workspace, in
         if (tab.reach == 6) hipLaunchKernelGGL((nms_round_kernel<6, false>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
         else hipLaunchKernelGGL((nms_round_kernel<0, false>), rgrid, dim3(256), 0, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], H, W, wpr, tab);
     }
-    const int min_bands = nms_min_bands();
-    const NmsFinishPlan pl = nms_finish_plan(H, W, tab.reach, NMS_FIN_LDS, min_bands);
+    const NmsFinishPlan pl = nms_finish_plan(H, W, tab.reach, NMS_FIN_LDS);
     const int launches = pl.bands > 1 ? (band_sweeps > 0 ? band_sweeps : 1) : 1;
     if (pl.bands > 1) hipLaunchKernelGGL(nms_reset_counters_kernel, dim3(1), dim3(64), 0, s, w.counters);
     for (int sw = 0; sw < launches; ++sw, cur ^= 1) {
-        if (tab.reach == 6) hipLaunchKernelGGL(nms_finish_kernel<6>, dim3(pl.bands, batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], (int*)w.gtab, H, W, tab, w.counters, sw, w.info, min_bands);
-        else hipLaunchKernelGGL(nms_finish_kernel<0>, dim3(pl.bands, batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], (int*)w.gtab, H, W, tab, w.counters, sw, w.info, min_bands);
+        if (tab.reach == 6) hipLaunchKernelGGL(nms_finish_kernel<6>, dim3(pl.bands, batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], (int*)w.gtab, H, W, tab, w.counters, sw, w.info);
+        else hipLaunchKernelGGL(nms_finish_kernel<0>, dim3(pl.bands, batch), dim3(NMS_FIN_THREADS), NMS_FIN_LDS, s, prob, out, um[cur], km[cur], um[cur ^ 1], km[cur ^ 1], (int*)w.gtab, H, W, tab, w.counters, sw, w.info);
     }
     if (pl.bands > 1 && launches != NMS_MAX_SWEEPS) hipLaunchKernelGGL(nms_publish_counter_kernel, dim3(1), dim3(64), 0, s, w.counters, launches - 1);
     XP_LAUNCH_CHECK();

@@ -11,7 +11,6 @@ static const XpKnob kXpKnobs[] = {
     {"XP_DENSE_ENGINE", "api.cpp", "initial value of xp_set_dense_engine: h2 (default) | x3"},
     {"XP_DENSE_PRODUCTS", "api.cpp", "initial value of xp_set_dense_products: 6 (default) | 3 | 1"},
     {"XP_RING", "gemm_ring.hip", "0: keep every layer on the round-4 GEMM kernels (default 1: ring engine for N, K >= 256 layers of the split class)"},
-    {"XP_RING_F16", "gemm_ring.hip", "1: also route the fp16 class's K, N >= 384 layers to the ring engine (default 0: slower in the three-stream step)"},
     {"XP_RING_TILE", "gemm_ring.hip", "force the ring tile: 0 = 256x256, 1 = 256x128, 2 = 128x128"},
     {"XP_H2P", "gemm_h2p.hip", "ping-pong split-fp16 GEMM: 0 off, 1 (default) K >= 768 and N >= 384, 2 widened"},
     {"XP_H2_ENGINE", "gemm_h2.hip", "rs | lds: force the row-stationary / tile variant of the split-fp16 GEMM"},
@@ -29,8 +28,6 @@ static const XpKnob kXpKnobs[] = {
     {"XP_FUSED_X3", "model.cpp", "1: fused block kernels on the x3 planes under the h2 engine"},
     {"XP_NO_LN_PROJ_F16", "model.cpp", "fp16 class: LayerNorm and in_proj as two launches"},
     {"XP_NO_FUSED_MLP_F16", "model.cpp", "fp16 class: 1 two-GEMM MLP everywhere, 2 fused MLP behind a separate LayerNorm"},
-    {"XP_MLP_PP", "mlp_fused.hip", "ping-pong chunk loop of the split-fp16 fused tail: 0 (default) off, 1 C = 192, 2 also C = 96 (profiles/r5_mlp_pingpong.txt)"},
-    {"XP_MLP_WS", "mlp_fused.hip", "warp-specialised instance of the split-fp16 fused tail at C = 96 (experiment, bit-identical, slower: profiles/r5_mlp_warp_specialised.txt): 1 = 8 matrix + 4 vector waves, 2 = 4 + 4"},
     {"XP_MLP_TAIL", "mlp_fused.hip", "0: no separate 4-wave launch for a last round less than half full (C = 192)"},
     {"XP_MLP_NW8", "mlp_fused.hip", "1: 8-wave workgroups in the x3 fused tail (C <= 96)"},
     {"XP_MLP_H2_NW4", "mlp_fused.hip", "1: 4-wave workgroups in the h2 fused tail at C = 192"},
@@ -49,7 +46,6 @@ static const XpKnob kXpKnobs[] = {
     {"XP_LN_COVER", "elementwise.hip", "1: LayerNorm lane mapping that covers 96 / 192 / 384-channel rows exactly (different sum order: moves near-ties)"},
     {"XP_NMS_SCHED", "postproc.hip", "NMS local-iteration schedule"},
     {"XP_NMS_SWEEP", "postproc.hip", "NMS sweep count"},
-    {"XP_NMS_BANDS", "postproc.hip", "n > 1: at least n row bands (workgroups) per image in the NMS finisher instead of one (latency of the step, not its throughput)"},
     {"XP_NMS_WIDE_ROUNDS", "postproc.hip", "wide suppression rounds ahead of the NMS finisher"},
     // ---- profiling
     {"XP_PROF_SHAPES", "*.hip", "1: per-shape tags in the HIP-event breakdown (xp_prof_*)"},

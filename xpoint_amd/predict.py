@@ -29,12 +29,19 @@ def _cfg(pred):
     return c
 
 
-def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_mnn", estimate_homography=False):
+def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_mnn", estimate_homography=False, warp_optical=None):
     """data: the reference pair dict ({'optical': {'image','valid_mask',...}, 'thermal': {...}}) on the GPU.
     Returns (out_optical, out_thermal, results) where results[i] = dict(kp_optical, kp_thermal (N,2) int64 (y,x),
     desc_optical, desc_thermal (N,D), matches [DMatch]).  estimate_homography=True adds the registration step of
     predict_align_image_pair.py:287-303: H_est (3,3) float64 mapping optical (x, y) to thermal (identity when fewer than
-    4 matches, as the reference) and matchesMask, from `utils.find_homography` at `reprojection_threshold` (default 3)."""
+    4 matches, as the reference) and matchesMask, from `utils.find_homography` at `reprojection_threshold` (default 3), and — unless
+    warp_optical=False — the script's final product (predict_align_image_pair.py:271, 308): `warped_optical`, the optical image quantised
+    to uint8 RGB as the reference builds `im_optical` and warped by H_est into the thermal frame (`utils.warp_perspective`: INTER_LINEAR,
+    BORDER_CONSTANT; (H, W, 3) uint8 on the device).  warp_optical=True without estimate_homography is an error."""
+    if warp_optical and not estimate_homography:
+        raise ValueError("predict_align_image_pair: warp_optical needs estimate_homography=True (the warp uses H_est)")
+    if warp_optical is None:
+        warp_optical = estimate_homography
     pred = _cfg(cfg_prediction)
     if net.takes_pair():
         out_o, out_t, _ = net(data)
@@ -64,6 +71,8 @@ def predict_align_image_pair(net, data, cfg_prediction=None, match_mode="strict_
                                                     float(pred.get('reprojection_threshold', 3.0)))
             r["H_est"] = H_est if H_est is not None else np.eye(3)
             r["matchesMask"] = mask.ravel().tolist() if mask is not None else []
+            if warp_optical:
+                r["warped_optical"] = utils.warp_perspective(data['optical']['image'][i, 0], r["H_est"], quantise_u8=True, dst_channels=3)
         results.append(r)
     return out_o, out_t, results
 
@@ -94,7 +103,7 @@ class PairPipeline:
     synchronises, checks NMS convergence / capacity and returns host lists."""
 
     def __init__(self, net, batch, H, W, cap=8192, cfg_prediction=None, match_mode="strict_mnn", nms_sweeps=8, overlap=False,
-                 split_encoder=False, estimate_homography=False, ransac_iters=10000, alternate_encoders=False):
+                 split_encoder=False, estimate_homography=False, ransac_iters=10000, alternate_encoders=False, warp_optical=False):
         """overlap=True: two HIP streams — the encoder of call i+1 runs while the detection / matching kernels of call i
         (many small, latency-bound launches) are still in flight; encoder outputs are double-buffered.  Results of a
         call are complete after fetch() / torch.cuda.synchronize(), exactly as without overlap."""
@@ -118,6 +127,13 @@ class PairPipeline:
         self.device = dev
         with torch.cuda.device(dev):            # streams / events below belong to the model's device, whatever device is current
             self._init_buffers(net, H, W, estimate_homography, ransac_iters)
+            # warp_optical: the registration output of predict_align_image_pair.py:308 for every pair, stream-ordered behind the robust fit —
+            # the optical image (quantised to uint8 as the reference's im_optical, :271) warped by the DEVICE-resident H_est
+            self.warp_optical = bool(warp_optical)
+            if self.warp_optical:
+                if not self.estimate_homography:
+                    raise ValueError("PairPipeline: warp_optical needs estimate_homography=True")
+                self.hg["warped"] = torch.empty((self.B, self.H, self.W), dtype=torch.uint8, device=dev)
 
     def _init_buffers(self, net, H, W, estimate_homography, ransac_iters):
         dev = self.device
@@ -303,6 +319,9 @@ class PairPipeline:
             _lib.check(lib.xp_find_homography(ptr(h["src"]), ptr(h["dst"]), ptr(m["match_count"]), B, self.cap,
                                               float(self.pred.get('reprojection_threshold', 3.0)), self.ransac_iters, 0, ptr(h["H"]), ptr(h["mask"]),
                                               ptr(h["n_inliers"]), ptr(h["ws"]), h["ws"].numel() * 8, st), "xp_find_homography")
+            if self.warp_optical:
+                _lib.check(lib.xp_warp_perspective(ptr(self.images_b[k]), ctypes.c_void_p(h["warped"].data_ptr()), ctypes.c_void_p(h["H"].data_ptr()),
+                                                   B, H, W, H, W, 1, 1, 2, 0, st), "xp_warp_perspective")
         return self
 
     def match_stats(self):
@@ -557,6 +576,8 @@ class PairPipeline:
             if self.estimate_homography:
                 extra = dict(H_est=self.hg["H"][i].cpu().numpy(), matchesMask=self.hg["mask"][i, :nm].cpu().numpy(),
                              n_inliers=int(self.hg["n_inliers"][i].item()))
+                if self.warp_optical:
+                    extra["warped_optical"] = self.hg["warped"][i].cpu()
             out.append(dict(extra, kp_optical=self.kp[i, :no].cpu().long(), kp_thermal=self.kp[B + i, :nt].cpu().long(),
                             desc_optical=self.desc[i, :no].cpu(), desc_thermal=self.desc[B + i, :nt].cpu(),
                             match_q=self.m["match_q"][i, :nm].cpu().numpy(), match_t=self.m["match_t"][i, :nm].cpu().numpy(),

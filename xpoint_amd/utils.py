@@ -299,3 +299,60 @@ def find_homography(src_pts, dst_pts, reproj_threshold=3.0, max_iters=10000, see
     if int(n_inl[0].item()) == 0:
         return None, np.zeros((n, 1), np.uint8)
     return H[0].cpu().numpy(), mask[0].cpu().numpy().reshape(n, 1)
+
+
+# ---------------------------------------------------------------- image registration output
+def warp_perspective(img, M, dsize=None, inverse_map=False, quantise_u8=False, dst_channels=None):
+    """cv2.warpPerspective(img, M, dsize, flags=INTER_LINEAR [| WARP_INVERSE_MAP], borderMode=BORDER_CONSTANT) on the device
+    (reference predict_align_image_pair.py:308, demo.py:225-249).
+
+    img: device tensor uint8 or float32, (H, W), (H, W, C) or batched (B, H, W, C) with C <= 4 channel-interleaved as cv2 images are
+    (a (B, 1, H, W) network input is accepted as B one-channel images); M: (3, 3) or (B, 3, 3) forward map src -> dst in (x, y)
+    — numpy, or a float64 device tensor such as `find_homography_batched` returns (no host round trip); dsize = (width, height)
+    as in cv2 (default: the source size).  quantise_u8: a float32 image in [0, 1] is quantised on load exactly as the reference
+    builds `im_optical` ((np.clip(img, 0, 1) * 255.0).astype(np.uint8)) and the result is uint8; dst_channels=3 replicates a
+    one-channel source (cv2.COLOR_GRAY2RGB ahead of the warp).  Returns a device tensor shaped like the input with (Hd, Wd).
+    Arithmetic: OpenCV's documented 1/32-pixel fixed-point scheme (include/xpoint_hip.h: xp_warp_perspective; parity unpinned)."""
+    import numpy as np
+    if not (torch.is_tensor(img) and img.is_cuda):
+        raise _lib.XPointHipError("warp_perspective needs a device tensor: xpoint_amd has no CPU fallback")
+    if img.dtype not in (torch.uint8, torch.float32):
+        raise ValueError(f"warp_perspective: uint8 or float32 images, got {img.dtype}")
+    if quantise_u8 and img.dtype != torch.float32:
+        raise ValueError("warp_perspective: quantise_u8 applies to float32 images")
+    x = img
+    shape_kind = x.dim()
+    nchw1 = x.dim() == 4 and x.shape[1] == 1 and x.shape[3] > 4
+    if x.dim() == 2:
+        x = x[None, :, :, None]
+    elif x.dim() == 3:
+        x = x[None]
+    elif x.dim() == 4:
+        if nchw1:
+            x = x.permute(0, 2, 3, 1)
+    else:
+        raise ValueError(f"warp_perspective: bad image shape {tuple(img.shape)}")
+    x = x.contiguous()
+    B, Hs, Ws, C = x.shape
+    Wd, Hd = (Ws, Hs) if dsize is None else (int(dsize[0]), int(dsize[1]))
+    Cd = C if dst_channels is None else int(dst_channels)
+    if torch.is_tensor(M) and M.is_cuda:
+        Md = M.to(torch.float64).reshape(-1, 9)
+    else:
+        Md = torch.from_numpy(np.ascontiguousarray(np.asarray(M.cpu() if torch.is_tensor(M) else M, dtype=np.float64).reshape(-1, 9))).to(x.device)
+    if Md.shape[0] == 1 and B > 1:
+        Md = Md.expand(B, 9)
+    if Md.shape[0] != B:
+        raise ValueError(f"warp_perspective: {Md.shape[0]} matrices for {B} images")
+    Md = Md.contiguous()
+    u8_out = x.dtype == torch.uint8 or quantise_u8
+    out = torch.empty((B, Hd, Wd, Cd), dtype=torch.uint8 if u8_out else torch.float32, device=x.device)
+    dtype = 0 if x.dtype == torch.uint8 else (2 if quantise_u8 else 1)
+    with torch.cuda.device(x.device):
+        _lib.call("xp_warp_perspective", ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(Md.data_ptr()),
+                  B, Hs, Ws, Hd, Wd, C, Cd, dtype, 1 if inverse_map else 0, _lib.current_stream(x.device))
+    if shape_kind == 2:
+        return out[0, :, :, 0] if Cd == 1 else out[0]
+    if shape_kind == 3:
+        return out[0]
+    return out.permute(0, 3, 1, 2) if (nchw1 and Cd == 1) else out
