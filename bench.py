@@ -169,6 +169,65 @@ def pmc_family_for_tag(tag, names):
     return hits
 
 
+def pmc_files(config, precision_class):
+    """The PMC summaries a bench line of (config, precision class) may quote: collected on THAT workload (tools/profile_round.sh), never another one's."""
+    sfx = ("" if config == "c2" else "_" + config) + ("" if precision_class == "f32" else "_" + precision_class)
+    return os.path.join(ROOT, "profiles", f"pmc_traffic{sfx}.json"), os.path.join(ROOT, "profiles", f"pmc_mfma{sfx}.json")
+
+
+def pmc_fields(dominant, bound, config, precision_class, current_hash=None, files=None):
+    """roofline.traffic / frac_mfma_busy_pmc from the committed rocprofv3 --pmc summaries (counters cannot be collected from inside this process), tied
+    to what ran: every summary carries the hash of the kernel sources it was collected on (xpoint_amd.build.source_hash); when it differs from the
+    sources of THIS tree the numbers are still quoted but flagged `traffic_stale` / `frac_mfma_busy_pmc_stale` = true.  A missing file, a summary
+    of another workload or a tag that matches no kernel is reported (`*_error`), never swallowed."""
+    from xpoint_amd.build import source_hash
+    cur = current_hash or source_hash()
+    tf, mf_path = files or pmc_files(config, precision_class)
+    want = config if precision_class == "f32" else precision_class
+    out = {"traffic": None, "kernel_source_hash": cur}
+    try:
+        doc = json.load(open(tf))
+        if doc.get("workload", "c2") != want:
+            raise KeyError(f"{os.path.basename(tf)} holds workload {doc.get('workload')!r}, this line is {want!r}")
+        pmc = doc["kernels"]
+        knames = pmc_family_for_tag(dominant, list(pmc))
+        nl = sum(pmc[k]["launches"] for k in knames)            # launch-weighted mean over the tag's template instances, like `achieved`
+        out["traffic"] = round(sum(pmc[k]["hbm_bytes_per_launch"] * pmc[k]["launches"] for k in knames) / nl)
+        out["traffic_kernel"] = knames[0] if len(knames) == 1 else knames
+        out["traffic_source"] = f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
+        out["traffic_source_hash"] = doc.get("source_hash")
+        out["traffic_stale"] = doc.get("source_hash") != cur
+    except Exception as e:
+        out["traffic_error"] = f"{type(e).__name__}: {e}"
+        sys.stderr.write(f"bench.py: roofline.traffic unavailable for {dominant}: {e}\n")
+    try:
+        doc = json.load(open(mf_path))
+        if doc.get("workload", "c2") != want:
+            raise KeyError(f"{os.path.basename(mf_path)} holds workload {doc.get('workload')!r}, this line is {want!r}")
+        mf = doc["kernels"]
+        kname = pmc_kernel_for_tag(dominant, list(mf))
+        out["frac_mfma_busy_pmc"] = round(mf[kname]["mfma_busy_frac"], 4)
+        out["frac_mfma_busy_pmc_source"] = (f"profiles/{os.path.basename(mf_path)} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                                            "tools/mfma_util.sh)")
+        out["frac_mfma_busy_pmc_stale"] = doc.get("source_hash") != cur
+    except Exception as e:
+        if bound == "mfma":
+            out["frac_mfma_busy_pmc_error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def dense_engine_ceilings():
+    """STATIC reference data (not a measurement of this run): the measured ceilings of the ring dense engine's load path and matrix-instruction stream
+    (tools/ring_bench stage-removal builds), read from profiles/ring_ceilings.json with the source hash and box they were measured on.  Emitted only
+    when the dominant kernel is a gemm_ring_* launch."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "ring_ceilings.json")))
+        doc["static_reference_data"] = True
+        return doc
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -646,39 +705,9 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 1e6, 3)}
-        pmc_suffix = "" if args.precision_class == "f32" else "_" + args.precision_class      # the precision-class runs have their own counter files
-        # HBM traffic and MFMA-busy fraction of that kernel from the committed rocprofv3 PMC runs (counters cannot be collected from inside this
-        # process).  A tag that matches no kernel of the PMC files is reported in the line (traffic_error), never swallowed.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic{pmc_suffix}.json")))["kernels"]
-            knames = pmc_family_for_tag(dominant, list(pmc))
-            nl = sum(pmc[k]["launches"] for k in knames)            # launch-weighted mean over the tag's template instances, like `achieved`
-            roof["traffic"] = round(sum(pmc[k]["hbm_bytes_per_launch"] * pmc[k]["launches"] for k in knames) / nl)
-            roof["traffic_kernel"] = knames[0] if len(knames) == 1 else knames
-            roof["traffic_source"] = f"profiles/pmc_traffic{pmc_suffix}.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; (2F+W)*1024 bytes per launch)"
-        except Exception as e:
-            roof["traffic_error"] = f"{type(e).__name__}: {e}"
-            sys.stderr.write(f"bench.py: roofline.traffic unavailable for {dominant}: {e}\n")
-        try:
-            mf = json.load(open(os.path.join(ROOT, "profiles", f"pmc_mfma{pmc_suffix}.json")))["kernels"]
-            kname = pmc_kernel_for_tag(dominant, list(mf))
-            roof["frac_mfma_busy_pmc"] = round(mf[kname]["mfma_busy_frac"], 4)
-            roof["frac_mfma_busy_pmc_source"] = f"profiles/pmc_mfma{pmc_suffix}.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), tools/mfma_util.sh)"
-        except Exception as e:
-            if roof["bound"] == "mfma":
-                roof["frac_mfma_busy_pmc_error"] = f"{type(e).__name__}: {e}"
-        # What bounds the dense engine: MEASURED ceilings of the ring GEMM's own load pattern and of its matrix-instruction stream, from the
-        # stage-removal builds of tools/ring_bench (profiles/r5_ring_stage_removal.txt) — not a blend of guide rows.  Constant per build: re-measured by
-        # `tools/ring_dbg.sh run`, copied here by hand with the file that holds them.
-        roof["dense_engine_ceilings"] = {
-            "source": "profiles/r5_ring_stage_removal.txt (tools/ring_bench: XP_RING_DBG=5 = the GEMM's own LDS-DMA load pattern with matrix instructions and fragment reads "
-                      "compiled out; XP_RING_DBG=6 = matrix instructions only), 8192 x 4096 x 4096, three-product class",
-            "l2_to_lds_tb_s": {"256x256_S2": 10.25, "256x128_S3": 13.19, "128x128_S4": 12.55},
-            "needed_at_full_matrix_rate_tb_s": {"256x256": 11.5, "256x128": 17.2, "128x128": 23.0},
-            "matrix_pipe_only_pflops": 1.52, "kernel_pflops": 1.25,
-            "note": "the load path delivers 10 - 17 TB/s to the LDS (19 - 32 B/clk/CU; bytes in flight are capped by the LDS ring), the matrix pipe alone sustains 1.5 PF/s "
-                    "(clock held down under dense MFMA), the kernel reaches 1.25 PF/s on a large GEMM; the model's layers (0.9 - 1.8 rounds of tiles, 6 - 96 slabs) are "
-                    "bounded by per-tile fixed cost and the epilogue's write burst instead: profiles/r5_ring_instep_ab.txt"}
+        roof.update(pmc_fields(dominant, roof["bound"], args.config, args.precision_class))
+        if dominant.startswith("gemm_ring"):
+            roof["dense_engine_ceilings"] = dense_engine_ceilings()
         roof.update({"avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom["launches"]})
         if overlap or args.graph:
             roof["measured_in"] = ("3 single-stream eager passes of the same step next to the timed region: " +
@@ -765,11 +794,15 @@ def main():
         if pcie is not None:
             out["pcie_inclusive_pairs_per_s"] = round(pcie, 2)
             out["pcie_inclusive_u8_pairs_per_s"] = round(pcie_u8, 2)
-        if not args.no_cpu_baseline and world == 1:
+        if dist.is_initialized():
+            dist.destroy_process_group()          # the other ranks are done: the baseline below has the host to itself
+        if not args.no_cpu_baseline:
+            # rank 0, after the timed region, at every world size (bounded: 24 pairs at N = 1 = 10 - 30 s; 8 pairs = ~3 - 7 s beside an N-rank job, so that an
+            # 8-GPU line carries the same keys as the 1-GPU line)
             try:
                 if pin.get("applied"):
                     affinity.restore(pin["previous"])
-                out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_pairs if world == 1 else min(args.cpu_pairs, 8))
             except Exception as e:   # the baseline must never hide the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
         json_out.write(json.dumps(out) + "\n")

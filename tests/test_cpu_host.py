@@ -253,3 +253,39 @@ def test_knob_registry_is_complete():
         used |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(XP_[A-Z0-9_]+)"', txt))
     assert used - set(reg) == set(), f"read but not registered: {sorted(used - set(reg))}"
     assert set(reg) - used == set(), f"registered but read nowhere: {sorted(set(reg) - used)}"
+
+
+def test_bench_pmc_numbers_are_tied_to_the_kernel_sources(tmp_path):
+    """every PMC summary under profiles/ carries the hash of the kernel sources it was collected on; bench.py quotes its numbers with
+    `traffic_stale` / `frac_mfma_busy_pmc_stale` = (hash differs from this tree), refuses a summary of another workload, and reports a missing file —
+    shown by flipping one source byte in a copy of csrc/."""
+    import importlib, json, shutil, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    from xpoint_amd import build
+    h0 = build.source_hash()
+    assert len(h0) == 16 and h0 == build.source_hash()
+    csrc = tmp_path / "csrc"; shutil.copytree(os.path.join(root, "xpoint_amd", "csrc"), csrc, ignore=shutil.ignore_patterns("_obj"))
+    assert build.source_hash(str(csrc)) == h0
+    f = csrc / "mlp_fused.hip"; b = bytearray(f.read_bytes()); b[100] ^= 1; f.write_bytes(bytes(b))
+    h1 = build.source_hash(str(csrc))
+    assert h1 != h0
+    tf, mf = tmp_path / "pmc_traffic.json", tmp_path / "pmc_mfma.json"
+    kern = "mlp_fused_kernel<192, 8, 1, 3, true>"
+    json.dump({"source_hash": h0, "workload": "c2", "kernels": {kern: {"launches": 4, "hbm_bytes_per_launch": 2.5e8}}}, open(tf, "w"))
+    json.dump({"source_hash": h0, "workload": "c2", "kernels": {kern: {"launches": 4, "mfma_busy_frac": 0.34}}}, open(mf, "w"))
+    fresh = bench.pmc_fields("proj_mlp_fused_h2_c192", "mfma", "c2", "f32", current_hash=h0, files=(str(tf), str(mf)))
+    assert fresh["traffic"] == 250000000 and fresh["traffic_stale"] is False and fresh["frac_mfma_busy_pmc_stale"] is False and fresh["kernel_source_hash"] == h0
+    stale = bench.pmc_fields("proj_mlp_fused_h2_c192", "mfma", "c2", "f32", current_hash=h1, files=(str(tf), str(mf)))
+    assert stale["traffic"] == 250000000 and stale["traffic_stale"] is True and stale["frac_mfma_busy_pmc_stale"] is True and stale["traffic_source_hash"] == h0
+    other = bench.pmc_fields("proj_mlp_fused_h2_c192", "mfma", "c4", "f32", current_hash=h0, files=(str(tf), str(mf)))     # C2's bytes are not C4's
+    assert other["traffic"] is None and "workload" in other["traffic_error"] and "frac_mfma_busy_pmc_error" in other
+    missing = bench.pmc_fields("proj_mlp_fused_h2_c192", "mfma", "c2", "f32", current_hash=h0, files=(str(tmp_path / "no.json"), str(mf)))
+    assert missing["traffic"] is None and "traffic_error" in missing
+    # per-configuration file names
+    assert [os.path.basename(x) for x in bench.pmc_files("c2", "f32")] == ["pmc_traffic.json", "pmc_mfma.json"]
+    assert [os.path.basename(x) for x in bench.pmc_files("c4", "f32")] == ["pmc_traffic_c4.json", "pmc_mfma_c4.json"]
+    assert [os.path.basename(x) for x in bench.pmc_files("c2", "amp16f")] == ["pmc_traffic_amp16f.json", "pmc_mfma_amp16f.json"]
+    # static reference data is labelled as such
+    assert bench.dense_engine_ceilings().get("static_reference_data") is True

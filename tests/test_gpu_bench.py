@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 def _run(n, extra=()):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    # the CPU baseline stays ON (bounded to one pair here): every line, at every world size, must carry it
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--cpu-pairs", "1",
            "--no-other-backend", *extra]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
 
@@ -50,6 +51,14 @@ def test_bench_launcher_rccl_world():
     aff = out["rank_cpu_affinity"]
     assert len(aff["cpus_per_rank"]) == world and aff["rank0"]["count"] >= 1 and aff["rank0"]["applied"] in (True, False)
     assert out["precision_class"] == "f32" and "NOT the headline" not in out["metric"]
+    # round 6: the N-rank line is complete — the keys of the 1-GPU line at every world size (cpu_baseline runs on rank 0 after the process group is torn down)
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and "sample" in cb, cb
+    assert set(("roofline", "cpu_baseline", "rccl_ranks", "per_rank_pairs_per_s", "rank_cpu_affinity", "timed_regions", "rank_headers")) <= set(out)
+    # and the counter numbers quoted in it are tied to what ran: source hash of this tree, stale flag (a missing / foreign summary is an error key)
+    roof = out["roofline"]
+    assert len(roof["kernel_source_hash"]) == 16
+    assert ("traffic_stale" in roof and roof["traffic_source_hash"]) or "traffic_error" in roof, roof
 
 
 def test_bench_hygiene_keys_and_fast_class_label():

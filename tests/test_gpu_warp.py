@@ -1,0 +1,196 @@
+"""§8(f) rank 2, last step — the aligned image: xp_warp_perspective / utils.warp_perspective / predict_align_image_pair(..., estimate_homography=True)
+against the oracle's plain-C restatement of OpenCV's documented INTER_LINEAR fixed-point scheme (oracle/csrc/oracle_kernels.c:
+xo_warp_perspective_u8 / _f32; reference call predict_align_image_pair.py:308).  PARITY UNPINNED vs OpenCV itself (absent); the bar here is
+bit-equality HIP == oracle for uint8 and for float32 (tolerance written: 0 for u8, 1e-6 for f32 — measured 0)."""
+import numpy as np
+import pytest
+import torch
+
+from xpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _img(tag, shape, dtype):
+    u = synth.uniform(tag, shape, 0.0, 1.0)
+    return (u * 255.999).astype(np.uint8) if dtype == np.uint8 else u.astype(np.float32)
+
+
+def _homography(kind, H, W):
+    if kind == "identity":
+        return np.eye(3)
+    if kind == "shift_int":
+        return np.array([[1, 0, 7], [0, 1, -5], [0, 0, 1.0]])
+    if kind == "shift_frac":
+        return np.array([[1, 0, 3.3], [0, 1, 2.71], [0, 0, 1.0]])
+    if kind == "affine":
+        a = 0.21
+        return np.array([[1.1 * np.cos(a), -np.sin(a), 0.12 * W], [np.sin(a), 0.93 * np.cos(a), -0.08 * H], [0, 0, 1.0]])
+    if kind == "projective":
+        return np.array([[0.94, 0.07, 11.3], [-0.05, 1.06, 6.9], [1.7e-4, -2.3e-4, 1.0]])
+    if kind == "strong":          # the horizon (w = 0) crosses the destination: W == 0 / huge coordinates / saturation paths
+        return np.array([[1.3, 0.2, -20.0], [0.1, 0.8, 14.0], [4.0e-3, 2.5e-3, 1.0]])
+    if kind == "far":             # the whole source lands outside the destination
+        return np.array([[1, 0, 10.0 * W], [0, 1, 0], [0, 0, 1.0]])
+    if kind == "singular":        # det = 0: OpenCV's invert gives the zero matrix -> every pixel samples source (0, 0)
+        return np.array([[1, 2, 3], [2, 4, 6], [0, 0, 1.0]])
+    raise KeyError(kind)
+
+
+KINDS = ["identity", "shift_int", "shift_frac", "affine", "projective", "strong", "far", "singular"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_warp_perspective_equals_oracle(gpu_lib, kind, dtype):
+    from oracle import xpoint_oracle as xo
+    from xpoint_amd import utils
+    H, W = 120, 200                      # 200 = three 64-wide blocks + a ragged one: the block base of OpenCV's coordinate arithmetic matters
+    img = _img(f"warp{kind}", (H, W), dtype)
+    M = _homography(kind, H, W)
+    ref = xo.warp_perspective(img, M)
+    got = utils.warp_perspective(torch.from_numpy(img).cuda(), M).cpu().numpy()
+    assert got.dtype == ref.dtype and got.shape == ref.shape
+    if dtype == np.uint8:
+        assert np.array_equal(got, ref), int((got != ref).sum())
+    else:
+        assert float(np.abs(got - ref).max()) <= 1e-6
+        assert np.array_equal(got, ref)          # same operation order, no contraction: the same bits
+    if kind == "identity":
+        assert np.array_equal(got, img)
+    if kind == "shift_int":
+        assert np.array_equal(got[:-5, 7:], img[5:, :-7]) and not got[:, :7].any() and not got[-5:].any()
+    if kind == "far":
+        assert not got.any()
+    if kind == "singular":
+        assert np.all(got == img[0, 0])
+
+
+def test_warp_perspective_shapes_channels_batch_dsize_inverse(gpu_lib):
+    from oracle import xpoint_oracle as xo
+    from xpoint_amd import utils
+    H, W = 57, 91
+    rgb = _img("warprgb", (H, W, 3), np.uint8)
+    Ms = np.stack([_homography(k, H, W) for k in ("projective", "affine", "shift_frac")])
+    # (H, W, C) image, dsize different from the source size (width, height as in cv2), narrow destination (block width = the width)
+    for dsize in ((140, 33), (40, 70), (64, 8)):
+        ref = xo.warp_perspective(rgb, Ms[0], dsize)
+        got = utils.warp_perspective(torch.from_numpy(rgb).cuda(), Ms[0], dsize).cpu().numpy()
+        assert got.shape == (dsize[1], dsize[0], 3) and np.array_equal(got, ref), dsize
+    # batch with one matrix per image, matrices as a float64 DEVICE tensor (what find_homography_batched returns)
+    batch = np.stack([_img(f"warpb{i}", (H, W, 1), np.float32) for i in range(3)])
+    got = utils.warp_perspective(torch.from_numpy(batch).cuda(), torch.from_numpy(Ms).cuda()).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], xo.warp_perspective(batch[i], Ms[i]))
+    # one matrix broadcast over the batch; the network's (B, 1, H, W) layout comes back as (B, 1, H, W)
+    nchw = torch.from_numpy(batch[..., 0][:, None]).cuda()
+    got = utils.warp_perspective(nchw, Ms[1])
+    assert tuple(got.shape) == (3, 1, H, W)
+    assert np.array_equal(got[2, 0].cpu().numpy(), xo.warp_perspective(batch[2, ..., 0], Ms[1]))
+    # cv2.WARP_INVERSE_MAP: M is used as given; equals warping by inv(M) up to the inversion's rounding (here: against the oracle's own flag)
+    ref = xo.warp_perspective(rgb, Ms[0], inverse_map=True)
+    got = utils.warp_perspective(torch.from_numpy(rgb).cuda(), Ms[0], inverse_map=True).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # gray -> 3 identical channels (cv2.COLOR_GRAY2RGB ahead of the warp), and the reference's quantisation of a [0, 1] float image on load
+    gray = synth.uniform("warpq", (H, W), -0.2, 1.2).astype(np.float32)
+    ref = xo.warp_perspective(np.repeat(xo.to_u8_image(gray)[..., None], 3, axis=2), Ms[0])
+    got = utils.warp_perspective(torch.from_numpy(gray).cuda(), Ms[0], quantise_u8=True, dst_channels=3).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, ref)
+
+
+def test_warp_perspective_argument_errors(gpu_lib):
+    import ctypes
+    from xpoint_amd import _lib as L, utils
+    img = torch.zeros((8, 8), dtype=torch.uint8)
+    with pytest.raises(L.XPointHipError):                      # no CPU fallback
+        utils.warp_perspective(img, np.eye(3))
+    with pytest.raises(ValueError):
+        utils.warp_perspective(img.cuda().to(torch.int32), np.eye(3))
+    with pytest.raises(ValueError):
+        utils.warp_perspective(img.cuda(), np.eye(3), quantise_u8=True)
+    with pytest.raises(ValueError):
+        utils.warp_perspective(torch.zeros((2, 8, 8, 1), dtype=torch.uint8).cuda(), np.zeros((3, 3, 3)))
+    d = img.cuda(); o = torch.empty_like(d); M = torch.eye(3, dtype=torch.float64).cuda()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = L.current_stream()
+    for args in ((None, vp(o), vp(M), 1, 8, 8, 8, 8, 1, 1, 0, 0), (vp(d), vp(o), vp(M), 1, 8, 8, 8, 8, 5, 5, 0, 0),
+                 (vp(d), vp(o), vp(M), 1, 8, 8, 8, 8, 3, 1, 0, 0), (vp(d), vp(o), vp(M), 1, 8, 8, 8, 8, 1, 1, 7, 0),
+                 (vp(d), vp(d), vp(M), 1, 8, 8, 8, 8, 1, 1, 0, 0), (vp(d), vp(o), vp(M), 1, 40000, 8, 8, 8, 1, 1, 0, 0)):
+        with pytest.raises(L.XPointHipError):
+            L.call("xp_warp_perspective", *args, st)
+
+
+def test_predict_align_image_pair_returns_the_aligned_image(gpu_lib):
+    """predict_align_image_pair.py:271, 283-308 end to end: the flow returns `warped_optical` = the uint8 RGB optical image warped by H_est.
+    thermal == optical -> H_est = identity -> the warp is the quantised image itself; fewer than 4 matches -> identity too (the reference's
+    `H_est = np.eye(3,3)` branch); the batched PairPipeline's device-resident warp equals the per-pair flow."""
+    from oracle import xpoint_oracle as xo
+    from xpoint_amd import models
+    from xpoint_amd.predict import PairPipeline, predict_align_image_pair
+    H, W, B = 96, 128, 2
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = models.XPoint(cfg)
+    net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
+    net = net.to("cuda").eval()
+    d = synth.to_torch(synth.make_pair_batch(4, B, H, W), "cuda")
+    with torch.no_grad():
+        _, _, res = predict_align_image_pair(net, d, estimate_homography=True)
+    for i, r in enumerate(res):
+        img = d["optical"]["image"][i, 0].cpu().numpy()
+        ref = xo.warp_perspective(np.repeat(xo.to_u8_image(img)[..., None], 3, axis=2), r["H_est"])
+        got = r["warped_optical"].cpu().numpy()
+        assert got.shape == (H, W, 3) and got.dtype == np.uint8 and np.array_equal(got, ref)
+    d["thermal"]["image"] = d["optical"]["image"].clone()
+    with torch.no_grad():
+        _, _, res = predict_align_image_pair(net, d, estimate_homography=True)
+        pipe = PairPipeline(net, B, H, W, cap=2048, estimate_homography=True, warp_optical=True)
+        out = pipe.run(d["optical"]["image"], d["thermal"]["image"]).fetch()
+    for i, r in enumerate(res):
+        q = xo.to_u8_image(d["optical"]["image"][i, 0].cpu().numpy())
+        assert np.abs(r["H_est"] - np.eye(3)).max() < 1e-6
+        assert np.array_equal(r["warped_optical"].cpu().numpy(), np.repeat(q[..., None], 3, axis=2))
+        assert np.array_equal(out[i]["warped_optical"].numpy(), xo.warp_perspective(q, out[i]["H_est"]))
+    # fewer than four matches: detection threshold no pixel reaches -> no keypoints, no matches, identity, the quantised image back
+    with torch.no_grad():
+        _, _, res = predict_align_image_pair(net, d, dict(detection_threshold=2.0), estimate_homography=True)
+    assert len(res[0]["matches"]) == 0 and np.array_equal(res[0]["H_est"], np.eye(3)) and res[0]["matchesMask"] == []
+    assert np.array_equal(res[0]["warped_optical"].cpu().numpy()[..., 0], xo.to_u8_image(d["optical"]["image"][0, 0].cpu().numpy()))
+    with pytest.raises(ValueError):
+        predict_align_image_pair(net, d, warp_optical=True)
+    with torch.no_grad():
+        _, _, res = predict_align_image_pair(net, d, estimate_homography=True, warp_optical=False)
+    assert "warped_optical" not in res[0] and "H_est" in res[0]
+
+
+def test_h_correctness_on_synthetic_ground_truth_homographies(gpu_lib):
+    """benchmark_evaluation.py:560-586, 755-830: thermal = the optical image warped by a KNOWN homography (this build's warp) -> compute_metrics'
+    'homography' block (mean corner distance, h_correctness at epsilon) from the estimated model; and the aligned image closes the loop: warping the
+    optical image by H_est reproduces the thermal image where both are defined."""
+    from xpoint_amd import evaluation as ev, models, utils
+    H, W, B = 128, 160, 2
+    cfg = synth.xpoint_exp1_config(H, W)
+    net = models.XPoint(cfg)
+    net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
+    net = net.to("cuda").eval()
+    d = synth.to_torch(synth.make_pair_batch(7, B, H, W), "cuda")
+    # ground truth in the reference's (row, col) convention for data[...]['homography'] (warp_keypoints works on (y, x) points): a small
+    # translation + shear;  in (x, y) for the image warp
+    H_yx = np.array([[1.0, 0.01, 3.0], [-0.008, 1.0, -2.0], [0.0, 0.0, 1.0]])
+    P = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1.0]])
+    H_xy = P @ H_yx @ P
+    d["thermal"]["image"] = utils.warp_perspective(d["optical"]["image"], H_xy)
+    eye = torch.eye(3).repeat(B, 1, 1)
+    d["optical"]["homography"] = eye.clone(); d["thermal"]["homography"] = torch.from_numpy(H_yx).float().repeat(B, 1, 1)
+    config = {"prediction": {"nms": 4, "topk": 0, "cpu_nms": False, "detection_threshold": 0.015,
+                             "matching": {"method": "bfmatcher", "knn_matches": False, "method_kwargs": {"crossCheck": True}}}}
+    with torch.no_grad():
+        out = ev.compute_metrics(net, [d], "cuda", config, thresh_warp=[1, 3], ransac_reproj_thresholds=[3])
+        _, _, res = __import__("xpoint_amd.predict", fromlist=["x"]).predict_align_image_pair(net, d, config["prediction"], estimate_homography=True)
+    hd = out["homography"][3]
+    assert set(hd) == {"average_h_error", "h_correctness"} and set(hd["h_correctness"]) == {"epsilon_warp_th1", "epsilon_warp_th3"}
+    assert 0.0 <= hd["h_correctness"]["epsilon_warp_th1"] <= hd["h_correctness"]["epsilon_warp_th3"] <= 1.0
+    # the synthetic network's keypoints are texture-driven, so a warped copy re-detects most of them: the model is recovered to well under 3 px
+    assert hd["average_h_error"] < 3.0 and hd["h_correctness"]["epsilon_warp_th3"] == 1.0, hd
+    for i, r in enumerate(res):
+        assert sum(r["matchesMask"]) >= 4
+        np.testing.assert_allclose(r["H_est"], H_xy, atol=0.05 * np.array([[1, 1, 40], [1, 1, 40], [0.01, 0.01, 1]]))

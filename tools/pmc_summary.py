@@ -1,5 +1,6 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs per kernel (KB per launch).
-usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv>"""
+usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json [workload tag: c2 | c4 | c5 | amp16f]]
+The json carries the hash of the kernel sources (xpoint_amd.build.source_hash) so that bench.py can tell when the numbers are stale."""
 import collections, csv, re, sys
 
 def short(name):
@@ -17,14 +18,17 @@ def agg(path, counter):
         d[k][0] += float(r["Counter_Value"]); d[k][1] += 1
     return d
 
-import json
+import json, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from xpoint_amd.build import source_hash
 f = agg(sys.argv[1], "FETCH_SIZE"); w = agg(sys.argv[2], "WRITE_SIZE")
 if len(sys.argv) > 3:   # machine-readable copy for bench.py's roofline.traffic
     js = {k: {"launches": f[k][1], "fetch_kb": f[k][0] / f[k][1], "write_kb": w.get(k, [0.0, 1])[0] / max(w.get(k, [0.0, 1])[1], 1)} for k in f}
     for k in js:
         js[k]["hbm_bytes_per_launch"] = (2 * js[k]["fetch_kb"] + js[k]["write_kb"]) * 1024
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                       "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)", "kernels": js}, open(sys.argv[3], "w"), indent=1)
+                       "(gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",
+               "source_hash": source_hash(), "workload": (sys.argv[4] if len(sys.argv) > 4 else "c2"), "kernels": js}, open(sys.argv[3], "w"), indent=1)
 print("# per-launch averages; FETCH_SIZE/WRITE_SIZE are in KB as rocprofv3 reports them.")
 print("# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request for wide coalesced")
 print("# reads, so read bytes ~= 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 is exact for 16-B/lane streaming stores.")

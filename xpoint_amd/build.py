@@ -14,6 +14,20 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-I", os.path.join(HERE, "..", "include"), "-I", CSRC] + os.environ.get("XP_EXTRA_HIPCC_FLAGS", "").split()
 
 
+def source_hash(csrc: str = CSRC, include: str = os.path.join(HERE, "..", "include")) -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.cpp, *.h, include/*.h; names + bytes, sorted).
+    Stored next to every PMC summary under profiles/ (tools/pmc_summary.py, tools/mfma_util.sh) and compared by bench.py: counter numbers
+    quoted in a bench line that were collected on OTHER kernel sources are flagged `traffic_stale` / `frac_mfma_busy_pmc_stale`."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")) +
+                   glob.glob(os.path.join(include, "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(b"\0")
+        h.update(open(f, "rb").read()); h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def _sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
@@ -50,4 +64,7 @@ def build(force: bool = False, jobs: int = 6) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build(force="--force" in sys.argv))

@@ -42,15 +42,6 @@
 #ifndef XP_MLP_FRAG_DEPTH
 #define XP_MLP_FRAG_DEPTH 2   /* LDS fragment look-ahead of the split-fp16 instances, in k slabs (1 = round 4) */
 #endif
-#ifndef XP_MLP_H2_PIPE
-#define XP_MLP_H2_PIPE 0   /* experiment: split-fp16 instances on the software-pipelined chunk loop (fc1 of chunk c + 1 between the GELU slices of chunk c) */
-#endif
-#ifndef XP_MLP_AGPR
-#define XP_MLP_AGPR 0      /* experiment: accumulators in AccVGPRs (an "a" asm operand makes hipcc select the AGPR form of every MFMA) */
-#endif
-#ifndef XP_MLP_WPE
-#define XP_MLP_WPE 2       /* waves per SIMD the split-fp16 instances are compiled for */
-#endif
 #ifndef XP_MLP_DBG
 #define XP_MLP_DBG 0   /* timing experiments only (wrong results): 1 no GELU, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no bf16 split of the hidden values, 16 no MFMA */
 #endif
@@ -124,12 +115,12 @@ __global__ void mlp_pack_kernel(const uint4* __restrict__ W1, const uint4* __res
     if (u < T::UNITS && k < KD) {
         // x3 (fc1 of chunk c+1 runs ahead of fc2 of chunk c): image n: 0 -> W1(0); odd n < 2NC-1 -> W1((n+1)/2); even n > 0 -> W2(n/2 - 1);
         // n = 2NC-1 -> W2(NC-1).   h2 (one hidden accumulator, chunk after chunk): even n -> W1(n/2), odd n -> W2(n/2).
-        const bool is_w1 = (H2 && !XP_MLP_H2_PIPE) ? !(n & 1) : ((n == 0) || ((n & 1) && n < 2 * NC - 1));
+        const bool is_w1 = H2 ? !(n & 1) : ((n == 0) || ((n & 1) && n < 2 * NC - 1));
         if (is_w1) {
-            const int c = (H2 && !XP_MLP_H2_PIPE) ? n >> 1 : (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
+            const int c = H2 ? n >> 1 : (n + 1) >> 1, s = row >> 5, h = 32 * c + mlp_swap23(row & 31);
             v = mlp_src_unit<H2>(W1, H4, h, s, k);
         } else {
-            const int c = (H2 && !XP_MLP_H2_PIPE) ? n >> 1 : ((n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1), j = row / C, nn = row - j * C;
+            const int c = H2 ? n >> 1 : ((n == 2 * NC - 1) ? NC - 1 : (n >> 1) - 1), j = row / C, nn = row - j * C;
             v = mlp_src_unit<H2>(W2, C, nn, 2 * c + j, k);
         }
     }
@@ -184,16 +175,19 @@ __device__ __forceinline__ void mlp_split2(float x, float y, unsigned& p0, unsig
 }
 
 template <int C, int NW, int MODE, int NP, bool H2>
-__global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)) void mlp_fused_kernel(MlpParams p) {      // h2: two waves per SIMD at every C (two planes resident)
+__global__ __launch_bounds__(NW * 64, H2 ? 2 : ((C <= 96 ? 8 : 4) / NW)) void mlp_fused_kernel(MlpParams p) {      // h2: two waves per SIMD at every C (two planes resident)
     static_assert(NP == 6 || NP == 3 || NP == 1, "partial products per multiply (gemm_x3_core.h)");
     static_assert(!H2 || NP == 3, "the split-fp16 engine always forms its three products");
     constexpr bool PRE = MODE == 1, PROJ_ONLY = MODE == 2;
     using T = MlpTile<C, H2>;
     constexpr int ROWB = T::ROWB;
     constexpr int KS = T::KS, NT = T::NT;
+    // HALF2 (round 6, split-fp16 MLP instances wider than 96 channels): GELU + split of the SECOND half of a hidden chunk run between the fc2 matrix instructions of
+    // its first half instead of ahead of fc2 — no extra registers, same instructions per row in the same order (bit-identical); C = 192: 250 -> 242 - 246 us
+    // per launch, C = 96: no change (left off there).  profiles/r6_mlp_pipelined_agpr.txt
+    constexpr bool HALF2 = H2 && MODE != 2 && C > 96;
     constexpr int NI = T::NI * 4 / NW;          // DMA instructions per wave and image
     static_assert(T::NI * 4 % NW == 0, "image pieces must divide among the waves");
-    if constexpr (H2 && XP_MLP_AGPR) { float dummy_a = 0.f; asm volatile("" :: "a"(dummy_a)); }
     extern __shared__ __align__(16) unsigned char lds[];       // [3 image slots][b1 (H4 floats)][h2: 1 / row scale of fc1 (H4 floats)] — ONE array (LDS-DMA waits)
     unsigned char* const bias_lds = lds + 3 * T::IMGP;
     unsigned char* const inv1_lds = bias_lds + (size_t)p.H4 * 4;
@@ -353,18 +347,18 @@ __global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)
     };
     // VALU slices placed between MFMAs.  Slices 0..15: GELU of element r in place; 16..19 / 20..23: bf16 split of pair q of half 0 / 1.
     auto slice = [&](int k, f32x16& h) {
-        // (pipelined schedule: a slice's result is pinned where the slice stands — hipcc otherwise SINKS this register-only code past the sched_barriers to its
-        // consumer, the fc2 phase, and nothing runs between the matrix instructions: round 6, the ISA of the first XP_MLP_H2_PIPE build)
+        // HALF2 (below): a slice's result is pinned where the slice stands — hipcc otherwise SINKS this register-only code past the sched_barriers to its
+        // consumer and nothing runs between the matrix instructions (round 6: the ISA of the first interleaved build; profiles/r6_mlp_pipelined_agpr.txt)
         if (k < 16) {
             float v = mlp_gelu(H2 ? h[k] * inv_cur[k] : h[k]);
-            if (H2 && XP_MLP_H2_PIPE) asm volatile("" : "+v"(v));
+            if (HALF2) asm volatile("" : "+v"(v));
             h[k] = v;
             return;
         }
         const int j = (k - 16) >> 2, q = (k - 16) & 3;
         if (XP_MLP_DBG & 8) { hp[j][0][q] = __float_as_uint(h[8 * j + 2 * q]); hp[j][1][q] = __float_as_uint(h[8 * j + 2 * q + 1]); hp[j][2][q] = hp[j][0][q]; }
         else mlp_split2<H2>(h[8 * j + 2 * q], h[8 * j + 2 * q + 1], hp[j][0][q], hp[j][1][q], hp[j][2][q]);
-        if (H2 && XP_MLP_H2_PIPE) asm volatile("" : "+v"(hp[j][0][q]), "+v"(hp[j][1][q]));
+        if (HALF2) asm volatile("" : "+v"(hp[j][0][q]), "+v"(hp[j][1][q]));
     };
     // fc1 of one chunk from the W1 image in `slot` into nxt (preloaded with the bias); between the MFMAs, slices [0, NSL) of the
     // previous chunk's accumulators `cur` (NSL = 0: none)
@@ -421,6 +415,15 @@ __global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)
             for (int pp = 6 - NP; pp < 6; ++pp) {
                 if (XP_MLP_DBG & 16) { if (pp == 5) oacc[t][0] += __uint_as_float(hp[j][0][0]) * __uint_as_float(b[i % (FD + 1)][0][0]); }
                 else oacc[t] = mlp_mfma<H2>(hfrag(j, PA[pp]), b[i % (FD + 1)][PB[pp]], oacc[t]);
+                if (HALF2) {
+                    // hidden half 1 (GELU of elements 8..15, then their split) spread over the MFMAs of hidden half 0
+                    constexpr int ORDER[12] = {8, 9, 20, 10, 11, 21, 12, 13, 22, 14, 15, 23};
+                    const int m = i * NP + pp - (6 - NP);
+                    if (i < NT) {
+#pragma unroll
+                        for (int k = (m * 12 + NT * NP - 1) / (NT * NP); k < ((m + 1) * 12 + NT * NP - 1) / (NT * NP); ++k) slice(ORDER[k], cur);
+                    }
+                } else
                 if (i == 0 && pp - (6 - NP) < (NP >= 4 ? 4 : 1)) {      // split of half 1: one pair per MFMA (NP = 6), else all at once
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (NP >= 4 ? q == pp - (6 - NP) : true) slice(20 + q, cur);
@@ -505,13 +508,8 @@ __global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)
     // chunk c: phase A = fc1(c+1) with GELU(c) (all 16 elements) and the split of half 0 between its MFMAs (image 1 + 2c);
     //          phase B = fc2(c) (image 2 + 2c)
     auto iter = [&](int c, f32x16& cur, f32x16& nxt) {
-        if constexpr (H2) {
-            float bv[16];
-            lds_read16_asm(inv1_lds, c, inv_cur);
-            lds_read16_asm(bias_lds, c + 1, bv);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) nxt[r] = bv[r];
-        } else load_bias(c + 1, nxt);
+        if constexpr (H2) load_inv1(c, inv_cur);
+        load_bias(c + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         fc1(slot, nxt, cur, std::integral_constant<int, 20>{});
         end_phase();
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)
         end_phase();
     };
     int c = 0;
-    if constexpr (H2 && !XP_MLP_H2_PIPE) {
+    if constexpr (H2) {
         // split-fp16 instances: ONE hidden accumulator, chunk after chunk — fc1(c), GELU + split, fc2(c) — over a stream packed in that
         // order.  The x3 schedule below (fc1 of chunk c+1 with the GELU of chunk c between its MFMAs, two accumulator sets) spills 149
         // registers at C = 192 with two planes resident and eight waves (8 here); measured 314 -> 272 us at C = 192, 278 -> 266 us at C = 96.
@@ -540,16 +538,16 @@ __global__ __launch_bounds__(NW * 64, H2 ? XP_MLP_WPE : ((C <= 96 ? 8 : 4) / NW)
             }
             if constexpr (H2) { if (XP_MLP_ASM_LDS) lds_read16_asm(inv1_lds, c, inv_cur); else load_inv1(c, inv_cur); }
 #pragma unroll
-            for (int k = 0; k < 20; ++k) slice(k, h0);
+            for (int k = 0; k < 20; ++k) if (!HALF2 || k < 8 || k >= 16) slice(k, h0);
             fc2(slot, h0);
             if (c + 1 < NC) end_phase();
         }
         c = NC;
     }
-    if constexpr (!H2 || XP_MLP_H2_PIPE)
+    if constexpr (!H2)
     for (; c + 2 < NC; c += 2) { iter(c, h0, h1); iter(c + 1, h1, h0); }
     auto tail = [&](f32x16& cur) {         // last chunk: nothing left to overlap the GELU with; image 2 NC - 1
-        if constexpr (H2) lds_read16_asm(inv1_lds, NC - 1, inv_cur);
+        if constexpr (H2) load_inv1(NC - 1, inv_cur);
 #pragma unroll
         for (int k = 0; k < 20; ++k) slice(k, cur);
         fc2(slot, cur);
