@@ -395,6 +395,12 @@ def test_pipeline_edge_cases(gpu_lib):
         torch.cuda.synchronize()
         with pytest.raises(RuntimeError, match="exceed capacity"):
             small.verify()
+        # input contract: one uint8 image (0..255) beside one float image ([0, 1]) would silently run on two scales — refused
+        u8 = (data["optical"]["image"] * 255.0).to(torch.uint8)
+        with pytest.raises(ValueError, match="both images as uint8"):
+            PairPipeline(net, B, H, W, cap=512).run(u8, data["thermal"]["image"])
+        with pytest.raises(ValueError, match="exactly"):
+            PairPipeline(net, B, H, W, cap=512).run(u8[..., :-1], u8[..., :-1])
 
 
 def test_async_nms_reports_non_convergence(gpu_lib):

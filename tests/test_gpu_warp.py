@@ -173,14 +173,12 @@ def test_h_correctness_on_synthetic_ground_truth_homographies(gpu_lib):
     net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)
     net = net.to("cuda").eval()
     d = synth.to_torch(synth.make_pair_batch(7, B, H, W), "cuda")
-    # ground truth in the reference's (row, col) convention for data[...]['homography'] (warp_keypoints works on (y, x) points): a small
-    # translation + shear;  in (x, y) for the image warp
-    H_yx = np.array([[1.0, 0.01, 3.0], [-0.008, 1.0, -2.0], [0.0, 0.0, 1.0]])
-    P = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1.0]])
-    H_xy = P @ H_yx @ P
+    # ground truth: data[...]['homography'] acts on (x, y, 1) — cv2.perspectiveTransform's convention (homographies.py:479-497 flips the (y, x) keypoints
+    # before applying it) — i.e. the very matrix the image warp takes: a small translation + shear
+    H_xy = np.array([[1.0, -0.008, -2.0], [0.01, 1.0, 3.0], [0.0, 0.0, 1.0]])
     d["thermal"]["image"] = utils.warp_perspective(d["optical"]["image"], H_xy)
     eye = torch.eye(3).repeat(B, 1, 1)
-    d["optical"]["homography"] = eye.clone(); d["thermal"]["homography"] = torch.from_numpy(H_yx).float().repeat(B, 1, 1)
+    d["optical"]["homography"] = eye.clone(); d["thermal"]["homography"] = torch.from_numpy(H_xy).float().repeat(B, 1, 1)
     config = {"prediction": {"nms": 4, "topk": 0, "cpu_nms": False, "detection_threshold": 0.015,
                              "matching": {"method": "bfmatcher", "knn_matches": False, "method_kwargs": {"crossCheck": True}}}}
     with torch.no_grad():

@@ -497,15 +497,10 @@ static int layernorm_impl(const float* x, float* y, const float* w, const float*
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
     const int C4 = C / 4;
 #define XP_LN_LAUNCH(LPR, NV) hipLaunchKernelGGL((layernorm_vec_kernel<LPR, NV, (NV == 1 ? 4 : 1)>), dim3(xp_cdiv(rows, 4 * (64 / LPR) * (NV == 1 ? 4 : 1))), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu)
-    // XP_LN_COVER=1 (A/B only): for the network's widths (96 / 192 / 384 channels = 24 / 48 / 96 float4s) LPR x 3 covers the row exactly — every lane active,
-    // three 16-byte loads in flight per lane: C = 96 54 -> 44 us (5.4 TB/s), 13 us per step in all.  NOT the default: it changes the order of the two row
-    // sums, i.e. the last bit of some outputs, and with it WHICH near-tied keypoints / matches agree with the reference run (the C3 rehearsal's
-    // CRC-identical pairs went 51 -> 49 of 56; every difference an attributed near-tie either way) — not worth 0.2 % of the step.
-    static const bool ln3 = getenv("XP_LN_COVER") && atoi(getenv("XP_LN_COVER"));
+    // (A lane mapping that covers 96 / 192 / 384-channel rows exactly — LPR x 3 — was measured in round 3: C = 96 54 -> 44 us, 13 us per step, but it changes the
+    // order of the two row sums, i.e. the last bit of some outputs and with it WHICH near-tied keypoints agree with the reference; removed in round 6 so that
+    // xp_layernorm and xp_layernorm_p32 cannot drift apart.)
     if (!vec) hipLaunchKernelGGL(layernorm_kernel, dim3(xp_cdiv(rows, 4)), dim3(256), 0, s, x, y, w, b, rows, C, eps, gelu);
-    else if (ln3 && C4 == 24) XP_LN_LAUNCH(8, 3);
-    else if (ln3 && C4 == 48) XP_LN_LAUNCH(16, 3);
-    else if (ln3 && C4 == 96) XP_LN_LAUNCH(32, 3);
     else if (C4 <= 4) XP_LN_LAUNCH(4, 1);
     else if (C4 <= 8) XP_LN_LAUNCH(8, 1);
     else if (C4 <= 16) XP_LN_LAUNCH(16, 1);

@@ -128,13 +128,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 template <int WM, int WN, int TM, int TN>
 void launch(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, TM, TN>;
-    static bool attr_set = false;
-    if (!attr_set && T::kLdsBytes > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
-        attr_set = true;
+    static XpPerDeviceOnce attr_once;
+    if (T::kLdsBytes > 64 * 1024 && attr_once.need()) {
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes));
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes));
     }
     dim3 grid(xp_cdiv(p.N, T::BN) * xp_cdiv(p.M, T::BM));
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;

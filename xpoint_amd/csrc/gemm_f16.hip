@@ -267,11 +267,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BK == 64 ? 2 : 4) / (WM * WN > 4 ? 2
 template <int WM, int WN, int TM, int TN, int BK>
 void f16_launch(const F16Params& p, hipStream_t s) {
     using T = F16Tile<WM, WN, TM, TN, BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 0, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 1, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes);
-        attr_set = true;
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 0, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes));
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<WM, WN, TM, TN, 1, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes));
     }
     const int grid = xp_cdiv(p.M, T::BM) * xp_cdiv(p.N, T::BN);
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;

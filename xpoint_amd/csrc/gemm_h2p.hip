@@ -248,10 +248,9 @@ bool xp_gemm_h2p_applies(const GemmParams& p) {
 }
 
 int xp_gemm_h2p_launch(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS));
-        attr_set = true;
     }
     const int grid = xp_cdiv(p.M, P_BM) * xp_cdiv(p.N, P_BN);
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;

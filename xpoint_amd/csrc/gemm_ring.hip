@@ -21,8 +21,8 @@ namespace {
 template <int GM, int GN, int TM, int TN, int PL, int S>
 void ring_launch(const RingParams& p, hipStream_t s, const char* name, double flops, double bytes) {
     using T = RingTile<GM, GN, TM, TN, PL, S>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ring_gemm_kernel<GM, GN, TM, TN, PL, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes); attr = true; }
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&ring_gemm_kernel<GM, GN, TM, TN, PL, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::kLdsBytes));
     const int grid = xp_cdiv(p.M, T::BM) * xp_cdiv(p.N, T::BN);
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     std::string tag = std::string(name) + "_" + std::to_string(T::BM) + "x" + std::to_string(T::BN);

@@ -704,13 +704,12 @@ template <int KSD>
 static void mt_launch(const GramParams& g, const float* d1, const float* d2, int D, int pairs, int kind, hipStream_t s) {
     constexpr int ROWB = mt_rowb(KSD);
     constexpr size_t kLds = 2 * (size_t)MT_TILE * ROWB + 16 + 4 * MT_QCAP + 4 * MT_STRIP;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        attr_set = true;
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_gram_kernel<KSD, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
     }
     const int rowsmax = g.rows1P > g.rows2P ? g.rows1P : g.rows2P;
     hipLaunchKernelGGL(match_convert_kernel<KSD>, dim3(xp_cdiv(rowsmax, 4), pairs, 2), dim3(256), 0, s, d1, d2, g.counts, g.cnt_stride, g.which1, g.which2,

@@ -267,10 +267,9 @@ __global__ __launch_bounds__(256, C <= 96 ? XP_MLP16_WG96 : XP_MLP16_WG192) void
 template <int C>
 int mlp16_launch(const Mlp16Params& p, hipStream_t s) {
     using T = Mlp16Cfg<C>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        attr_set = true;
     }
     const std::string tag = std::string(p.ln_w ? "ln_mlp_fused_f16_c" : "mlp_fused_f16_c") + std::to_string(C);
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * C * 8.0 * C, 2.0 * 3.0 * p.M * C);
@@ -363,10 +362,9 @@ int lnproj16_launch(const LnProj16Params& p, hipStream_t s) {
     constexpr int SPA = C / 8 + 1;
     constexpr int A_IMG = (128 * SPA * 16 + 1023) / 1024 * 1024, W_IMG = (C * SPA * 16 + 1023) / 1024 * 1024;
     constexpr int LDS = A_IMG > W_IMG ? A_IMG : W_IMG;         // one region, three uses (see the kernel)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_proj_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     const std::string tag = "ln_proj_f16_c" + std::to_string(C);
     XpProfScope prof(tag.c_str(), s, 2.0 * p.M * C * (double)C, 2.0 * 2.0 * p.M * C);

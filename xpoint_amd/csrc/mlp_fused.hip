@@ -587,11 +587,10 @@ int launch_mlp_np(const MlpParams& p, hipStream_t s) {
     constexpr bool PRE = MODE == 1;
     using T = MlpTile<C, H2>;
     const size_t lds_bytes = 3 * (size_t)T::IMGP + (size_t)p.H4 * 4 * (H2 ? 2 : 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * T::IMGP + 4096 * 4 * (H2 ? 2 : 1));
-        attr_set = true;
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        XP_HIP_WARN(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, MODE, NP, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * T::IMGP + 4096 * 4 * (H2 ? 2 : 1)));
     }
     static const bool by_shape = getenv("XP_PROF_SHAPES") != nullptr;
     const char* eng = H2 ? "_h2_c" : "_x3_c";

@@ -933,11 +933,10 @@ static int box_nms_two_launch(const float* prob, float* out, void* workspace, in
                               int band_sweeps, hipStream_t s) {
     const NmsWs w = nms_ws(workspace, batch, H, W, cap);
     XpProfScope prof("box_nms", s, 0.0, 8.0 * (double)batch * H * W);   // 8*H*W bytes per image
-    static bool attr_set = false;
-    if (!attr_set) {
+    static XpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_FIN_LDS));
         XP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finish_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NMS_FIN_LDS));
-        attr_set = true;
     }
     const int wpr = xp_cdiv(W, 32);
     if (tab.reach == 6) hipLaunchKernelGGL(nms_localmax_kernel<6>, dim3(wpr, xp_cdiv(H, NMS_TH), batch), dim3(256), 0, s, prob, out, w.cand32, w.kept32, H, W, wpr, tab, min_prob);

@@ -999,6 +999,20 @@ extern "C" int xp_ss2d_core_set_mode(int mode) {
     return XP_OK;
 }
 
+// THE decision "does this per-image shape take the sequential (deep-stage) form" — the one copy of it: ss2d_core_impl, xp_ss2d_core_p32_supported and
+// xp_ss2d_core_f16_wants_f32_copies all call it, so the predicates the host plans with can never disagree with what the launch does.
+// Per-image quantities only (never the batch).  half_io: the fp16-storage class, which needs f32 copies of u / xdbl for this form (have_copies).
+static bool ss2d_takes_seq(int H, int W, int C, int R, bool half_io, bool have_copies) {
+    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
+    if (!(C <= 768 && C % 64 == 0)) return false;
+    switch (R) { case 2: case 4: case 6: case 8: case 12: case 16: case 24: case 48: break; default: return false; }
+    if (!half_io && xp_amp_value()) return false;          // the f32-container mixed-precision class: chunked form only (its dt rounding lives in step_vals)
+    const bool seq2 = seq_scan2_applies(R, H, W, C);
+    if (half_io && !(seq2 && have_copies)) return false;
+    const int mode = g_ss2d_mode.load();
+    return mode >= 0 ? mode != 0 : (seq2 && H * W <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL));
+}
+
 extern "C" size_t xp_ss2d_core_workspace_bytes(int batch, int H, int W, int C) {
     // P and S: (B, 2, nc, 2, C) each with the smallest chunk (T = 8) -> upper bound; + ya (B,H,W,C)
     const int64_t L = (int64_t)H * W;
@@ -1061,15 +1075,11 @@ static int ss2d_core_impl(const void* u, const void* xdbl, const float* u32, con
     // this path is measured on run >= 8 pairs per GPU; the wave-pipelined kernel (ss2d_seq_scan3) then removed the one-pair cost as well (965 -> 1 029 pairs/s,
     // above the chunked form's 1 022), and the bound went to 8 192: stage 2 of a 1024 x 1024 image (L = 4 096) through the pipelined kernel is +2.4 % on
     // config C4 at 4 pairs per call, +2 % at 2, +0.8 % at 1.  xp_ss2d_core_set_mode / XP_SS2D_SEQ force one form.
-    const int mode = g_ss2d_mode.load();
-    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
-    const bool seq2 = seq_scan2_applies(R, H, W, C);
-    // (the f32-container mixed-precision class always takes the chunked form: its dt rounding lives in step_vals; the fp16-storage class takes the
-    //  sequential form when the caller supplied f32 copies of u and xdbl — xp_ss2d_core_f16_wants_f32_copies says when it will)
-    bool seq = (!half_io && xp_amp_value()) ? false : (mode >= 0 ? mode != 0 : (seq2 && L <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL)));
-    if (half_io && !(seq2 && u32 && xdbl32)) seq = false;
-    XP_CHECK_ARG(!out_p32 || (seq && C <= 768 && C % 64 == 0 && !half_io), "%s: a P32 output exists for the sequential form only (xp_ss2d_core_p32_supported)", who);
-    if (seq && C <= 768 && C % 64 == 0) {
+    // (the f32-container mixed-precision class always takes the chunked form; the fp16-storage class takes the sequential form when the caller supplied f32
+    //  copies of u and xdbl — xp_ss2d_core_f16_wants_f32_copies says when it will)
+    const bool seq = ss2d_takes_seq(H, W, C, R, half_io, u32 && xdbl32);
+    XP_CHECK_ARG(!out_p32 || (seq && !half_io), "%s: a P32 output exists for the sequential form only (xp_ss2d_core_p32_supported)", who);
+    if (seq) {
         if (half_io) { p.u = u32; p.xdbl = xdbl32; }
         switch (R) {
             case 2: return launch_ss2d_seq<2>(p, workspace, s, half_io);
@@ -1105,13 +1115,7 @@ extern "C" int xp_ss2d_core_fwd(const float* u, const float* xdbl, const float* 
 
 // out_fmt 0: f32 rows (= xp_ss2d_core_fwd); 2: the P32 image of the result (the operand format of xp_gemm_nt_h2s: out_proj loads it by DMA) — only where the
 // sequential form runs (xp_ss2d_core_p32_supported, a per-image predicate)
-extern "C" int xp_ss2d_core_p32_supported(int H, int W, int C, int R) {
-    const int mode = g_ss2d_mode.load();
-    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
-    if (xp_amp_value() || !(C <= 768 && C % 64 == 0)) return 0;
-    switch (R) { case 2: case 4: case 6: case 8: case 12: case 16: case 24: case 48: break; default: return 0; }
-    return mode >= 0 ? (mode != 0) : (seq_scan2_applies(R, H, W, C) && H * W <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL));
-}
+extern "C" int xp_ss2d_core_p32_supported(int H, int W, int C, int R) { return ss2d_takes_seq(H, W, C, R, false, false) ? 1 : 0; }
 extern "C" int xp_ss2d_core_fwd_ex(const float* u, const float* xdbl, const float* wdt, const float* dt_bias,
                                    const float* A, const float* Ds, const float* ln_w, const float* ln_b, void* out, int out_fmt,
                                    float* workspace, size_t workspace_bytes, int batch, int H, int W, int C, int R,
@@ -1122,12 +1126,7 @@ extern "C" int xp_ss2d_core_fwd_ex(const float* u, const float* xdbl, const floa
 
 // Would xp_ss2d_core_fwd_f16 take the sequential (deep-stage) form for this per-image shape if it is given f32 copies of u and xdbl?  (A per-image
 // predicate like the f32 class's: never depends on the batch.)
-extern "C" int xp_ss2d_core_f16_wants_f32_copies(int H, int W, int C, int R) {
-    const int mode = g_ss2d_mode.load();
-    static const int max_l = getenv("XP_SS2D_SEQ_MAXL") ? atoi(getenv("XP_SS2D_SEQ_MAXL")) : -1;
-    if (!(seq_scan2_applies(R, H, W, C) && C <= 768 && C % 64 == 0)) return 0;
-    return mode >= 0 ? (mode != 0) : (H * W <= (max_l >= 0 ? max_l : XP_SS2D_SEQ_DEFAULT_MAXL));
-}
+extern "C" int xp_ss2d_core_f16_wants_f32_copies(int H, int W, int C, int R) { return ss2d_takes_seq(H, W, C, R, true, true) ? 1 : 0; }
 
 // The fast mixed-precision class's core: u (batch,H,W,C) and xdbl (batch*H*W, 4*(R+2)) are fp16, out is fp16 (= out_norm's f32 result cast to half,
 // VMamba.py:646); the scan state, softplus / exp and out_norm run in f32 (csms6s.py:47-67); the dt projection's output is rounded to fp16 before the f32

@@ -29,6 +29,13 @@ void xp_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+// the same check inside a void launch helper: the message is recorded, the launch that follows fails and XP_LAUNCH_CHECK at the caller returns the error
+#define XP_HIP_WARN(call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) xp_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
 #define XP_LAUNCH_CHECK()                                                                  \
     do {                                                                                   \
         hipError_t e__ = hipGetLastError();                                                \
@@ -48,6 +55,19 @@ private:
     bool active_;
     hipStream_t stream_;
     size_t index_ = 0;
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one "done" flag per device ordinal (a process that drives several GPUs
+// would otherwise launch with > 64 KB of dynamic LDS on the second device without the opt-in).  `static XpPerDeviceOnce once; if (once.need()) XP_HIP(...)`.
+struct XpPerDeviceOnce {
+    bool done[64] = {};
+    bool need() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;      // unknown device: set the attribute every time
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
 };
 
 static inline int xp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -43,7 +43,6 @@ static const XpKnob kXpKnobs[] = {
     {"XP_SCAN_V2", "selective_scan.hip", "force the second d_state = 1 operator-boundary scan kernel"},
     {"XP_SCAN_OLD_GEN", "selective_scan.hip", "1: the round-1 generic-N operator-boundary scan kernel"},
     // ---- glue / post-processing
-    {"XP_LN_COVER", "elementwise.hip", "1: LayerNorm lane mapping that covers 96 / 192 / 384-channel rows exactly (different sum order: moves near-ties)"},
     {"XP_NMS_SCHED", "postproc.hip", "NMS local-iteration schedule"},
     {"XP_NMS_SWEEP", "postproc.hip", "NMS sweep count"},
     {"XP_NMS_WIDE_ROUNDS", "postproc.hip", "wide suppression rounds ahead of the NMS finisher"},

@@ -187,6 +187,9 @@ class PairPipeline:
         self._capture_masked = None
 
     def run(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        """Input contract (also of capture() / the replay callable): optical and thermal are (B, 1, H, W) / (B, H, W) images of the SAME dtype —
+        float32 in [0, 1] (device-resident: staged by one kernel; host / pinned: copied), or uint8 gray 0..255 (a quarter of the PCIe bytes; divided by 255
+        on the device, the same f32 division the reference's loader does on the host).  A uint8 / float mix raises ValueError.  Masks: both or neither."""
         if (mask_optical is None) != (mask_thermal is None):
             raise ValueError("PairPipeline.run: pass both valid masks or neither")
         with torch.cuda.device(self.device):
@@ -259,7 +262,14 @@ class PairPipeline:
                                                        ptr(mask_thermal) if masked else None, ptr(self.mask_b[k]) if masked else None, n,
                                                        _lib.current_stream()), "xp_stage_pair_batch")
             return
-        if optical.dtype == torch.uint8 and thermal.dtype == torch.uint8 and optical.numel() == n and thermal.numel() == n:
+        if (optical.dtype == torch.uint8) != (thermal.dtype == torch.uint8):
+            # a uint8 image means "0..255 gray, divide by 255 on the device"; a float image means "already in [0, 1]".  One of each would put the two spectra
+            # on different scales without any error: refuse it
+            raise ValueError(f"PairPipeline: optical is {optical.dtype} and thermal is {thermal.dtype} — pass both images as uint8 (0..255, normalised on the "
+                             "device) or both as float32 in [0, 1]")
+        if optical.dtype == torch.uint8 and (optical.numel() != n or thermal.numel() != n):
+            raise ValueError(f"PairPipeline: uint8 images must hold exactly {self.B} x {H} x {W} pixels each (got {optical.numel()} and {thermal.numel()})")
+        if optical.dtype == torch.uint8:
             # 8-bit gray images (what a camera / decoder delivers): a quarter of the bytes over PCIe, gray / 255 on the device — the same f32 division the
             # reference's loader does on the host (xpoint/datasets/ImagePairDataset.py:254-274), so the staged images are the same bits
             if getattr(self, "_u8_b", None) is None:
