@@ -58,7 +58,9 @@ def test_bench_launcher_rccl_world():
     # and the counter numbers quoted in it are tied to what ran: source hash of this tree, stale flag (a missing / foreign summary is an error key)
     roof = out["roofline"]
     assert len(roof["kernel_source_hash"]) == 16
-    assert ("traffic_stale" in roof and roof["traffic_source_hash"]) or "traffic_error" in roof, roof
+    assert "traffic_stale" in roof or "traffic_error" in roof, roof          # (a summary written before round 6 has no hash: quoted, flagged stale)
+    if roof.get("traffic_source_hash") == roof["kernel_source_hash"]:
+        assert roof["traffic_stale"] is False
 
 
 def test_bench_hygiene_keys_and_fast_class_label():

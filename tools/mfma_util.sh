@@ -1,9 +1,9 @@
 #!/bin/bash
 # MFMA utilisation per kernel of one single-stream bench step: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
 cd /tmp; export TMPDIR=/tmp
-# XP_MFMA_UTIL_ARGS: extra bench.py arguments (e.g. "--precision-class amp16f"); XP_MFMA_UTIL_TAG: suffix of the output files
+# XP_MFMA_UTIL_OVERLAP=" ": keep the default multi-stream schedule (config c5: its streaming step needs it); XP_MFMA_UTIL_ARGS: extra bench.py arguments (e.g. "--precision-class amp16f"); XP_MFMA_UTIL_TAG: suffix of the output files
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAGSFX=${XP_MFMA_UTIL_TAG:+_$XP_MFMA_UTIL_TAG}; OUT=$R/gpurun_out/mfma_util$TAGSFX; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend --no-overlap --no-h2d $XP_MFMA_UTIL_ARGS > $OUT/p1.log 2>&1 || echo "pass failed: $(tail -2 $OUT/p1.log)"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-backend ${XP_MFMA_UTIL_OVERLAP:---no-overlap} --no-h2d $XP_MFMA_UTIL_ARGS > $OUT/p1.log 2>&1 || echo "pass failed: $(tail -2 $OUT/p1.log)"
 python3 - "$OUT" "$TAGSFX" "$R" > $R/gpurun_out/mfma_utilisation$TAGSFX.txt <<'PY'
 import collections, csv, glob, os, re, sys
 d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))

@@ -16,8 +16,20 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- p
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats4 -name "*kernel_stats.csv" | head -1) $OUT/c4_kernel_stats.csv
 cp $(find $OUT/stats5 -name "*kernel_stats.csv" | head -1) $OUT/c5_kernel_stats.csv
-python3 $R/tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_hbm_traffic.txt
+python3 $R/tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json c2 > $OUT/pmc_hbm_traffic.txt
 rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write
+# round 6: the C4 / C5 lines quote their OWN counters (per-configuration summaries, each stamped with the kernel-source hash: bench.py pmc_files / pmc_fields)
+for CF in c4 c5; do
+  EXTRA="--no-cpu-baseline --no-other-backend --no-h2d"; [ $CF = c4 ] && EXTRA="$EXTRA --no-overlap"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$CF -- python3 $R/bench.py --config $CF --steps 2 --warmup 1 $EXTRA > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$CF -- python3 $R/bench.py --config $CF --steps 2 --warmup 1 $EXTRA > /dev/null 2>&1
+  python3 $R/tools/pmc_summary.py $(find $OUT/fetch_$CF -name "*counter_collection.csv" | head -1) $(find $OUT/write_$CF -name "*counter_collection.csv" | head -1) $OUT/${CF}_pmc_traffic.json $CF > $OUT/${CF}_pmc_hbm_traffic.txt
+  cp $OUT/${CF}_pmc_traffic.json $R/profiles/pmc_traffic_$CF.json
+  OV="--no-overlap"; [ $CF = c5 ] && OV=" "
+  XP_MFMA_UTIL_OVERLAP="$OV" XP_MFMA_UTIL_ARGS="--config $CF" XP_MFMA_UTIL_TAG=$CF bash $R/tools/mfma_util.sh > /dev/null 2>&1
+  cp $R/gpurun_out/mfma_utilisation_$CF.txt $OUT/${CF}_mfma_utilisation.txt; cp $R/gpurun_out/pmc_mfma_$CF.json $OUT/${CF}_pmc_mfma.json; cp $R/gpurun_out/pmc_mfma_$CF.json $R/profiles/pmc_mfma_$CF.json
+  rm -rf $OUT/fetch_$CF $OUT/write_$CF
+done
 bash $R/tools/mfma_util.sh > /dev/null 2>&1
 cp $R/gpurun_out/mfma_utilisation.txt $OUT/
 cp $R/gpurun_out/pmc_mfma.json $OUT/; cp $R/gpurun_out/pmc_mfma.json $R/profiles/pmc_mfma.json
@@ -31,7 +43,7 @@ cp $R/gpurun_out/mfma_utilisation_amp16f.txt $OUT/amp16f_mfma_utilisation.txt; c
 cp $R/gpurun_out/pmc_mfma_amp16f.json $R/profiles/pmc_mfma_amp16f.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch16 -- python3 $R/bench.py --precision-class amp16f --steps 2 --warmup 1 $COMMON > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write16 -- python3 $R/bench.py --precision-class amp16f --steps 2 --warmup 1 $COMMON > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py $(find $OUT/fetch16 -name "*counter_collection.csv" | head -1) $(find $OUT/write16 -name "*counter_collection.csv" | head -1) $OUT/amp16f_pmc_traffic.json > $OUT/amp16f_pmc_hbm_traffic.txt
+python3 $R/tools/pmc_summary.py $(find $OUT/fetch16 -name "*counter_collection.csv" | head -1) $(find $OUT/write16 -name "*counter_collection.csv" | head -1) $OUT/amp16f_pmc_traffic.json amp16f > $OUT/amp16f_pmc_hbm_traffic.txt
 rm -rf $OUT/fetch16 $OUT/write16
 cp $OUT/amp16f_pmc_traffic.json $R/profiles/pmc_traffic_amp16f.json
 # the class's line again with its own counter files in place (roofline.traffic, frac_mfma_busy_pmc)
@@ -49,4 +61,7 @@ XP_BENCH_PCIE_PARTS=1 python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baselin
 cp $OUT/bench.json $OUT/bench_before_pmc.json
 cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/hip_event_breakdown.txt
+python3 $R/bench.py --config c4 --steps 30 --no-cpu-baseline > $OUT/c4_bench.json 2> $OUT/c4_hip_event_breakdown.txt
+python3 $R/bench.py --config c5 --steps 30 --no-cpu-baseline > $OUT/c5_bench.json 2> $OUT/c5_hip_event_breakdown.txt
+python3 $R/bench.py --config c5 --pairs 32 --steps 8 --no-cpu-baseline > $OUT/c5_32pairs_bench.json 2> /dev/null
 cat $OUT/bench.json; head -12 $OUT/kernel_stats.csv | cut -c1-200; head -20 $OUT/pmc_hbm_traffic.txt
