@@ -279,6 +279,8 @@ def self_launch(args):
     import signal
     import subprocess
     visible = visible_gpus()
+    if os.environ.get("XP_BENCH_REHEARSE_ON_ONE_GPU") == "1" and visible >= 1:
+        visible = args.gpus              # rehearsal of the N-rank code path on a 1-GPU box (see main): every rank shares GPU 0
     if visible < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {visible} visible on this node\n")
         raise SystemExit(3)
@@ -374,8 +376,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run bench.py unwrapped)")
+    # XP_BENCH_REHEARSE_ON_ONE_GPU=1: the N ranks of the job share GPU 0 and their collectives run over gloo on host tensors — a REHEARSAL of the N-rank
+    # code path (pair sharding, weight broadcast, gathers, the line's per-rank keys) on a box with one GPU; RCCL refuses two ranks on one device.
+    # The rates of such a run mean nothing and the line says so (tests/test_gpu_bench.py::test_bench_two_rank_rehearsal_on_one_gpu).
+    rehearse = os.environ.get("XP_BENCH_REHEARSE_ON_ONE_GPU") == "1" and world > 1
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = torch.device("cpu") if rehearse else dev          # where the tensors of the (few, untimed) collectives live
     # RCCL is initialised at EVERY world size (world 1 included: a single-rank communicator), so that the weight
     # broadcast and the result-header all-gather below run through the same code on 1 and on 8 GPUs
     import torch.distributed as dist
@@ -383,7 +392,9 @@ def main():
     try:
         if world == 1 and os.environ.get("XP_BENCH_NO_RCCL"):       # A/B knob: the timed region without a live communicator
             raise RuntimeError("XP_BENCH_NO_RCCL set")
-        if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+        if rehearse:
+            dist.init_process_group("gloo")
+        elif "MASTER_ADDR" in os.environ and "RANK" in os.environ:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
@@ -401,7 +412,10 @@ def main():
     net = models.XPoint(cfg).eval()
     net.gemm_mode = args.gemm if args.precision_class == "f32" else args.precision_class
     # shared "pretrained" weights: rank 0 packs, ONE RCCL broadcast over xGMI to the other ranks (no data-path collective)
-    blob = xdist.broadcast_weights(net, (lambda: synth.make_torch_state_dict(cfg)), src=0, device=dev)
+    blob = xdist.broadcast_weights(net, (lambda: synth.make_torch_state_dict(cfg)), src=0, device=coll_dev)
+    if rehearse:
+        net.set_weight_blob(blob.to(dev))
+        rccl["rehearsal"] = f"{world} ranks share ONE GPU, collectives over gloo on host tensors: a check of the N-rank code path only — the rates of this line mean nothing"
     if dist.is_initialized():
         rccl["rccl_ranks"] = dist.get_world_size()
         rccl["weight_blob_mb"] = round(blob.numel() * 4 / 1e6, 1)
@@ -671,18 +685,18 @@ def main():
         pipe.run(opt, thr, mo, mt)                                             # leave the buffers holding the headline inputs' results
         torch.cuda.synchronize()
     res = pipe.fetch()
-    per_rank = xdist.gather_floats(region_dt, device=dev) if dist.is_initialized() else [region_dt]
+    per_rank = xdist.gather_floats(region_dt, device=coll_dev) if dist.is_initialized() else [region_dt]
     # region r of the job = its slowest rank; the reported region = the median one
     job_dt = [max(per_rank[k][r] for k in range(len(per_rank))) for r in range(len(region_dt))]
     order = sorted(range(len(job_dt)), key=lambda r: job_dt[r])
     med = order[(len(order) - 1) // 2]
     dt = job_dt[med]
     rank_rates = [B * args.steps / per_rank[k][med] for k in range(len(per_rank))]
-    rank_cpus = xdist.gather_strings(str(pin.get("cpus")), device=dev) if dist.is_initialized() else [str(pin.get("cpus"))]
+    rank_cpus = xdist.gather_strings(str(pin.get("cpus")), device=coll_dev) if dist.is_initialized() else [str(pin.get("cpus"))]
     if dist.is_initialized():
         # fixed-size result headers of every rank's last step, all-gathered (the only other collective)
         hdr = xdist.gather_headers(first, len(res), sum(len(r["kp_optical"]) + len(r["kp_thermal"]) for r in res),
-                                   sum(len(r["match_q"]) for r in res), device=dev)
+                                   sum(len(r["match_q"]) for r in res), device=coll_dev)
         rccl["rank_headers"] = [dict(rank=i, first_pair=h[0], pairs=h[1], keypoints=h[2], matches=h[3]) for i, h in enumerate(hdr)]
 
     if rank == 0:

@@ -63,6 +63,33 @@ def test_bench_launcher_rccl_world():
         assert roof["traffic_stale"] is False
 
 
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """the first real N-GPU line must not be the thing that fails.  No multi-GPU node exists for this run, so the N-rank code path is
+    REHEARSED on the one GPU: two ranks (torch.distributed.run, started by bench.py itself) share GPU 0, their collectives run over gloo on host tensors
+    (RCCL refuses two ranks on one device) — pair sharding, the weight broadcast to a rank that never built the state dict, the gathers of the timed
+    regions / CPU masks / result headers, max-over-ranks timing, ONE JSON line with every key of the 1-GPU line.  Rates of this run mean nothing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["XP_BENCH_REHEARSE_ON_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-pairs", "1", "--no-other-backend", "--no-h2d"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and "rehearsal" in out and out["scaling"] == "weak"
+    hdr = out["rank_headers"]
+    assert [h["rank"] for h in hdr] == [0, 1] and [h["first_pair"] for h in hdr] == [0, 8] and all(h["pairs"] == 8 for h in hdr)
+    assert all(h["keypoints"] > 8 * 2 * 3000 and h["matches"] > 8 * 500 for h in hdr), hdr
+    assert hdr[0]["keypoints"] != hdr[1]["keypoints"]              # rank 1 ran ITS pairs (8..15), with weights it only ever received by broadcast
+    assert len(out["rank_cpu_affinity"]["cpus_per_rank"]) == 2
+    pr = out["per_rank_pairs_per_s"]
+    assert 0 < pr["min"] <= pr["max"] and out["value"] <= 2 * pr["min"] * 1.001      # whole-job value = all pairs / the SLOWEST rank's time
+    assert out["timed_regions"]["count"] == 5
+    assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] > 0 and out["weight_bcast_ms"] > 0
+    assert set(("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline")) <= set(out)
+
+
 def test_bench_hygiene_keys_and_fast_class_label():
     """The default line carries the rotating-input and sustained-region rates (with the shader clock) and the reduced-precision classes incl. amp16f; a
     `--precision-class amp16f` run labels itself as not the headline."""

@@ -60,6 +60,7 @@ static const XpKnob kXpKnobs[] = {
     {"XP_BENCH_DEPTH", "bench.py", "steps in flight of the alternating-encoder schedule (default 3)"},
     {"XP_BENCH_NO_PIN", "bench.py", "1: do not pin the rank to its GPU's NUMA CPUs"},
     {"XP_BENCH_NO_RCCL", "bench.py", "1: world 1 without a live RCCL communicator"},
+    {"XP_BENCH_REHEARSE_ON_ONE_GPU", "bench.py", "1: --gpus N on a 1-GPU box: the N ranks share GPU 0, collectives over gloo (code-path rehearsal of the N-rank line; rates meaningless)"},
     {"XP_BENCH_PCIE_PARTS", "bench.py", "1: print the parts of the streaming loop (profiles/r5_streaming_parts.txt)"},
 };
 static const int kXpKnobCount = (int)(sizeof(kXpKnobs) / sizeof(kXpKnobs[0]));
