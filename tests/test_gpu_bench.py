@@ -80,7 +80,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     hdr = out["rank_headers"]
     assert [h["rank"] for h in hdr] == [0, 1] and [h["first_pair"] for h in hdr] == [0, 8] and all(h["pairs"] == 8 for h in hdr)
     assert all(h["keypoints"] > 8 * 2 * 3000 and h["matches"] > 8 * 500 for h in hdr), hdr
-    assert hdr[0]["keypoints"] != hdr[1]["keypoints"]              # rank 1 ran ITS pairs (8..15), with weights it only ever received by broadcast
+    assert (hdr[0]["keypoints"], hdr[0]["matches"]) != (hdr[1]["keypoints"], hdr[1]["matches"])      # rank 1 ran ITS pairs (8..15), with weights it only ever received by broadcast
     assert len(out["rank_cpu_affinity"]["cpus_per_rank"]) == 2
     pr = out["per_rank_pairs_per_s"]
     assert 0 < pr["min"] <= pr["max"] and out["value"] <= 2 * pr["min"] * 1.001      # whole-job value = all pairs / the SLOWEST rank's time
