@@ -98,6 +98,22 @@ def test_warp_perspective_shapes_channels_batch_dsize_inverse(gpu_lib):
     assert got.dtype == np.uint8 and np.array_equal(got, ref)
 
 
+def test_checkerboard_visualization_matches_the_reference_recipe(gpu_lib):
+    """demo.py:222-234: warp the visible image by H into the other image's frame, composite in 50-pixel checker cells — against the same recipe evaluated
+    with the oracle's warp in numpy; other image of a different size than the visible one."""
+    from oracle import xpoint_oracle as xo
+    from xpoint_amd import utils
+    vis = _img("cbv", (120, 170), np.uint8); oth = _img("cbo", (130, 160), np.uint8)
+    M = _homography("projective", 120, 170)
+    got = utils.checkerboard_visualization(torch.from_numpy(vis).cuda(), torch.from_numpy(oth).cuda(), M).cpu().numpy()
+    warped = xo.warp_perspective(vis, M, (160, 130))
+    x, y = np.meshgrid(np.arange(160), np.arange(130))
+    ref = np.where(((x // 50) + (y // 50)) % 2, warped, oth)
+    assert got.shape == oth.shape and np.array_equal(got, ref)
+    with pytest.raises(ValueError):
+        utils.checkerboard_visualization(torch.from_numpy(vis).cuda().float(), torch.from_numpy(oth).cuda(), M)
+
+
 def test_warp_perspective_argument_errors(gpu_lib):
     import ctypes
     from xpoint_amd import _lib as L, utils

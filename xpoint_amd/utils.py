@@ -356,3 +356,17 @@ def warp_perspective(img, M, dsize=None, inverse_map=False, quantise_u8=False, d
     if shape_kind == 3:
         return out[0]
     return out.permute(0, 3, 1, 2) if (nchw1 and Cd == 1) else out
+
+
+def checkerboard_visualization(img_visible, img_other, H, cell_size=50):
+    """demo.py:222-234 `create_checkerboard_visualization`: the visible image warped into the other image's frame by H
+    (`cv2.warpPerspective(img_visible, H, (W, H))`), composited with the other image in a checkerboard of `cell_size`-pixel cells
+    (cells with odd (x // cell + y // cell) show the warped image).  img_* : (H, W) device tensors of one dtype (uint8 or float32); returns a
+    device tensor like img_other.  The warp is `warp_perspective`; the select is elementwise glue."""
+    if img_visible.dtype != img_other.dtype or img_other.dim() != 2 or img_visible.dim() != 2:
+        raise ValueError("checkerboard_visualization: two (H, W) images of the same dtype")
+    Ho, Wo = img_other.shape
+    warped = warp_perspective(img_visible, H, (Wo, Ho))
+    y = torch.arange(Ho, device=img_other.device)[:, None] // int(cell_size)
+    x = torch.arange(Wo, device=img_other.device)[None, :] // int(cell_size)
+    return torch.where(((x + y) % 2).bool(), warped, img_other)
