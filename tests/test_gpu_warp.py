@@ -114,6 +114,19 @@ def test_checkerboard_visualization_matches_the_reference_recipe(gpu_lib):
         utils.checkerboard_visualization(torch.from_numpy(vis).cuda().float(), torch.from_numpy(oth).cuda(), M)
 
 
+def test_warp_perspective_degenerate_sizes(gpu_lib):
+    """1 x 1 images, one-row / one-column destinations (OpenCV's block width then follows the height), a destination far larger than the source."""
+    from oracle import xpoint_oracle as xo
+    from xpoint_amd import utils
+    M = np.array([[1.02, 0.01, 0.4], [-0.02, 0.98, 0.3], [1e-4, 2e-4, 1.0]])
+    for (hs, ws), dsize in (((1, 1), (1, 1)), ((1, 1), (9, 7)), ((5, 300), (300, 1)), ((300, 5), (1, 300)), ((17, 23), (700, 3)), ((9, 9), (130, 15)), ((40, 30), (900, 600))):
+        for dtype in (np.uint8, np.float32):
+            img = _img(f"deg{hs}{ws}{dsize}", (hs, ws), dtype)
+            ref = xo.warp_perspective(img, M, dsize)
+            got = utils.warp_perspective(torch.from_numpy(img).cuda(), M, dsize).cpu().numpy()
+            assert got.shape == (dsize[1], dsize[0]) and np.array_equal(got, ref), ((hs, ws), dsize, dtype)
+
+
 def test_warp_perspective_argument_errors(gpu_lib):
     import ctypes
     from xpoint_amd import _lib as L, utils
