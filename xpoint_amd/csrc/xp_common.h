@@ -85,6 +85,8 @@ int xp_l2norm_rows_st(const float* x, float* y, int64_t rows, int C, float eps, 
 int xp_dense_products_value();
 // Dense-layer engine of the fused encoder (xp_set_dense_engine): 0 = x3 (split bf16), 1 = h2 (split fp16, three products).
 int xp_dense_engine_value();
+// Per-launch override of the split-fp16 engine inside xp_xpoint_forward (xp_set_dense_override): bit i = dense launch i runs on the split-bf16 planes.
+unsigned long long xp_dense_override_value();
 // Mixed-precision class (xp_set_amp_mode): 1 = every operation autocast would end in a half tensor rounds its output to fp16.
 int xp_amp_value();
 

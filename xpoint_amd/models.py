@@ -89,6 +89,7 @@ class XPoint(torch.nn.Module):
         if os.environ.get("XP_HONOR_MIXED_PRECISION", "0") not in ("", "0") and "XP_GEMM_MODE" not in os.environ:
             self.use_config_precision()
         self._h2_off = False
+        self._h2_mask = 0                 # dense launches of the forward that run on the x3 planes under the h2 engine (xp_set_dense_override)
         self._status: Dict[str, torch.Tensor] = {}
         # RegNet head beyond 256x256 (opt-in, NOT reference semantics: the reference's head only accepts 256x256 inputs, RegNet.py:38-52):
         # adaptive-average-pool the pooled cost-volume map to the 16x16 grid its FC layer was sized for (convmodels.regnet_forward)
@@ -194,6 +195,7 @@ class XPoint(torch.nn.Module):
         self._conv_impl = None
         self._regnet_w = None
         self._h2_off = False              # a new weight set gets the default engine back
+        self._h2_mask = 0
         return _LoadResult(missing, unexpected)
 
     def _bn_affine(self, pre, eps=1e-5):
@@ -293,6 +295,7 @@ class XPoint(torch.nn.Module):
         self._wsplit = None
         self._amp_w = {}                  # derived copies of the OLD weights (fp16-rounded blob, its split planes) must not survive a new blob
         self._h2_off = False              # and a new weight set gets the default engine back, as in load_state_dict
+        self._h2_mask = 0
         self._device = blob.device
 
     def to(self, device=None, *a, **k):
@@ -351,9 +354,59 @@ class XPoint(torch.nn.Module):
     _STATUS_BITS = ((1, "encoder output non-finite or beyond the dense engine's operand range"), (2, "non-finite heat-map logit"),
                     (4, "non-finite descriptor element"))
 
-    def handle_status(self, st: int, where: str, engine: str = None) -> bool:
-        """Host policy for a non-zero status: on the split-fp16 engine switch this weight set to "x3" (warning) and return True = the
-        caller re-runs; on any other engine the outputs are genuinely non-finite: raise.
+    N_DENSE_LAUNCHES = 47          # XP_DENSE_LAUNCHES of include/xpoint_hip.h (xp_set_dense_override numbering)
+    MAX_LOCALISED = 6              # more out-of-range launches than this: the whole weight set moves to "x3" as before
+
+    def engine_key(self) -> str:
+        """What distinguishes two forwards of this model arithmetically: the effective gemm_mode plus, on "h2", the per-launch override mask.  A pipeline
+        re-captures its graphs when this changes."""
+        m = self.effective_gemm_mode()
+        return f"h2+{self._h2_mask:x}" if (m == "h2" and self._h2_mask) else m
+
+    def _localise_range_trip(self, retry) -> bool:
+        """The range guard tripped on "h2".  Find the dense launches whose operands leave the fp16 range by BISECTION over the per-launch override mask
+        (xp_set_dense_override: launches >= k on the x3 planes; the forward is clean exactly when every offender is among them) and keep only THOSE on
+        x3 for this weight set — one layer re-routed instead of the whole weight set (−1 % instead of −23 %).  `retry()` re-runs the
+        caller's forward with the model's current settings, synchronises, reads and clears the status word and returns it.  True = a mask that runs
+        clean is installed (the caller re-runs once more to produce its results); False = nothing installed (genuinely non-finite, or more than
+        MAX_LOCALISED offenders): the caller falls back to "x3"."""
+        n = self.N_DENSE_LAUNCHES
+        full = (1 << n) - 1
+        keep = self._h2_mask
+
+        def run(mask):
+            self._h2_mask = mask
+            return retry()
+        try:
+            if keep and run(keep) == 0:          # another user of this model has localised the trip since these forwards were enqueued
+                return True
+            found = keep
+            if run(full) != 0:                   # every launch on x3 and still non-finite: not a range problem
+                self._h2_mask = keep
+                return False
+            for _ in range(self.MAX_LOCALISED):
+                lo, hi = 0, n                    # launches >= lo on x3: clean;  launches >= hi on x3: trips
+                while hi - lo > 1:
+                    mid = (lo + hi) // 2
+                    if run(found | (full & ~((1 << mid) - 1))) == 0:
+                        lo = mid
+                    else:
+                        hi = mid
+                found |= 1 << lo                 # launch `lo` on h2 trips, with every later launch on x3: an offender
+                if run(found) == 0:
+                    self._h2_mask = found
+                    return True
+            self._h2_mask = keep
+            return False
+        except Exception:
+            self._h2_mask = keep
+            raise
+
+    def handle_status(self, st: int, where: str, engine: str = None, retry=None) -> bool:
+        """Host policy for a non-zero status.  On the split-fp16 engine: with `retry` (a callable that re-runs the caller's forward and returns its
+        status) first try to LOCALISE the trip — keep the engine, send only the out-of-range launches to the x3 planes (_localise_range_trip; warning);
+        otherwise, or when that fails, switch this weight set to "x3" (warning).  Either way return True = the caller re-runs.  On any other engine the
+        outputs are genuinely non-finite: raise.
         engine: the engine the reporting forwards were ENQUEUED with (stream-ordered callers: a pipeline's steps in flight or its captured graphs) —
         default: the model's engine now.  A trip of forwards enqueued on "h2" is recoverable also when another caller has switched the model to
         "x3" in the meantime: no second switch, no second warning, the caller re-runs."""
@@ -364,6 +417,15 @@ class XPoint(torch.nn.Module):
         if eng == "h2":
             if self.gemm_mode == "h2" and not self._h2_off:
                 import warnings
+                if retry is not None:
+                    before = self._h2_mask
+                    if self._localise_range_trip(retry):
+                        if self._h2_mask != before:
+                            ids = [i for i in range(self.N_DENSE_LAUNCHES) if (self._h2_mask >> i) & 1]
+                            warnings.warn(f"xpoint_amd.XPoint ({where}): {what} on the split-fp16 dense engine (operands must stay below 65504); dense "
+                                          f"launch(es) {ids} of the forward now run on the split-bf16 planes for this weight set, every other layer stays on "
+                                          "'h2' (xp_set_dense_override)", RuntimeWarning, stacklevel=3)
+                        return True
                 warnings.warn(f"xpoint_amd.XPoint ({where}): {what} on the split-fp16 dense engine (operands must stay below 65504); "
                               "re-running on gemm_mode 'x3' (split-bf16, no range limit) and keeping it for this weight set", RuntimeWarning, stacklevel=3)
                 self._h2_off = True
@@ -390,7 +452,13 @@ class XPoint(torch.nn.Module):
                 st = int(word.item())
                 if st:
                     word.zero_()
-                    if self.handle_status(st, "forward"):
+
+                    def retry():
+                        self._forward_raw(images, want_prob, want_desc, want_logits, res if out is None else out, workspace, is_optical, status)
+                        v = int(word.item())
+                        word.zero_()
+                        return v
+                    if self.handle_status(st, "forward", retry=retry):
                         res = self._forward_raw(images, want_prob, want_desc, want_logits, res if out is None else out, workspace, is_optical, status)
                         st = int(word.item())
                         word.zero_()
@@ -525,11 +593,16 @@ class XPoint(torch.nn.Module):
         prev_amp = int(lib.xp_get_amp_mode())
         if int(amp) != prev_amp:
             _lib.call("xp_set_amp_mode", int(amp))
+        ovmask = self._h2_mask if mode == "h2" else 0          # launches of THIS weight set that left the fp16 range (handle_status)
+        if ovmask:
+            _lib.call("xp_set_dense_override", ovmask)
         try:
             _lib.check(lib.xp_xpoint_forward_ex(self._ctx, ptr(blob), wsplit, ptr(images), n, H, W, ptr(ws), ctypes.c_size_t(ws.numel()),
                                                 ptr(out["prob"]), ptr(out["desc_nhwc"]), ptr(out["enc_nhwc"]), ptr(out["logits_nhwc"]),
                                                 ptr(self.status_word(dev) if status is None else status), _lib.current_stream()), "xp_xpoint_forward_ex")
         finally:
+            if ovmask:
+                _lib.call("xp_set_dense_override", 0)
             if int(amp) != prev_amp:
                 _lib.call("xp_set_amp_mode", prev_amp)
             if nprod != prev:

@@ -464,6 +464,12 @@ class PairPipeline:
             self._h2_pending = True
         self._engine_enqueued = engine
 
+    def _handle_status_params(self):
+        if getattr(self, "_hs_params", None) is None:
+            import inspect
+            self._hs_params = set(inspect.signature(self.net.handle_status).parameters)
+        return self._hs_params
+
     def _settle_engine(self):
         """After a device-wide synchronisation: read and clear the forward status word.  Non-zero on the split-fp16 engine = an operand left
         the fp16 range: the model switches to "x3" for this weight set (warning), captured graphs are re-captured on it, and the latest call
@@ -481,7 +487,17 @@ class PairPipeline:
         # the same model has already switched it to "x3"); raises unless the h2 -> x3 switch applies
         pending = "h2" if getattr(self, "_h2_pending", False) else getattr(self, "_engine_enqueued", None)
         self._h2_pending = False
-        self.net.handle_status(st, "PairPipeline", pending)
+        retry = None
+        if self._last is not None:
+            def retry():          # the latest call's forward again (eager, from its staged inputs) on the model's current settings -> its status
+                self._encode(self._last[0], None, None)
+                torch.cuda.synchronize()
+                v = int(word.item())
+                word.zero_()
+                return v
+        # round 6: on "h2" the model first tries to LOCALISE the trip (only the out-of-range launches move to the x3 planes) before giving up the engine
+        self.net.handle_status(st, "PairPipeline", pending, **({"retry": retry} if retry is not None and "retry" in self._handle_status_params() else {}))
+        self._h2_pending = False                               # (the localisation's forwards were synchronised and read by retry())
         if self._graphs is not None:
             self._capture_graphs()
         if self._last is not None:
