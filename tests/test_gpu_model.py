@@ -680,13 +680,16 @@ def test_fp16_range_trip_is_localised_to_the_offending_launches(gpu_lib):
     sd = {k: v.clone() for k, v in synth.make_torch_state_dict(cfg).items()}
     sd["encoder.layers.2.blocks.0.norm2.weight"] *= 1.0e6
     fc1, fc2 = 1 + 5 * (2 * 2 + 0) + 3, 1 + 5 * (2 * 2 + 0) + 4            # launch numbers of stage 2 / block 0 fc1 and fc2 (include/xpoint_hip.h)
+    # fc1's operand is LN(x) * 1e6, fc2's the GELU of that; the block then adds ~1e5 to the residual stream, which goes un-normalised into the downsample
+    # convolution after stage 2 (launch 41 + 2): three offenders, found one by one
+    want = (1 << fc1) | (1 << fc2) | (1 << (41 + 2))
     with torch.no_grad():
         ref_net = _net(cfg, sd); ref_net.gemm_mode = "x3"
         ro, rt, _ = ref_net(data)
         net = _net(cfg, sd)
         with pytest.warns(RuntimeWarning, match="now run on the split-bf16 planes"):
             o, t, _ = net(data)
-        assert net.effective_gemm_mode() == "h2" and net._h2_mask == (1 << fc1) | (1 << fc2), hex(net._h2_mask)
+        assert net.effective_gemm_mode() == "h2" and net._h2_mask == want, hex(net._h2_mask)
         assert net.engine_key() == f"h2+{net._h2_mask:x}"
         for a, b in ((o["prob"], ro["prob"]), (t["prob"], rt["prob"]), (o["desc"], ro["desc"]), (t["desc"], rt["desc"])):
             assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) < 1e-4
@@ -712,7 +715,7 @@ def test_fp16_range_trip_is_localised_to_the_offending_launches(gpu_lib):
                 pipe.run(*args)
                 with pytest.warns(RuntimeWarning, match="now run on the split-bf16 planes"):
                     got = pipe.fetch()
-            assert net.effective_gemm_mode() == "h2" and net._h2_mask == (1 << fc1) | (1 << fc2)
+            assert net.effective_gemm_mode() == "h2" and net._h2_mask == want, hex(net._h2_mask)
             if eager is None:
                 eager = got
             assert torch.equal(got[0]["kp_optical"], eager[0]["kp_optical"]) and got[0]["match_q"].tolist() == eager[0]["match_q"].tolist()
@@ -727,7 +730,7 @@ def test_fp16_range_trip_is_localised_to_the_offending_launches(gpu_lib):
         clean = _net(cfg)
         c1, _, _ = clean(data)
         assert clean._h2_mask == 0
-        # rate at the bench size: pure h2 vs the same weights with the two launches re-routed (mask set by hand: the timing needs no trip)
+        # rate at the bench size: pure h2 vs the same weights with the three launches re-routed (mask set by hand: the timing needs no trip)
         Hb, Wb, Bb = 480, 640, 4
         cfgb = synth.xpoint_exp1_config(Hb, Wb)
         netb = _net(cfgb)
@@ -742,9 +745,9 @@ def test_fp16_range_trip_is_localised_to_the_offending_launches(gpu_lib):
                 netb.forward_raw(x, check=False)
             torch.cuda.synchronize()
             return 10 / (time.perf_counter() - t0)
-        r0 = rate(); netb._h2_mask = (1 << fc1) | (1 << fc2); r1 = rate(); netb._h2_mask = 0; r0b = rate()
+        r0 = rate(); netb._h2_mask = want; r1 = rate(); netb._h2_mask = 0; r0b = rate()
         netb._h2_off = True; rx = rate(); netb._h2_off = False
-        print(f"forward rate, {2 * Bb} images 480x640: h2 {r0:.1f} / {r0b:.1f}, two launches on x3 {r1:.1f} ({r1 / max(r0, r0b):.3f}), whole set on x3 {rx:.1f} ({rx / max(r0, r0b):.3f})")
+        print(f"forward rate, {2 * Bb} images 480x640: h2 {r0:.1f} / {r0b:.1f}, three launches on x3 {r1:.1f} ({r1 / max(r0, r0b):.3f}), whole set on x3 {rx:.1f} ({rx / max(r0, r0b):.3f})")
         assert r1 >= 0.93 * min(r0, r0b), (r0, r1, r0b)
 
 
