@@ -87,7 +87,15 @@ class StreamingRegistrationStep:
         st = int(word.item())
         if st:
             word.zero_()
-            if self.net_hm.handle_status(st, "StreamingRegistrationStep head"):
+
+            def retry():          # the head's forward again, eagerly, on the model's current settings -> its status (round 6: the trip is localised first)
+                with torch.cuda.device(self.pipe.device), torch.no_grad():
+                    self.net_hm.forward_raw(torch.cat([self.crop_o, self.crop_t], 0), want_prob=False, want_desc=False, check=False)
+                    torch.cuda.synchronize()
+                v = int(word.item())
+                word.zero_()
+                return v
+            if self.net_hm.handle_status(st, "StreamingRegistrationStep head", retry=retry):
                 with torch.cuda.device(self.pipe.device), torch.no_grad():
                     self.graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph):
