@@ -90,7 +90,8 @@ class StreamingRegistrationStep:
 
             def retry():          # the head's forward again, eagerly, on the model's current settings -> its status (round 6: the trip is localised first)
                 with torch.cuda.device(self.pipe.device), torch.no_grad():
-                    self.net_hm.forward_raw(torch.cat([self.crop_o, self.crop_t], 0), want_prob=False, want_desc=False, check=False)
+                    flags = [True] * self.B + [False] * self.B if self.net_hm.config['multispectral'] else None      # as predict_homography
+                    self.net_hm.forward_raw(torch.cat([self.crop_o, self.crop_t], 0), want_prob=False, want_desc=False, is_optical=flags, check=False)
                     torch.cuda.synchronize()
                 v = int(word.item())
                 word.zero_()
