@@ -627,6 +627,9 @@ int launch_mlp_pre(const MlpParams& p, hipStream_t s) {
                 return launch_mlp_np<C, (C == 192 ? 8 : 4), MODE, 3, true>(q, s);
             };
             const int round_rows = n_cu * 256;
+            // Small calls (round 6: the 256 x 256 crops of the C5 head, single pairs): when 256-row workgroups would occupy less than half of the CUs, 128-row
+            // (4-wave) workgroups fill twice as many and a workgroup's latency — the kernel's time at this size — is no longer (same bits: see above)
+            if (p.M <= round_rows / 2) return launch_mlp_np<C, 4, MODE, 3, true>(p, s);
             const int rem = p.M % round_rows;
             if (tail_split && p.M > round_rows && rem > 0 && rem <= round_rows / 2) {
                 MlpParams a = p, b = p;
