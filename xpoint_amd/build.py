@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
 
 
 def source_hash(csrc: str = CSRC, include: str = os.path.join(HERE, "..", "include")) -> str:
-    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.cpp, *.h, include/*.h; names + bytes, sorted).
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.cpp, *.h except the knob-description registry xp_knobs.h, include/*.h; names + bytes, sorted).
     Stored next to every PMC summary under profiles/ (tools/pmc_summary.py, tools/mfma_util.sh) and compared by bench.py: counter numbers
     quoted in a bench line that were collected on OTHER kernel sources are flagged `traffic_stale` / `frac_mfma_busy_pmc_stale`."""
     import hashlib
@@ -23,6 +23,8 @@ def source_hash(csrc: str = CSRC, include: str = os.path.join(HERE, "..", "inclu
     files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")) +
                    glob.glob(os.path.join(include, "*.h")))
     for f in files:
+        if os.path.basename(f) == "xp_knobs.h":      # the registry of knob DESCRIPTIONS: text, not kernel code
+            continue
         h.update(os.path.basename(f).encode()); h.update(b"\0")
         h.update(open(f, "rb").read()); h.update(b"\0")
     return h.hexdigest()[:16]

@@ -269,8 +269,11 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
     // Per-launch override (xp_set_dense_override, numbering in include/xpoint_hip.h): a launch whose bit is set runs on the split-bf16 planes although the
     // engine is split fp16 — how the host keeps ONE out-of-range layer from moving the whole weight set to x3.  Never for the mixed-precision classes.
     const unsigned long long ovmask = (h2 && !xp_amp_value()) ? xp_dense_override_value() : 0ull;
-    auto ov = [&](int id) { return ((ovmask >> id) & 1ull) != 0; };
-    auto blk = [&](int s, int j) { return 1 + 5 * (2 * s + j); };
+    auto ov = [&](int id) { return id >= 0 && id < 64 && ((ovmask >> id) & 1ull) != 0; };
+    // block numbering of the configured model (depths 2, 2, 2, 2): 1 + 5 (2 s + j).  Deeper configurations keep the scheme with the running block index
+    // clipped to 7, so late blocks share the last block's bits (a coarser override, still monotone for the host's bisection)
+    int block_index = 0;
+    auto blk = [&]() { const int b = block_index < 7 ? block_index : 7; ++block_index; return 1 + 5 * b; };
     // dense layers: the split-bf16 kernels when the caller passed split weights, else the exact-f32 MFMA kernels
     auto gemm = [&](const float* A, const std::string& w, float* C, const float* bias, const float* scale, const float* shift,
                     const float* res, int M, int N, int K, int lda, int ldc, int ldres, int act, int id) -> int {
@@ -312,7 +315,7 @@ extern "C" int xp_xpoint_forward_ex(void* ctx, const float* weights, const void*
             const bool fused_block = fuse_mlp && C <= fuse_max_c && c->pack_off(b) != (size_t)-1;
             // Stages 2 - 3 on the split-fp16 engine: the ring GEMM (csrc/gemm_ring.hip) takes its activation operand as a P32 image written by the producer
             // (LayerNorm, the SS2D out_norm, fc1's epilogue), so its K loop is DMA + matrix instructions only.  Per-layer predicates (N, K): never the batch.
-            const int id0 = blk(s, j);          // + 0 in_proj, + 1 x_proj, + 2 out_proj, + 3 fc1, + 4 fc2 (xp_set_dense_override)
+            const int id0 = blk();              // + 0 in_proj, + 1 x_proj, + 2 out_proj, + 3 fc1, + 4 fc2 (xp_set_dense_override)
             const bool ring_ok = wsplit && h2 && !amp && !fused_block;
             const bool ring_in = ring_ok && xp_gemm_nt_h2s_applies(C, C) && !ov(id0);
             const bool ring_out = ring_ok && xp_gemm_nt_h2s_applies(C, C) && !ov(id0 + 2) && xp_ss2d_core_p32_supported(sh.H[s], sh.W[s], C, R);
